@@ -1,0 +1,303 @@
+"""ORACLE - test infrastructure only.
+
+ctypes wrapper over oracle/liboracle.so (plain-C restatements, see mc_oracle.c
+and surs_oracle.c) plus numpy compositions of the encoder.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this; the
+product package (surs_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+
+
+class _McResult(C.Structure):
+    _fields_ = [("nverts", C.c_int), ("nfaces", C.c_int), ("verts", C.POINTER(C.c_float)),
+                ("faces", C.POINTER(C.c_int)), ("normals", C.POINTER(C.c_float)),
+                ("values", C.POINTER(C.c_float))]
+
+
+class _Mlp(C.Structure):
+    _fields_ = [("w", C.c_void_p * 5), ("b", C.c_void_p * 5), ("dims", C.c_int * 6)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_mc_lewiner.restype = C.c_int
+        _lib.orc_mc_lewiner.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(_McResult)]
+        _lib.orc_mc_free.argtypes = [C.POINTER(_McResult)]
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ marching cubes
+
+def marching_cubes_lewiner(volume, level):
+    """measure.marching_cubes_lewiner(volume, level) with the reference's defaults
+    (/root/reference/lib/mesh_util.py:40,45): returns verts f32 [V,3], faces i32 [F,3],
+    normals f32 [V,3], values f32 [V]; raises like scikit-image does."""
+    vol = _f32(volume)
+    if vol.ndim != 3:
+        raise ValueError("Input volume should be a 3D numpy array.")
+    if min(vol.shape) < 2:
+        raise ValueError("Input array must be at least 2x2x2.")
+    r = _McResult()
+    rc = lib().orc_mc_lewiner(_p(vol), vol.shape[0], vol.shape[1], vol.shape[2], float(level), C.byref(r))
+    if rc == 1:
+        raise ValueError("Surface level must be within volume data range.")
+    if rc == 2:
+        raise RuntimeError("No surface found at the given iso value.")
+    try:
+        nv, nf = r.nverts, r.nfaces
+        verts = np.ctypeslib.as_array(r.verts, shape=(nv, 3)).copy()
+        faces = np.ctypeslib.as_array(r.faces, shape=(nf, 3)).copy()
+        normals = np.ctypeslib.as_array(r.normals, shape=(nv, 3)).copy()
+        values = np.ctypeslib.as_array(r.values, shape=(nv,)).copy()
+    finally:
+        lib().orc_mc_free(C.byref(r))
+    return verts, faces, normals, values
+
+
+# ------------------------------------------------------------------ encoder primitives (NCHW, batch 1)
+
+def conv2d(x, w, b=None, stride=1):
+    x, w = _f32(x), _f32(w)
+    cin, h, wd = x.shape
+    cout, cin2, k, _ = w.shape
+    assert cin == cin2
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    y = np.empty((cout, ho, wo), np.float32)
+    bb = _f32(b) if b is not None else None
+    lib().orc_conv2d(_p(x), cin, h, wd, _p(w), _p(bb) if bb is not None else None, cout, k, stride, _p(y))
+    return y
+
+
+def group_norm(x, gamma, beta, groups=32, eps=1e-5):
+    x = _f32(x)
+    c, h, w = x.shape
+    y = np.empty_like(x)
+    g, b = _f32(gamma), _f32(beta)
+    lib().orc_group_norm(_p(x), c, h * w, groups, _p(g), _p(b), C.c_float(eps), _p(y))
+    return y
+
+
+def avg_pool2(x):
+    x = _f32(x)
+    c, h, w = x.shape
+    y = np.empty((c, h // 2, w // 2), np.float32)
+    lib().orc_avg_pool2(_p(x), c, h, w, _p(y))
+    return y
+
+
+def bicubic_up2(x, align_corners):
+    x = _f32(x)
+    c, h, w = x.shape
+    y = np.empty((c, 2 * h, 2 * w), np.float32)
+    lib().orc_bicubic_up2(_p(x), c, h, w, int(bool(align_corners)), _p(y))
+    return y
+
+
+def pixel_shuffle2(x):
+    """nn.PixelShuffle(2): out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w]  (SuRSSR_v3.py:111-115)"""
+    c4, h, w = x.shape
+    c = c4 // 4
+    return np.ascontiguousarray(x.reshape(c, 2, 2, h, w).transpose(0, 3, 1, 4, 2).reshape(c, 2 * h, 2 * w))
+
+
+def lrelu(x, slope):
+    return np.where(x > 0, x, np.float32(slope) * x).astype(np.float32)
+
+
+def relu(x):
+    return np.maximum(x, np.float32(0))
+
+
+# ------------------------------------------------------------------ encoder compositions
+
+def super_res(sd, img, residual=True, n_block=(2, 2, 2)):
+    """SuRSSR_v3.forward (/root/reference/lib/model/SuRSSR_v3.py:143-181), img [3,H,W].
+    Returns (img_SR, new2=feature_lr, new_fin=feature_hr)."""
+    P = "super_resolution."
+
+    def cv(name, x, stride=1):
+        return conv2d(x, sd[P + name + ".weight"], sd[P + name + ".bias"], stride)
+
+    def resblocks(i, x, nb):
+        for b in range(nb):
+            r = cv("body%d.%d.body.2" % (i, b), relu(cv("body%d.%d.body.0" % (i, b), x)))
+            x = r + x
+        return x
+
+    h = lrelu(cv("head.0", bicubic_up2(img, False)), 0.2)
+    feats = []
+    d = h
+    for i, nb in zip((1, 2, 3), n_block):
+        d = lrelu(cv("down%d.0" % i, d, 2), 0.2)
+        if residual:
+            d = resblocks(i, d, nb)
+        d = lrelu(cv("tail%d.0" % i, d), 0.2)
+        d = lrelu(cv("tail%d.2" % i, d), 0.2)
+        feats.append(d)
+    d1_f, d2_f, d3_f = feats
+    bo = lrelu(cv("bottleneck.0", d3_f), 0.2)
+    up1 = lrelu(pixel_shuffle2(lrelu(cv("bott2.0", np.concatenate([d3_f, bo], 0)), 0.2)), 0.2)
+    new2 = np.concatenate([d2_f, up1], 0)
+    up2 = lrelu(pixel_shuffle2(lrelu(cv("ups2.0", new2), 0.2)), 0.2)
+    new3 = np.concatenate([d1_f, up2], 0)
+    up3 = lrelu(pixel_shuffle2(lrelu(cv("ups3.0", new3), 0.2)), 0.2)
+    fin = np.concatenate([h, up3], 0)
+    new_fin = lrelu(cv("ups4.0", fin), 0.2)
+    img_sr = cv("last.2", lrelu(cv("last.0", new_fin), 0.2))
+    return img_sr, new2, new_fin
+
+
+def conv_block(sd, prefix, x):
+    """ConvBlock.forward, in_planes == out_planes (HGFilters.py:57-74)."""
+    o1 = conv2d(relu(group_norm(x, sd[prefix + "bn1.weight"], sd[prefix + "bn1.bias"])), sd[prefix + "conv1.weight"])
+    o2 = conv2d(relu(group_norm(o1, sd[prefix + "bn2.weight"], sd[prefix + "bn2.bias"])), sd[prefix + "conv2.weight"])
+    o3 = conv2d(relu(group_norm(o2, sd[prefix + "bn3.weight"], sd[prefix + "bn3.bias"])), sd[prefix + "conv3.weight"])
+    return np.concatenate([o1, o2, o3], 0) + x
+
+
+def hourglass(sd, prefix, depth, x):
+    """HourGlass._forward (HGFilters.py:96-117)."""
+
+    def fwd(level, inp):
+        up1 = conv_block(sd, prefix + "b1_%d." % level, inp)
+        low1 = conv_block(sd, prefix + "b2_%d." % level, avg_pool2(inp))
+        if level > 1:
+            low2 = fwd(level - 1, low1)
+        else:
+            low2 = conv_block(sd, prefix + "b2_plus_%d." % level, low1)
+        low3 = conv_block(sd, prefix + "b3_%d." % level, low2)
+        return up1 + bicubic_up2(low3, True)
+
+    return fwd(depth, x)
+
+
+def filter_lr(sd, feature_lr, n_stack=3, depth=2, taps=None):
+    """HGFilter.forward, down_type 'low_res', use_sigmoid False (HGFilters.py:183-206);
+    eval keeps only the last stack's output (SuRSNet.py:109-110)."""
+    P = "image_filter_lr."
+
+    def c1(name, x):
+        return conv2d(x, sd[P + name + ".weight"], sd[P + name + ".bias"])
+
+    x = conv_block(sd, P + "conv2.", feature_lr)
+    if taps is not None:
+        taps["conv2"] = x
+    previous = x
+    out = None
+    for i in range(n_stack):
+        hg = hourglass(sd, P + "m%d." % i, depth, previous)
+        ll = conv_block(sd, P + "top_m_%d." % i, hg)
+        ll = relu(group_norm(c1("conv_last%d" % i, ll), sd[P + "bn_end%d.weight" % i], sd[P + "bn_end%d.bias" % i]))
+        out = c1("l%d" % i, ll)
+        if taps is not None:
+            taps["hg%d" % i] = hg
+            taps["out%d" % i] = out
+        if i < n_stack - 1:
+            previous = previous + c1("bl%d" % i, ll) + c1("al%d" % i, out)
+    return out
+
+
+def filter_hr(sd, feature_hr):
+    """HGFilter.forward, down_type 'high_res': a single 1x1 conv (HGFilters.py:179-181)."""
+    return conv2d(feature_hr, sd["image_filter_hr.conv5.weight"], sd["image_filter_hr.conv5.bias"])
+
+
+# ------------------------------------------------------------------ point query
+
+def _mlp_struct(sd, prefix, keep):
+    m = _Mlp()
+    dims = [sd[prefix + "conv0.weight"].shape[1]]
+    for l in range(5):
+        w = _f32(sd[prefix + "conv%d.weight" % l].reshape(sd[prefix + "conv%d.weight" % l].shape[0], -1))
+        b = _f32(sd[prefix + "conv%d.bias" % l])
+        keep += [w, b]
+        m.w[l] = w.ctypes.data
+        m.b[l] = b.ctypes.data
+        dims.append(w.shape[0])
+    for i, d in enumerate(dims):
+        m.dims[i] = d
+    return m
+
+
+def query(sd, points, calib, feat_lr, feat_hr, load_size=1024, z_size=200.0, want_logits=False):
+    """query_mr + query_sr + get_preds (SuRSNet.py:131-187, BaseSuRSNet.py:80-85), one view.
+    points [3,N] f32, calib [4,4], feat_lr [C,H,W], feat_hr [C,H,W].  Returns (pred_hr, pred_lr[, logit_hr, logit_lr])."""
+    pts = _f32(points)
+    n = pts.shape[1]
+    cal = _f32(np.asarray(calib).reshape(-1)[:16])
+    fl, fh = _f32(feat_lr), _f32(feat_hr)
+    keep = []
+    mlr, mhr = _mlp_struct(sd, "mlp_lr.", keep), _mlp_struct(sd, "mlp_hr.", keep)
+    outs = [np.empty(n, np.float32) for _ in range(4)]
+    lib().orc_query(_p(pts), n, _p(cal), C.c_float(load_size // 2), C.c_float(z_size), _p(fl), fl.shape[0], fl.shape[1],
+                    fl.shape[2], _p(fh), fh.shape[0], fh.shape[1], fh.shape[2], C.byref(mlr), C.byref(mhr),
+                    _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]))
+    return tuple(outs) if want_logits else (outs[0], outs[1])
+
+
+def grid_points(res, b_min, b_max, i0=0, i1=None):
+    """Flat grid coordinates [3, i1-i0] as float32 (create_grid + eval_func cast: sdf.py:4-29, mesh_util.py:24)."""
+    rx, ry, rz = (res, res, res) if np.isscalar(res) else res
+    total = rx * ry * rz
+    i1 = total if i1 is None else i1
+    bmin = np.ascontiguousarray(b_min, np.float64)
+    bmax = np.ascontiguousarray(b_max, np.float64)
+    out = np.empty((3, i1 - i0), np.float32)
+    lib().orc_grid_points(rx, ry, rz, _p(bmin), _p(bmax), C.c_longlong(i0), C.c_longlong(i1), _p(out))
+    return out
+
+
+def coords_matrix(res, b_min, b_max):
+    """create_grid's index->world matrix (sdf.py:16-21)."""
+    rx, ry, rz = (res, res, res) if np.isscalar(res) else res
+    m = np.eye(4)
+    length = np.asarray(b_max, np.float64) - np.asarray(b_min, np.float64)
+    m[0, 0], m[1, 1], m[2, 2] = length[0] / rx, length[1] / ry, length[2] / rz
+    m[0:3, 3] = np.asarray(b_min, np.float64)
+    return m
+
+
+def reconstruction_dense(sd, feat_lr, feat_hr, calib, res, b_min, b_max, load_size=1024, z_size=200.0):
+    """reconstruction(..., use_octree=False): dense sweep + 2x Lewiner MC + index->world transform
+    (/root/reference/lib/mesh_util.py:8-49, lib/sdf.py:32-52).  Returns dict."""
+    pts = grid_points(res, b_min, b_max)
+    phr, plr = query(sd, pts, calib, feat_lr, feat_hr, load_size, z_size)
+    shape = (res, res, res)
+    sdf_hr, sdf_lr = phr.astype(np.float64).reshape(shape), plr.astype(np.float64).reshape(shape)
+    mat = coords_matrix(res, b_min, b_max)
+    out = {"sdf_hr": sdf_hr, "sdf_lr": sdf_lr, "mat": mat}
+    for tag, sdf in (("hr", sdf_hr), ("lr", sdf_lr)):
+        v, f, nrm, val = marching_cubes_lewiner(sdf, 0.5)
+        vw = (np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T
+        out["verts_" + tag], out["faces_" + tag] = vw, f
+    return out
+
+
+def num_threads():
+    return int(lib().orc_num_threads())

@@ -1,0 +1,191 @@
+"""Parameter inventory of SuRSNet and deterministic synthetic weights.
+
+`state_dict_spec(opt)` restates the reference's module tree as an ordered list of
+(key, shape, kind) so that `load_state_dict` can be strict about all 553 keys
+ without importing the reference:
+
+  SuRSNet.__init__           /root/reference/lib/model/SuRSNet.py:44-99
+  HGFilter / ConvBlock / HourGlass   lib/model/HGFilters.py:29-174
+  SuRSSR_v3 / ResBlock / MeanShift   lib/model/SuRSSR_v3.py:30-141, lib/model/common.py:14-42
+  SurfaceClassifier          lib/model/SurfaceClassifier.py:30-43
+
+`synthetic_state_dict` fills it from the counter-based PRNG (prng.py): the
+reference's init is normal(0, 0.02) on conv weights, zero bias, GroupNorm
+weight 1 / bias 0 (lib/net_util.py:99-132).  We use a zero-mean uniform with the
+same standard deviation for the encoder and a larger gain for the two MLPs
+(with pure 0.02 init the occupancy field sits in [0.447, 0.570] and never
+crosses the 0.5 level - SURVEY.md 8c-1); GroupNorm affine and biases get
+non-trivial values so that parity tests exercise them.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from . import prng
+
+
+def _convblock(prefix, cin, cout):
+    c2, c4 = cout // 2, cout // 4
+    out = [
+        (prefix + "conv1.weight", (c2, cin, 3, 3), "conv"),
+        (prefix + "conv2.weight", (c4, c2, 3, 3), "conv"),
+        (prefix + "conv3.weight", (c4, c4, 3, 3), "conv"),
+    ]
+    for name, c in (("bn1", cin), ("bn2", c2), ("bn3", c4), ("bn4", cin)):
+        out += [(prefix + name + ".weight", (c,), "gn_w"), (prefix + name + ".bias", (c,), "gn_b")]
+    if cin != cout:
+        # nn.Sequential(self.bn4, ReLU, Conv2d 1x1 no bias): bn4 shows up twice in the state dict
+        out += [(prefix + "downsample.0.weight", (cin,), "alias:" + prefix + "bn4.weight"),
+                (prefix + "downsample.0.bias", (cin,), "alias:" + prefix + "bn4.bias"),
+                (prefix + "downsample.2.weight", (cout, cin, 1, 1), "conv")]
+    return out
+
+
+def _hourglass(prefix, depth, feat):
+    out = []
+
+    def gen(level):
+        out.extend(_convblock(prefix + "b1_%d." % level, feat, feat))
+        out.extend(_convblock(prefix + "b2_%d." % level, feat, feat))
+        if level > 1:
+            gen(level - 1)
+        else:
+            out.extend(_convblock(prefix + "b2_plus_%d." % level, feat, feat))
+        out.extend(_convblock(prefix + "b3_%d." % level, feat, feat))
+
+    gen(depth)
+    return out
+
+
+def _conv(prefix, cout, cin, k, bias=True):
+    out = [(prefix + ".weight", (cout, cin, k, k), "conv")]
+    if bias:
+        out.append((prefix + ".bias", (cout,), "bias"))
+    return out
+
+
+def _gn(prefix, c):
+    return [(prefix + ".weight", (c,), "gn_w"), (prefix + ".bias", (c,), "gn_b")]
+
+
+def _hgfilter(prefix, n_stack, depth, in_ch, last_ch, down_type):
+    out = _conv(prefix + "conv1", 64, in_ch, 7) + _gn(prefix + "bn1", 64)
+    if down_type == "low_res":
+        out += _convblock(prefix + "conv2.", 256, 256)
+    elif down_type == "high_res":
+        out += _convblock(prefix + "conv2.", 64, 128)
+    else:
+        raise ValueError(down_type)
+    out += _convblock(prefix + "conv3.", 128, 128)
+    out += _convblock(prefix + "conv4.", 128, 256)
+    out += _conv(prefix + "conv5", 64, 64, 1)
+    for s in range(n_stack):
+        out += _hourglass(prefix + "m%d." % s, depth, 256)
+        out += _convblock(prefix + "top_m_%d." % s, 256, 256)
+        out += _conv(prefix + "conv_last%d" % s, 256, 256, 1)
+        out += _gn(prefix + "bn_end%d" % s, 256)
+        out += _conv(prefix + "l%d" % s, last_ch, 256, 1)
+        if s < n_stack - 1:
+            out += _conv(prefix + "bl%d" % s, 256, 256, 1)
+            out += _conv(prefix + "al%d" % s, 256, last_ch, 1)
+    return out
+
+
+def _sr(prefix, n_block):
+    out = [(prefix + "sub_mean.weight", (3, 3, 1, 1), "meanshift_w"),
+           (prefix + "sub_mean.bias", (3,), "meanshift_b-"),
+           (prefix + "add_mean.weight", (3, 3, 1, 1), "meanshift_w"),
+           (prefix + "add_mean.bias", (3,), "meanshift_b+")]
+    out += _conv(prefix + "head.0", 32, 3, 3)
+
+    def stage(i, cin, cout, nb):
+        o = _conv(prefix + "down%d.0" % i, cin, cin, 3)
+        for b in range(nb):
+            o += _conv(prefix + "body%d.%d.body.0" % (i, b), cin, cin, 3)
+            o += _conv(prefix + "body%d.%d.body.2" % (i, b), cin, cin, 3)
+        o += _conv(prefix + "tail%d.0" % i, cin, cin, 3)
+        o += _conv(prefix + "tail%d.2" % i, cout, cin, 3)
+        return o
+
+    out += stage(1, 32, 64, n_block[0])
+    out += stage(2, 64, 128, n_block[1])
+    out += stage(3, 128, 256, n_block[2])
+    out += _conv(prefix + "bottleneck.0", 256, 256, 3)
+    out += _conv(prefix + "bott2.0", 512, 512, 3)
+    out += _conv(prefix + "ups2.0", 256, 256, 3)
+    out += _conv(prefix + "ups3.0", 128, 128, 3)
+    out += _conv(prefix + "ups4.0", 64, 64, 3)
+    out += _conv(prefix + "last.0", 32, 64, 3)
+    out += _conv(prefix + "last.2", 3, 32, 3)
+    return out
+
+
+def _mlp(prefix, dims, res_layers, no_residual):
+    out = []
+    for l in range(len(dims) - 1):
+        cin = dims[l] + (dims[0] if (not no_residual and l in res_layers) else 0)
+        out.append((prefix + "conv%d.weight" % l, (dims[l + 1], cin, 1), "mlp"))
+        out.append((prefix + "conv%d.bias" % l, (dims[l + 1],), "mlp_bias"))
+    return out
+
+
+def state_dict_spec(opt):
+    """Ordered [(key, shape, kind)] identical to reference SuRSNet(opt).state_dict()."""
+    spec = []
+    spec += _hgfilter("image_filter_lr.", opt.num_stack_lr, opt.hg_depth, 256, opt.hg_dim, "low_res")
+    spec += _hgfilter("image_filter_hr.", opt.num_stack_hr, opt.hg_depth, 64, opt.hg_dim, "high_res")
+    spec += _sr("super_resolution.", list(opt.n_block))
+    spec += _mlp("mlp_lr.", list(opt.mlp_dim_lr), list(opt.mlp_res_layers_lr), opt.no_residual)
+    spec += _mlp("mlp_hr.", list(opt.mlp_dim_hr), list(opt.mlp_res_layers_hr), opt.no_residual)
+    return spec
+
+
+_SQRT3 = 3.0 ** 0.5
+
+
+def synthetic_state_dict(opt, seed=0, enc_gain=0.02, mlp_gain=0.06):
+    """Deterministic weights as numpy float32 arrays, keyed like the reference."""
+    sd = OrderedDict()
+    for key, shape, kind in state_dict_spec(opt):
+        if kind.startswith("alias:"):
+            sd[key] = sd[kind[6:]]
+            continue
+        if kind == "conv":
+            a = enc_gain * _SQRT3
+            v = prng.uniform(key, seed, shape, -a, a)
+        elif kind == "bias":
+            v = prng.uniform(key, seed, shape, -0.05, 0.05)
+        elif kind == "gn_w":
+            v = prng.uniform(key, seed, shape, 0.7, 1.3)
+        elif kind == "gn_b":
+            v = prng.uniform(key, seed, shape, -0.1, 0.1)
+        elif kind == "mlp":
+            a = mlp_gain * _SQRT3
+            v = prng.uniform(key, seed, shape, -a, a)
+        elif kind == "mlp_bias":
+            v = prng.uniform(key, seed, shape, -0.1, 0.1)
+        elif kind == "meanshift_w":
+            v = np.eye(3, dtype=np.float32).reshape(3, 3, 1, 1)
+        elif kind in ("meanshift_b-", "meanshift_b+"):
+            sign = -1.0 if kind.endswith("-") else 1.0
+            v = (sign * opt.rgb_range * np.array([0.4488, 0.4371, 0.4040], np.float32)).astype(np.float32)
+        else:
+            raise ValueError(kind)
+        sd[key] = np.ascontiguousarray(v, dtype=np.float32)
+    return sd
+
+
+def synthetic_image(h, w=None, seed=1):
+    """[1,3,H,W] float32 in [-1,1] times a centred rectangular mask
+    (rows H/8..7H/8, cols W/4..3W/4): the output contract of
+    EvalDataset_LR_v2.get_render (/root/reference/lib/data/EvalDataset_LR_v2.py:239-243)."""
+    w = h if w is None else w
+    img = prng.uniform("synthetic_image", seed, (1, 3, h, w), -1.0, 1.0)
+    mask = np.zeros((1, 1, h, w), np.float32)
+    mask[:, :, h // 8: 7 * h // 8, w // 4: 3 * w // 4] = 1.0
+    return (img * mask).astype(np.float32)
+
+
+def synthetic_points(n, seed=2, lo=-0.55, hi=0.55):
+    """[3,N] float32 points; about 17 % fall outside the image for +-0.55."""
+    return prng.uniform("synthetic_points", seed, (3, n), lo, hi)
