@@ -11,10 +11,10 @@
 
 `synthetic_state_dict` fills it from the counter-based PRNG (prng.py): the
 reference's init is normal(0, 0.02) on conv weights, zero bias, GroupNorm
-weight 1 / bias 0 (lib/net_util.py:99-132).  We use a zero-mean uniform with the
-same standard deviation for the encoder and a larger gain for the two MLPs
-(with pure 0.02 init the occupancy field sits in [0.447, 0.570] and never
-crosses the 0.5 level - SURVEY.md 8c-1); GroupNorm affine and biases get
+weight 1 / bias 0 (lib/net_util.py:99-132).  With that init the occupancy field
+sits in [0.447, 0.570] and barely crosses the 0.5 level and
+activations shrink layer by layer, so we use a zero-mean uniform with a
+fan-in scaled standard deviation instead; GroupNorm affine and biases get
 non-trivial values so that parity tests exercise them.
 """
 from collections import OrderedDict
@@ -143,15 +143,21 @@ def state_dict_spec(opt):
 _SQRT3 = 3.0 ** 0.5
 
 
-def synthetic_state_dict(opt, seed=0, enc_gain=0.02, mlp_gain=0.06):
-    """Deterministic weights as numpy float32 arrays, keyed like the reference."""
+def synthetic_state_dict(opt, seed=0, enc_gain=0.6, mlp_gain=1.0):
+    """Deterministic weights as numpy float32 arrays, keyed like the reference.
+
+    Conv / MLP weights are zero-mean uniform with std = gain * sqrt(2 / fan_in) (gain 0.6 for the
+    encoder convolutions, whose residual/concat structure otherwise doubles the scale per stage) so that every
+    layer's output is O(1) (parity tests then see every layer at full sensitivity and the
+    occupancy field straddles the 0.5 level)."""
     sd = OrderedDict()
     for key, shape, kind in state_dict_spec(opt):
         if kind.startswith("alias:"):
             sd[key] = sd[kind[6:]]
             continue
-        if kind == "conv":
-            a = enc_gain * _SQRT3
+        if kind in ("conv", "mlp"):
+            fan_in = int(np.prod(shape[1:]))
+            a = (enc_gain if kind == "conv" else mlp_gain) * (2.0 / fan_in) ** 0.5 * _SQRT3
             v = prng.uniform(key, seed, shape, -a, a)
         elif kind == "bias":
             v = prng.uniform(key, seed, shape, -0.05, 0.05)
@@ -159,9 +165,6 @@ def synthetic_state_dict(opt, seed=0, enc_gain=0.02, mlp_gain=0.06):
             v = prng.uniform(key, seed, shape, 0.7, 1.3)
         elif kind == "gn_b":
             v = prng.uniform(key, seed, shape, -0.1, 0.1)
-        elif kind == "mlp":
-            a = mlp_gain * _SQRT3
-            v = prng.uniform(key, seed, shape, -a, a)
         elif kind == "mlp_bias":
             v = prng.uniform(key, seed, shape, -0.1, 0.1)
         elif kind == "meanshift_w":

@@ -1,0 +1,84 @@
+"""Pins oracle.query / oracle encoder / oracle reconstruction against outputs of the reference
+itself (tests/golden/*.npz, made by tools/gen_golden.py in the build container)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle
+from surs_amd import weights
+
+
+def test_state_dict_spec_matches_reference(golden_dir):
+    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
+    spec = weights.state_dict_spec(common.opt())
+    assert [[k, list(s)] for k, s, _ in spec] == keys
+    assert len(keys) == 553
+    assert sum(int(np.prod(s)) for _, s, _ in spec) == 23674400
+
+
+def test_query_random_points(golden_dir):
+    g = np.load(os.path.join(golden_dir, "query.npz"))
+    fl, fh = common.synth_features()
+    pts = weights.synthetic_points(50000, seed=2)
+    phr, plr, lhr, llr = oracle.query(common.state_dict(), pts, common.CALIB, fl, fh, 1024, 200.0, want_logits=True)
+    assert np.abs(phr - g["a_pred_hr"]).max() < 1e-5
+    assert np.abs(plr - g["a_pred_lr"]).max() < 1e-5
+    assert np.abs(lhr - g["a_logit_hr"]).max() < 2e-5
+    assert np.abs(llr - g["a_logit_lr"]).max() < 2e-5
+    assert ((phr == 0) == (g["a_pred_hr"] == 0)).all()  # the in-image mask
+
+
+def test_query_general_calib_and_edges(golden_dir):
+    g = np.load(os.path.join(golden_dir, "query.npz"))
+    fl, fh = common.synth_features()
+    pts = weights.synthetic_points(4099, seed=5)
+    phr, plr, lhr, llr = oracle.query(common.state_dict(), pts, g["b_calib"], fl, fh, 1024, 200.0, want_logits=True)
+    assert np.abs(phr - g["b_pred_hr"]).max() < 2e-5 and np.abs(plr - g["b_pred_lr"]).max() < 2e-5
+    assert np.abs(lhr - g["b_logit_hr"]).max() < 1e-4
+    phr, plr = oracle.query(common.state_dict(), g["c_points"], common.CALIB, fl, fh, 1024, 200.0)
+    assert np.abs(phr - g["c_pred_hr"]).max() < 1e-5 and np.abs(plr - g["c_pred_lr"]).max() < 1e-5
+    assert phr[5] == 0 and phr[6] == 0 and phr[0] > 0  # just outside -> 0, exactly on the border -> inside
+
+
+@pytest.mark.parametrize("H", [64, 96])
+def test_encoder(H, golden_dir):
+    g = np.load(os.path.join(golden_dir, "encoder_h%d.npz" % H))
+    sd = common.state_dict()
+    img = weights.synthetic_image(H, seed=1)[0]
+    img_sr, f_lr, f_hr = oracle.super_res(sd, img)
+    im_hr = oracle.filter_hr(sd, f_hr)
+    taps = {}
+    im_lr = oracle.filter_lr(sd, f_lr, taps=taps)
+    s2, s4 = (lambda a: a[..., ::2, ::2]), (lambda a: a[..., ::4, ::4])
+    tol = 2e-5
+    assert common.rel_err(s2(img_sr), g["img_sr_sub"]) < tol
+    assert common.rel_err(f_lr if H == 64 else s2(f_lr), g["feature_lr"]) < tol
+    assert common.rel_err(s4(f_hr), g["feature_hr_sub"]) < tol
+    assert common.rel_err(f_hr.mean((1, 2)), g["feature_hr_mean"]) < tol
+    assert common.rel_err(np.abs(f_hr).max((1, 2)), g["feature_hr_absmax"]) < tol
+    assert common.rel_err(im_lr if H == 64 else s2(im_lr), g["im_feat_lr"]) < tol
+    assert common.rel_err(s4(im_hr), g["im_feat_hr_sub"]) < tol
+    for k, v in taps.items():
+        assert common.rel_err(s2(v), g["tap_%s_sub" % k]) < tol, k
+
+
+@pytest.mark.parametrize("R", [32, 48])
+def test_reconstruction_dense(R, golden_dir):
+    g = np.load(os.path.join(golden_dir, "recon_r%d.npz" % R))
+    sd = common.state_dict()
+    img = weights.synthetic_image(64, seed=1)[0]
+    _, f_lr, f_hr = oracle.super_res(sd, img)
+    im_hr, im_lr = oracle.filter_hr(sd, f_hr), oracle.filter_lr(sd, f_lr)
+    out = oracle.reconstruction_dense(sd, im_lr, im_hr, common.CALIB, R, [-0.5] * 3, [0.5] * 3)
+    assert np.abs(out["sdf_hr"] - g["sdf_hr"]).max() < 2e-5
+    assert np.abs(out["sdf_lr"] - g["sdf_lr"]).max() < 2e-5
+    # mesh stage on the reference's own field: indices bit-exact, world vertices exact
+    mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)
+    for tag in ("hr", "lr"):
+        v, f, _, _ = oracle.marching_cubes_lewiner(g["sdf_" + tag].astype(np.float64), 0.5)
+        vw = (np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T
+        assert np.array_equal(f, g["faces_" + tag])
+        assert np.array_equal(vw, g["verts_" + tag])

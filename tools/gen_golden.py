@@ -1,0 +1,180 @@
+"""Generate golden vectors by running the upstream reference itself on CPU.
+
+Build-container only: imports /root/reference through tools/ref_harness.py
+(stub modules for the packages this image lacks) and writes small fixtures to
+tests/golden/.  Inputs (weights, images, points, synthetic features) come from
+the counter-based PRNG in surs_amd.prng, so the fixtures hold only the
+reference's OUTPUTS plus the seeds/flags that produced them.
+
+    python tools/gen_golden.py [query] [encoder] [recon] [keys] [octree]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_harness as rh  # noqa: E402
+from surs_amd import options, prng, weights  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+FLAGS = ["--loadSize", "1024", "--residual", "--b_min", "-0.5", "-0.5", "-0.5", "--b_max", "0.5", "0.5", "0.5",
+         "--num_samples", "50000", "--z_size", "200"]
+CALIB = np.diag([2.0, -2.0, 2.0, 1.0]).astype(np.float32)  # gen_mesh: lib/train_util.py:63-67
+
+
+def make_net(seed=0):
+    opt_ref = rh.parse_opt(FLAGS)
+    net = rh.build_net(opt_ref)
+    opt = options.BaseOptions().parse(FLAGS)
+    sd = weights.synthetic_state_dict(opt, seed=seed)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    return net, opt_ref, sd
+
+
+def run_query(net, pts, calib):
+    """query_mr + query_sr + get_preds with logits captured at mlp_*.conv4."""
+    cap = {}
+    h1 = net.mlp_lr.conv4.register_forward_hook(lambda m, i, o: cap.__setitem__("lr", o.detach().clone()))
+    h2 = net.mlp_hr.conv4.register_forward_hook(lambda m, i, o: cap.__setitem__("hr", o.detach().clone()))
+    p = torch.from_numpy(pts[None].copy())
+    c = torch.from_numpy(calib[None].copy())
+    with torch.no_grad(), rh.quiet():
+        net.query_mr(p, c)
+        net.query_sr(p, c)
+        phr, plr = net.get_preds()
+    h1.remove(); h2.remove()
+    return (phr[0, 0].numpy(), plr[0, 0].numpy(), cap["hr"][0, 0].numpy(), cap["lr"][0, 0].numpy())
+
+
+def synth_features(seed=3, hl=32, hh=128):
+    fl = prng.uniform("feat_lr", seed, (256, hl, hl), -1.0, 1.0)
+    fh = prng.uniform("feat_hr", seed, (64, hh, hh), -1.0, 1.0)
+    return fl, fh
+
+
+def gen_keys():
+    net, opt_ref, sd = make_net()
+    ref_sd = net.state_dict()
+    keys = [[k, list(v.shape)] for k, v in ref_sd.items()]
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("keys", len(keys))
+
+
+def gen_query():
+    net, opt_ref, sd = make_net()
+    fl, fh = synth_features()
+    net.im_feat_list_lr = [torch.from_numpy(fl[None].copy())]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None].copy())]
+    out = {}
+    # (a) 50k random points in [-0.55,0.55]^3 with gen_mesh's calib (about 17 % outside the image)
+    pts = weights.synthetic_points(50000, seed=2)
+    phr, plr, lhr, llr = run_query(net, pts, CALIB)
+    out.update(a_pred_hr=phr, a_pred_lr=plr, a_logit_hr=lhr, a_logit_lr=llr)
+    print("query a: pred_hr range", phr.min(), phr.max(), "pred_lr", plr.min(), plr.max(),
+          "outside frac", float((phr == 0).mean()))
+    # (b) general calib (rotation + translation, X/Y depend on z), 4099 points (ragged vs 64-point tiles)
+    calib_b = np.array([[1.7, 0.3, -0.2, 0.05], [0.25, -1.8, 0.15, -0.04], [0.1, 0.2, 1.9, 0.02], [0, 0, 0, 1]],
+                       np.float32)
+    pts_b = weights.synthetic_points(4099, seed=5)
+    phr, plr, lhr, llr = run_query(net, pts_b, calib_b)
+    out.update(b_calib=calib_b, b_pred_hr=phr, b_pred_lr=plr, b_logit_hr=lhr, b_logit_lr=llr)
+    # (c) edge cases: exactly on the image border (closed interval), just outside, centre, corners
+    e = 0.5
+    pts_c = np.array([[e, -e, 0, e, -e, 0.5000001, 0.0, 0.25, -0.5, 0.5],
+                      [e, -e, 0, -e, e, 0.0, -0.5000001, 0.5, 0.5, -0.5],
+                      [0.1, -0.2, 0, 0.3, -0.4, 0.0, 0.2, -0.5, 0.5, 0.0]], np.float32)
+    phr, plr, lhr, llr = run_query(net, pts_c, CALIB)
+    out.update(c_points=pts_c, c_pred_hr=phr, c_pred_lr=plr, c_logit_hr=lhr, c_logit_lr=llr)
+    np.savez_compressed(os.path.join(GOLD, "query.npz"), **out)
+    print("query done")
+
+
+def _sub(a, step):
+    return np.ascontiguousarray(a[..., ::step, ::step])
+
+
+def gen_encoder():
+    net, opt_ref, sd = make_net()
+    for H in (64, 96):
+        img = weights.synthetic_image(H, seed=1)
+        taps = {}
+        hooks = []
+
+        def tap(name, mod):
+            hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: taps.__setitem__(name, o.detach()[0].numpy().copy())))
+
+        tap("conv2", net.image_filter_lr.conv2)
+        for i in range(3):
+            tap("hg%d" % i, getattr(net.image_filter_lr, "m%d" % i))
+            tap("out%d" % i, getattr(net.image_filter_lr, "l%d" % i))
+        t = time.time()
+        with torch.no_grad(), rh.quiet():
+            img_sr, f_lr, f_hr = net.super_res(torch.from_numpy(img.copy()))
+            net.filter_hr(f_hr)
+            net.filter_lr(f_lr)
+        for h in hooks:
+            h.remove()
+        print("encoder H=%d: %.1fs" % (H, time.time() - t))
+        im_lr = net.im_feat_list_lr[0][0].numpy()
+        im_hr = net.im_feat_list_hr[0][0].numpy()
+        out = dict(img_sr_sub=_sub(img_sr[0].numpy(), 2), feature_lr=f_lr[0].numpy() if H == 64 else _sub(f_lr[0].numpy(), 2),
+                   feature_hr_sub=_sub(f_hr[0].numpy(), 4), im_feat_lr=im_lr if H == 64 else _sub(im_lr, 2),
+                   im_feat_hr_sub=_sub(im_hr, 4),
+                   feature_hr_mean=f_hr[0].numpy().mean((1, 2)), feature_hr_absmax=np.abs(f_hr[0].numpy()).max((1, 2)),
+                   im_feat_hr_mean=im_hr.mean((1, 2)), im_feat_hr_absmax=np.abs(im_hr).max((1, 2)),
+                   img_sr_mean=img_sr[0].numpy().mean((1, 2)))
+        for k, v in taps.items():
+            out["tap_" + k + "_sub"] = _sub(v, 2)
+        np.savez_compressed(os.path.join(GOLD, "encoder_h%d.npz" % H), **out)
+        for k, v in out.items():
+            print("  ", k, v.shape, float(np.abs(v).max()))
+        if H == 64:
+            torch.save({"im_lr": im_lr, "im_hr": im_hr}, "/tmp/enc64_feats.pt")
+
+
+def gen_recon():
+    net, opt_ref, sd = make_net()
+    ns = rh.load_reference()
+    img = weights.synthetic_image(64, seed=1)
+    with torch.no_grad(), rh.quiet():
+        img_sr, f_lr, f_hr = net.super_res(torch.from_numpy(img.copy()))
+        net.filter_hr(f_hr)
+        net.filter_lr(f_lr)
+    calib = torch.from_numpy(CALIB[None].copy())
+    b_min, b_max = np.array([-0.5, -0.5, -0.5]), np.array([0.5, 0.5, 0.5])
+    for R in (32, 48):
+        t = time.time()
+        cap = {}
+        orig = ns.sdf.eval_grid
+
+        def spy(coords, eval_func, num_samples):
+            a, b = orig(coords, eval_func, num_samples=num_samples)
+            cap["hr"], cap["lr"] = a, b
+            return a, b
+
+        ns.mesh_util.eval_grid = spy
+        try:
+            with torch.no_grad(), rh.quiet():
+                vh, fh, _, _, vl, fl_, _, _ = ns.mesh_util.reconstruction(
+                    opt_ref, net, torch.device("cpu"), calib, R, b_min, b_max, use_octree=False, num_samples=50000)
+        finally:
+            ns.mesh_util.eval_grid = orig
+        print("recon R=%d %.1fs verts %s faces %s | lr %s %s; sdf_hr range %.3f..%.3f" %
+              (R, time.time() - t, vh.shape, fh.shape, vl.shape, fl_.shape, cap["hr"].min(), cap["hr"].max()))
+        np.savez_compressed(os.path.join(GOLD, "recon_r%d.npz" % R), sdf_hr=cap["hr"].astype(np.float32),
+                            sdf_lr=cap["lr"].astype(np.float32), verts_hr=vh, faces_hr=fh, verts_lr=vl, faces_lr=fl_)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["keys", "query", "encoder", "recon"]
+    torch.set_num_threads(8)
+    for w in what:
+        globals()["gen_" + w]()
