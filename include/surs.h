@@ -1,0 +1,152 @@
+/*
+ * surs.h - C ABI of the MI355X-native SuRS occupancy-query hot path.
+ *
+ * The reference (marcopesavento/Super-resolution-3D-Human-Shape-from-a-Single-
+ * Low-Resolution-Image) is pure Python on PyTorch: it has no FFI of its own.
+ * The entry points below are what a binding for this path replaces, one per
+ * ATen / scikit-image call on the path:
+ *
+ *   surs_conv2d_nhwc          nn.Conv2d 3x3 / 1x1        lib/net_util.py:94-97, lib/model/SuRSSR_v3.py:46-138,
+ *                                                        lib/model/HGFilters.py:60-64,153-174
+ *   surs_groupnorm_coeffs     nn.GroupNorm(32, C) stats  lib/model/HGFilters.py:41-45,140,164
+ *   surs_avgpool2             F.avg_pool2d(x,2,2)        lib/model/HGFilters.py:101
+ *   surs_bicubic_up2          bicubic x2, both alignments lib/model/HGFilters.py:115, lib/model/SuRSSR_v3.py:140
+ *   surs_pixel_shuffle2       PixelShuffle(2)+LeakyReLU   lib/model/SuRSSR_v3.py:111-115
+ *   surs_axpby / surs_add3    residual adds / cat         lib/model/HGFilters.py:66-74,117,203-206
+ *   surs_query_points         query_mr+query_sr+get_preds lib/model/SuRSNet.py:131-187, lib/model/BaseSuRSNet.py:80-85,
+ *                                                        lib/geometry.py:4-31, lib/model/DepthNormalizer.py:18,
+ *                                                        lib/model/SurfaceClassifier.py:53-81
+ *   surs_query_grid           create_grid + eval_grid + eval_func  lib/sdf.py:4-52, lib/mesh_util.py:16-34
+ *   surs_mc_*                 measure.marching_cubes_lewiner(sdf, 0.5)  lib/mesh_util.py:40,45
+ *                             (scikit-image 0.17.2, skimage/measure/_marching_cubes_lewiner.py)
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Unless a parameter
+ * is marked HOST, every pointer is a DEVICE pointer valid on the current HIP
+ * device; work is enqueued on `stream` (a hipStream_t passed as void*, NULL =
+ * the null stream) and the call returns without synchronising unless stated.
+ * Return value: 0 on success, a negative SURS_E_* code otherwise;
+ * surs_last_error() returns a thread-local message.  No exceptions cross the
+ * ABI.  Image tensors are NHWC fp32 with an explicit channel pitch (`ld`, in
+ * floats, >= C) so that a channel slice of a wider tensor (the reference's
+ * torch.cat) is addressed in place.
+ */
+#ifndef SURS_H
+#define SURS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SURS_ABI_VERSION 1
+
+enum {
+    SURS_OK = 0,
+    SURS_E_INVALID = -1,   /* bad argument */
+    SURS_E_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+    SURS_E_UNSUPPORTED = -3,
+    SURS_E_LEVEL_RANGE = -4, /* marching cubes: level outside [min,max]  (skimage ValueError) */
+    SURS_E_NO_SURFACE = -5,  /* marching cubes: no surface              (skimage RuntimeError) */
+    SURS_E_CAPACITY = -6     /* marching cubes: output buffers too small; counts are reported */
+};
+
+enum { SURS_F32 = 0, SURS_BF16 = 1, SURS_F16 = 2 }; /* arithmetic of the dense MLP contractions */
+
+int surs_abi_version(void);
+const char *surs_last_error(void);
+/* number of compute units / gcn arch name of the current device (arch_out: >= 32 bytes, HOST) */
+int surs_device_info(int *cu_count, char *arch_out);
+
+/* ------------------------------------------------------------------ encoder primitives */
+
+/* y[:, :, 0:cout] (pitch y_ld) = act( conv_k(pre(x))[...] + bias ) (+ residual)
+ *   pre(x) = relu(x * in_scale[c] + in_shift[c]) if in_scale != NULL (fused GroupNorm-apply + ReLU, zero padding
+ *            applied AFTER it, as nn.Conv2d pads the normalised tensor), else x.
+ *   ksize 1 or 3, padding ksize/2, stride 1 or 2.  wpacked: surs_conv_pack_weights layout.  bias nullable.
+ *   act: 0 none, 1 leaky-relu with `slope` (slope 0 = ReLU), applied before the residual add.
+ *   residual (nullable): same spatial size as y, pitch res_ld. */
+int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld, const float *wpacked, const float *bias, float *y,
+                     int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
+                     float slope, const float *residual, int res_ld, void *stream);
+/* HOST helper: repack a PyTorch [cout][cin][k][k] weight into the kernel layout [k*k][cin_pad][cout_pad] (floats).
+ * Returns the number of floats written (query with out == NULL). */
+size_t surs_conv_pack_weights(const float *w, int cout, int cin, int ksize, float *out);
+
+/* GroupNorm statistics folded with the affine parameters into per-channel coefficients:
+ * scale[c] = gamma[c]*rstd[g(c)], shift[c] = beta[c] - mean[g]*rstd[g]*gamma[c]   (biased variance, eps). */
+int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
+                          const float *beta, float *scale, float *shift, void *stream);
+/* y = relu?(x*scale + shift) elementwise (GroupNorm apply when it is not followed by a conv) */
+int surs_scale_shift_act(const float *x, int hw, int c, int x_ld, const float *scale, const float *shift, int relu,
+                         float *y, int y_ld, void *stream);
+int surs_avgpool2(const float *x, int h, int w, int c, int x_ld, float *y, int y_ld, void *stream);
+/* y = bicubic_x2(x) (+ addend, nullable, pitch add_ld): A=-0.75, border-clamped taps */
+int surs_bicubic_up2(const float *x, int h, int w, int c, int x_ld, int align_corners, const float *addend, int add_ld,
+                     float *y, int y_ld, void *stream);
+/* y[2h+i][2w+j][c] = lrelu(x[h][w][4c+2i+j], slope)  (slope 1 = no activation) */
+int surs_pixel_shuffle2(const float *x, int h, int w, int c4, int x_ld, float slope, float *y, int y_ld, void *stream);
+/* y = a + b (+ c, nullable) */
+int surs_add3(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch, float *y,
+              int y_ld, void *stream);
+/* NCHW <-> NHWC(pitch ld) copies for the boundary tensors */
+int surs_nchw_to_nhwc(const float *x, int c, int h, int w, float *y, int y_ld, void *stream);
+int surs_nhwc_to_nchw(const float *x, int c, int h, int w, int x_ld, float *y, void *stream);
+
+/* ------------------------------------------------------------------ point evaluator */
+
+/* HOST: pack the two SurfaceClassifier MLPs (lr: 321-1024-512-256-128-1, hr: 322-..., skip-concat at layers
+ * 2,3,4; w[l] = Conv1d weight [out][in], b[l] = bias) into one blob that surs_query_* consume.  `dtype` selects
+ * the element type of the dense cores used by the grid kernel (SURS_BF16 or SURS_F16).  Call with blob == NULL
+ * to get the size in bytes.  The caller uploads the blob to device memory (256-byte aligned). */
+size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], const float *const w_hr[5],
+                     const float *const b_hr[5], int dtype, void *blob);
+
+/* bytes of device workspace the two query entry points need for `max_points` points per call / grid batch */
+size_t surs_query_workspace_bytes(int max_points);
+
+/* query_mr + query_sr + get_preds for one view, fp32 arithmetic (f32 MFMA).
+ *   points  [3][n] fp32 (x row, y row, z row), calib HOST [12] = rows 0..2 of the 4x4 calibration,
+ *   zmul = loadSize/2 (integer division done by the caller), zdiv = z_size,
+ *   feat_lr NHWC [hl][wl][c_lr=256] pitch c_lr, feat_hr NHWC [hh][wh][c_hr=64],
+ *   outputs [n] each; logit_* nullable (pre-sigmoid, pre-mask). */
+int surs_query_points(const float *points, int n, const float *calib, float zmul, float zdiv, const float *feat_lr,
+                      int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace,
+                      size_t workspace_bytes, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr,
+                      void *stream);
+
+/* Dense grid sweep: voxel (i,j,k), i in [i0,i1), j in [0,ry), k in [0,rz) has world position
+ * p = float32( mat[:,0]*i + mat[:,1]*j + mat[:,2]*k + mat[:,3] )  (mat HOST [12] doubles = create_grid's
+ * coords_matrix rows 0..2, evaluated in double like np.matmul on the float64 grid, then cast as eval_func does).
+ * vol_hr / vol_lr: [(i1-i0)][ry][rz] fp32, z fastest (the flattening of lib/sdf.py:14-15,28).
+ * dtype SURS_F32: same arithmetic as surs_query_points.  SURS_BF16 / SURS_F16: fused column kernel (requires the
+ * projected X,Y not to depend on k, true for gen_mesh's calib; otherwise returns SURS_E_UNSUPPORTED). */
+int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul, float zdiv,
+                    const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,
+                    int dtype, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr, void *stream);
+size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype);
+
+/* ------------------------------------------------------------------ Lewiner marching cubes */
+
+typedef struct {
+    int32_t n_verts;   /* vertices produced (also when SURS_E_CAPACITY) */
+    int32_t n_faces;   /* triangles produced */
+    float vmin, vmax;  /* data range of the volume */
+} surs_mc_counts;
+
+size_t surs_mc_workspace_bytes(int n0, int n1, int n2);
+/* Extract the level set of vol [n0][n1][n2] (fp32, axis 2 fastest) exactly as
+ * skimage.measure.marching_cubes_lewiner(vol, level) with default arguments does: same vertices (fp32,
+ * (axis0, axis1, axis2) order), same vertex numbering, same faces (int32, rows reversed for
+ * gradient_direction='descent'), normals and values.  Outputs are device buffers of capacity cap_verts /
+ * cap_faces; counts is a HOST struct filled before return (this call synchronises the stream).
+ * normals / values nullable.  verts == NULL or faces == NULL: count-only call (fills counts, writes nothing). */
+int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void *workspace, size_t workspace_bytes,
+                    float *verts, float *normals, float *values, int cap_verts, int32_t *faces, int cap_faces,
+                    surs_mc_counts *counts, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURS_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libsurs_hip.so (the C ABI of include/surs.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C csrc``.
+There is no fallback: if it is missing, or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsurs_hip.so")
+_lib = None
+
+F32, BF16, F16 = 0, 1, 2
+DTYPES = {"fp32": F32, "bf16": BF16, "fp16": F16, "f16": F16}
+
+
+class SursError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("surs error %d: %s" % (code, msg))
+        self.code = code
+
+
+class LevelRangeError(ValueError):
+    pass
+
+
+class NoSurfaceError(RuntimeError):
+    pass
+
+
+class McCounts(C.Structure):
+    _fields_ = [("n_verts", C.c_int32), ("n_faces", C.c_int32), ("vmin", C.c_float), ("vmax", C.c_float)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_SIGS = {
+    "surs_abi_version": (C.c_int, []),
+    "surs_last_error": (C.c_char_p, []),
+    "surs_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p]),
+    "surs_conv2d_nhwc": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),
+    "surs_conv_pack_weights": (_sz, [_vp, _i, _i, _i, _vp]),
+    "surs_groupnorm_coeffs": (C.c_int, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "surs_scale_shift_act": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "surs_avgpool2": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "surs_bicubic_up2": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "surs_pixel_shuffle2": (C.c_int, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "surs_add3": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "surs_nchw_to_nhwc": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "surs_nhwc_to_nchw": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "surs_mlp_pack": (_sz, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "surs_query_workspace_bytes": (_sz, [_i]),
+    "surs_query_points": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "surs_query_grid": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
+    "surs_query_grid_workspace_bytes": (_sz, [_i, _i, _i]),
+    "surs_mc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "surs_mc_lewiner": (C.c_int, [_vp, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(McCounts), _vp]),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (never falls back to a CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libsurs_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C %s/csrc)" % _HERE)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the library misses a declared entry point
+            fn.restype = res
+            fn.argtypes = args
+        if l.surs_abi_version() != 1:
+            raise ImportError("libsurs_hip.so has ABI version %d, expected 1" % l.surs_abi_version())
+        _lib = l
+    return _lib
+
+
+def check(code):
+    if code == 0:
+        return
+    msg = lib().surs_last_error().decode("utf-8", "replace")
+    if code == -4:
+        raise LevelRangeError("Surface level must be within volume data range.")
+    if code == -5:
+        raise NoSurfaceError("No surface found at the given iso value.")
+    raise SursError(code, msg)

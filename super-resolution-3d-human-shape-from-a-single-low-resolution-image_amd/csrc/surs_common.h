@@ -1,0 +1,45 @@
+// Shared host-side helpers for the gfx950 kernels (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/surs.h"
+
+namespace surs {
+
+inline char *err_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SURS_HIP_CHECK(expr)                                                                     \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return surs::fail(SURS_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define SURS_LAUNCH_CHECK() SURS_HIP_CHECK(hipGetLastError())
+
+#define SURS_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return surs::fail(SURS_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace surs

@@ -1,0 +1,410 @@
+// Image-encoder primitives for gfx950, NHWC fp32 with explicit channel pitch.
+//
+// Replaces the ATen ops on the encoder path of the reference (/root/reference):
+//   conv3x3 / conv1x1 (+bias, +LeakyReLU/ReLU, +residual)  lib/net_util.py:94-97, lib/model/SuRSSR_v3.py:46-138,
+//                                                          lib/model/common.py:14-33, lib/model/HGFilters.py:60-64,153-174
+//   GroupNorm(32, C) -> per-channel scale/shift, applied (+ReLU) in the conv's staging prologue
+//                                                          lib/model/HGFilters.py:41-45,57-64
+//   avg_pool2d(2,2)  lib/model/HGFilters.py:101      bicubic x2  lib/model/HGFilters.py:115, lib/model/SuRSSR_v3.py:140
+//   PixelShuffle(2)+LeakyReLU  lib/model/SuRSSR_v3.py:111-115     adds  lib/model/HGFilters.py:66-74,117,203-206
+//
+// The convolution is an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32): A = input patch (pixels x cin),
+// B = weights (cin x cout), so a lane holds one output channel and the NHWC store is 128 B coalesced per pixel.
+// A workgroup computes TR rows x 32 columns of pixels x 64 output channels; per 16-channel input chunk it stages
+// the (TR-1)*S+K by 31*S+K input patch (GroupNorm-apply + ReLU fused into the staging, zero padding applied
+// after it) and the K*K x 16 x 64 weight slice in LDS.  Pixel stride 17 floats keeps the A reads conflict-free.
+#include <hip/hip_runtime.h>
+
+#include "surs_common.h"
+
+namespace surs {
+namespace enc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 16;    // input channels per chunk
+constexpr int PS = 17;    // LDS pixel stride in floats (odd: conflict-free ds_read_b32 across 32 pixels)
+constexpr int NT = 64;    // output channels per workgroup
+constexpr int TC = 32;    // tile columns (pixels) = one MFMA tile
+
+struct ConvArgs {
+    const float *x; int h, w, cin, x_ld;
+    const float *wp; int cin_pad, cout_pad;
+    const float *bias;
+    float *y; int ho, wo, cout, y_ld;
+    const float *in_scale, *in_shift;
+    int act; float slope;
+    const float *res; int res_ld;
+};
+
+template <int KS, int STRIDE, int TR>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;  // patch rows / cols
+    constexpr int RPW = TR / 4;                                             // rows per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *xs = lds;                         // [PR*PC][PS]
+    float *ws = lds + PR * PC * PS;          // [KS*KS][CK][NT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ox0 = blockIdx.x * TC, oy0 = blockIdx.y * TR, n0 = blockIdx.z * NT;
+    const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD;
+
+    f32x16 acc[RPW][2];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[r][j][q] = 0.0f;
+
+    const bool vec_ok = (a.x_ld % 4 == 0) && ((reinterpret_cast<size_t>(a.x) & 15) == 0);
+    for (int c0 = 0; c0 < a.cin_pad; c0 += CK) {
+        // ---- stage the input patch: PR*PC pixels x 16 channels, 4 channels per thread-item
+        for (int item = tid; item < PR * PC * (CK / 4); item += 256) {
+            const int pix = item >> 2, cq = (item & 3) * 4;
+            const int pr = pix / PC, pc = pix - pr * PC;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) {
+                const float *src = a.x + ((size_t)iy * a.w + ix) * a.x_ld + c0 + cq;
+                if (vec_ok && c0 + cq + 4 <= a.cin) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(src);
+                    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + cq + q < a.cin) v[q] = src[q];
+                }
+                if (a.in_scale) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + cq + q < a.cin) {
+                            const float t = v[q] * a.in_scale[c0 + cq + q] + a.in_shift[c0 + cq + q];
+                            v[q] = t > 0.f ? t : 0.f;
+                        }
+                }
+            }
+            float *dst = xs + pix * PS + cq;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+        }
+        // ---- stage the weights: [tap][16][64]
+        for (int item = tid; item < KS * KS * CK * (NT / 4); item += 256) {
+            const int co4 = (item & 15) * 4, row = item >> 4;  // row = tap*CK + c
+            const int tap = row / CK, c = row - tap * CK;
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(a.wp + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + n0 + co4);
+            *reinterpret_cast<f32x4 *>(ws + row * NT + co4) = t;
+        }
+        __syncthreads();
+        const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const float *wt = ws + (ky * KS + kx) * CK * NT;
+#pragma unroll
+                for (int s = 0; s < CK / 2; ++s) {
+                    float av[RPW], bv[2];
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        const int prow = (wave * RPW + r) * STRIDE + ky, pcol = li * STRIDE + kx;
+                        av[r] = xs[(prow * PC + pcol) * PS + 2 * s + kh];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bv[j] = wt[(2 * s + kh) * NT + j * 32 + li];
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[j], acc[r][j], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+    }
+    // ---- epilogue: register q of a tile is pixel column (q&3) + 8*(q>>2) + 4*(lane>>5), lane&31 is the channel
+    const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int oy = oy0 + wave * RPW + r;
+        if (oy >= a.ho) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = n0 + j * 32 + li;
+            if (co >= a.cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                if (ox >= a.wo) continue;
+                float t = acc[r][j][q] + b;
+                if (a.act == 1) t = t > 0.f ? t : a.slope * t;
+                const size_t pix = (size_t)oy * a.wo + ox;
+                if (a.res) t += a.res[pix * a.res_ld + co];
+                a.y[pix * a.y_ld + co] = t;
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int TR>
+static int launch_conv(const ConvArgs &a, hipStream_t st) {
+    constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
+    const size_t lds = (size_t)(PR * PC * PS + KS * KS * CK * NT) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<KS, STRIDE, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), a.cout_pad / NT);
+    hipLaunchKernelGGL((conv_kernel<KS, STRIDE, TR>), grid, dim3(256), lds, st, a);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- GroupNorm coefficients: one workgroup per group
+__global__ __launch_bounds__(1024) void gn_coeffs_kernel(const float *__restrict__ x, int hw, int c, int x_ld, int groups, float eps,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         float *__restrict__ scale, float *__restrict__ shift) {
+    __shared__ double red[2][16];
+    const int g = blockIdx.x, cg = c / groups;
+    const size_t n = (size_t)cg * hw;
+    double s = 0.0, ss = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const size_t pix = i / cg;
+        const int ch = (int)(i - pix * cg);
+        const double v = x[pix * x_ld + g * cg + ch];
+        s += v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        ss += __shfl_xor(ss, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x < cg) {
+        double S = 0, SS = 0;
+        for (int w = 0; w < 16; ++w) { S += red[0][w]; SS += red[1][w]; }
+        const double mean = S / (double)n;
+        double var = SS / (double)n - mean * mean;
+        if (var < 0) var = 0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const int ch = g * cg + threadIdx.x;
+        scale[ch] = (float)(rstd * gamma[ch]);
+        shift[ch] = (float)(beta[ch] - mean * rstd * gamma[ch]);
+    }
+}
+
+// ---------------------------------------------------------------- small HBM-bound kernels (one thread = one pixel x 4 channels)
+__global__ void scale_shift_kernel(const float *__restrict__ x, size_t hw, int c, int x_ld, const float *__restrict__ scale,
+                                   const float *__restrict__ shift, int relu, float *__restrict__ y, int y_ld) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = c / 4;
+    if (i >= hw * c4) return;
+    const size_t pix = i / c4;
+    const int ch = (int)(i - pix * c4) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float t = x[pix * x_ld + ch + q] * scale[ch + q] + shift[ch + q];
+        if (relu) t = t > 0.f ? t : 0.f;
+        y[pix * y_ld + ch + q] = t;
+    }
+}
+
+__global__ void avgpool2_kernel(const float *__restrict__ x, int h, int w, int c, int x_ld, float *__restrict__ y, int y_ld) {
+    const int ho = h / 2, wo = w / 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ho * wo * c) return;
+    const int ch = (int)(i % c);
+    const size_t pix = i / c;
+    const int ox = (int)(pix % wo), oy = (int)(pix / wo);
+    const float *p = x + ((size_t)(2 * oy) * w + 2 * ox) * x_ld + ch;
+    y[pix * y_ld + ch] = (p[0] + p[x_ld] + p[(size_t)w * x_ld] + p[(size_t)w * x_ld + x_ld]) * 0.25f;
+}
+
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+    const float A = -0.75f;
+    float x = t + 1.0f;
+    c[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+    x = t;
+    c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 1.0f - t;
+    c[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+    x = 2.0f - t;
+    c[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+
+__global__ void bicubic_up2_kernel(const float *__restrict__ x, int h, int w, int c, int x_ld, int align_corners,
+                                   const float *__restrict__ addend, int add_ld, float *__restrict__ y, int y_ld) {
+    const int ho = 2 * h, wo = 2 * w;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ho * wo * c) return;
+    const int ch = (int)(i % c);
+    const size_t pix = i / c;
+    const int ox = (int)(pix % wo), oy = (int)(pix / wo);
+    const float sy = align_corners ? (ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f) : 0.5f;
+    const float sx = align_corners ? (wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f) : 0.5f;
+    const float ry = align_corners ? sy * (float)oy : sy * ((float)oy + 0.5f) - 0.5f;
+    const float rx = align_corners ? sx * (float)ox : sx * ((float)ox + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    float cy[4], cx[4];
+    cubic_coeffs(ry - (float)iy, cy);
+    cubic_coeffs(rx - (float)ix, cx);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), h - 1);
+        float r = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = min(max(ix - 1 + b, 0), w - 1);
+            r += cx[b] * x[((size_t)yy * w + xx) * x_ld + ch];
+        }
+        acc += cy[a] * r;
+    }
+    if (addend) acc = addend[pix * add_ld + ch] + acc;
+    y[pix * y_ld + ch] = acc;
+}
+
+__global__ void pixel_shuffle2_kernel(const float *__restrict__ x, int h, int w, int c4, int x_ld, float slope,
+                                      float *__restrict__ y, int y_ld) {
+    const int c = c4 / 4, ho = 2 * h, wo = 2 * w;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ho * wo * c) return;
+    const int ch = (int)(i % c);
+    const size_t pix = i / c;
+    const int ox = (int)(pix % wo), oy = (int)(pix / wo);
+    const float v = x[((size_t)(oy >> 1) * w + (ox >> 1)) * x_ld + 4 * ch + 2 * (oy & 1) + (ox & 1)];
+    y[pix * y_ld + ch] = v > 0.f ? v : slope * v;
+}
+
+__global__ void add3_kernel(const float *__restrict__ a, int a_ld, const float *__restrict__ b, int b_ld,
+                            const float *__restrict__ c, int c_ld, size_t hw, int ch, float *__restrict__ y, int y_ld) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw * ch) return;
+    const size_t pix = i / ch;
+    const int k = (int)(i - pix * ch);
+    float t = a[pix * a_ld + k] + b[pix * b_ld + k];
+    if (c) t += c[pix * c_ld + k];
+    y[pix * y_ld + k] = t;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int c, size_t hw, float *__restrict__ y, int y_ld) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw * c) return;
+    const size_t pix = i / c;
+    const int k = (int)(i - pix * c);
+    y[pix * y_ld + k] = x[(size_t)k * hw + pix];
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ x, int c, size_t hw, int x_ld, float *__restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw * c) return;
+    const int k = (int)(i / hw);
+    const size_t pix = i - (size_t)k * hw;
+    y[i] = x[pix * x_ld + k];
+}
+
+}  // namespace enc
+}  // namespace surs
+
+using namespace surs;
+using namespace surs::enc;
+
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld, const float *wpacked, const float *bias,
+                                float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
+                                const float *in_shift, int act, float slope, const float *residual, int res_ld,
+                                void *stream) {
+    SURS_REQUIRE(x && wpacked && y, "null argument");
+    SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
+    SURS_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "ksize must be 1 or 3, stride 1 or 2");
+    SURS_REQUIRE(!(ksize == 1 && stride != 1), "1x1 convolution with stride 2 is not on the path");
+    SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
+    ConvArgs a;
+    a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
+    a.wp = wpacked; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
+    a.bias = bias;
+    const int pad = ksize / 2;
+    a.y = y; a.ho = (h + 2 * pad - ksize) / stride + 1; a.wo = (w + 2 * pad - ksize) / stride + 1; a.cout = cout; a.y_ld = y_ld;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    a.act = act; a.slope = slope;
+    a.res = residual; a.res_ld = res_ld;
+    hipStream_t st = as_stream(stream);
+    if (ksize == 1) return launch_conv<1, 1, 8>(a, st);
+    if (stride == 1) return launch_conv<3, 1, 8>(a, st);
+    return launch_conv<3, 2, 4>(a, st);
+}
+
+extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
+                                     const float *beta, float *scale, float *shift, void *stream) {
+    SURS_REQUIRE(x && gamma && beta && scale && shift, "null argument");
+    SURS_REQUIRE(groups > 0 && c % groups == 0 && c / groups <= 1024 && hw > 0, "bad GroupNorm shape");
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(groups), dim3(1024), 0, as_stream(stream), x, hw, c, x_ld, groups, eps, gamma, beta,
+                       scale, shift);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_scale_shift_act(const float *x, int hw, int c, int x_ld, const float *scale, const float *shift, int relu,
+                                    float *y, int y_ld, void *stream) {
+    SURS_REQUIRE(x && scale && shift && y && c % 4 == 0, "bad argument");
+    hipLaunchKernelGGL(scale_shift_kernel, dim3(blocks_for((size_t)hw * (c / 4))), dim3(256), 0, as_stream(stream), x, (size_t)hw, c,
+                       x_ld, scale, shift, relu, y, y_ld);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_avgpool2(const float *x, int h, int w, int c, int x_ld, float *y, int y_ld, void *stream) {
+    SURS_REQUIRE(x && y && h >= 2 && w >= 2, "bad argument");
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for((size_t)(h / 2) * (w / 2) * c)), dim3(256), 0, as_stream(stream), x, h, w, c,
+                       x_ld, y, y_ld);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_bicubic_up2(const float *x, int h, int w, int c, int x_ld, int align_corners, const float *addend,
+                                int add_ld, float *y, int y_ld, void *stream) {
+    SURS_REQUIRE(x && y && h > 0 && w > 0, "bad argument");
+    hipLaunchKernelGGL(bicubic_up2_kernel, dim3(blocks_for((size_t)4 * h * w * c)), dim3(256), 0, as_stream(stream), x, h, w, c, x_ld,
+                       align_corners, addend, add_ld, y, y_ld);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_pixel_shuffle2(const float *x, int h, int w, int c4, int x_ld, float slope, float *y, int y_ld,
+                                   void *stream) {
+    SURS_REQUIRE(x && y && c4 % 4 == 0, "bad argument");
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(blocks_for((size_t)4 * h * w * (c4 / 4))), dim3(256), 0, as_stream(stream), x, h, w,
+                       c4, x_ld, slope, y, y_ld);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_add3(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch,
+                         float *y, int y_ld, void *stream) {
+    SURS_REQUIRE(a && b && y, "bad argument");
+    hipLaunchKernelGGL(add3_kernel, dim3(blocks_for((size_t)hw * ch)), dim3(256), 0, as_stream(stream), a, a_ld, b, b_ld, c, c_ld,
+                       (size_t)hw, ch, y, y_ld);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_nchw_to_nhwc(const float *x, int c, int h, int w, float *y, int y_ld, void *stream) {
+    SURS_REQUIRE(x && y, "bad argument");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for((size_t)h * w * c)), dim3(256), 0, as_stream(stream), x, c, (size_t)h * w,
+                       y, y_ld);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_nhwc_to_nchw(const float *x, int c, int h, int w, int x_ld, float *y, void *stream) {
+    SURS_REQUIRE(x && y, "bad argument");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks_for((size_t)h * w * c)), dim3(256), 0, as_stream(stream), x, c, (size_t)h * w,
+                       x_ld, y);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}

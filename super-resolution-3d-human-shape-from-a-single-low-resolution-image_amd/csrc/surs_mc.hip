@@ -1,0 +1,613 @@
+// Lewiner MC33 marching cubes on gfx950, bit-compatible with
+//     skimage.measure.marching_cubes_lewiner(vol, level)            (scikit-image 0.17.2 / 0.18.3 Cython core)
+// as called by the reference at /root/reference/lib/mesh_util.py:40,45.
+//
+// The Cython core is a sequential sweep (axis 0 outer, axis 2 inner) with a two-layer vertex cache; vertex ids
+// are handed out in order of first use.  Facts that make a parallel restatement exact (SURVEY.md A.7, and
+// pinned by tests/golden/mc_*):
+//   * every cell that contains an intersected lattice edge references it, so the vertex of an edge is created
+//     by the FIRST cell (in sweep order) containing it: the cell "below/left/behind".  Interior cells therefore
+//     own only the three edges meeting at their far corner (5, 6, 10) and their centre vertex (12);
+//   * inside the owning cell vertices are numbered in order of first appearance in its triangle list;
+//   * faces are emitted cell by cell in sweep order, triangles in LUT order.
+// So:  pass 1  classify + count (vertices owned, triangles) per cell, summed per block of 1024 sweep-consecutive cells
+//      pass 2  exclusive scan of the block sums
+//      pass 3a vertices: block-local scan -> vertex ids; positions; ids stored in 4 dense per-voxel tables
+//              (x-edge, y-edge, z-edge starting at the voxel, centre of the cell whose corner 0 it is)
+//      pass 3b faces (+ values by atomic max, normals by atomic add): vertex ids looked up in the tables
+//      pass 4  normalise normals.
+// HBM-bound: the volume is read once per pass (corner re-reads hit L1/L2); the ambiguity tests run in double
+// only on the (rare) active cells.  All arithmetic that decides topology or positions is double, written exactly
+// as the Cython core evaluates it (compiled with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "surs_common.h"
+
+namespace surs {
+namespace mc {
+
+#define MCL_QUAL __device__ const
+#include "mc_luts.inc"
+#undef MCL_QUAL
+
+// the Cython core defines FLT_EPSILON = np.spacing(1.0): DOUBLE epsilon (black-box verified, see oracle)
+#define MC_EPS 2.220446049250313e-16
+
+constexpr int CELLS_PER_BLOCK = 1024;
+constexpr int THREADS = 256;
+
+struct Dims {
+    int nz, ny, nx;     // volume dims (axis 0, 1, 2)
+    int cz, cy, cx;     // cells per axis
+    long long ncells;
+};
+
+struct Tiling {
+    const signed char *row;
+    int nt;
+};
+
+#define T1(name, cfg) (MCL_##name + (size_t)(cfg) * MCL_##name##_D1)
+#define T2(name, cfg, sub) (MCL_##name + ((size_t)(cfg) * MCL_##name##_D1 + (sub)) * MCL_##name##_D2)
+
+__device__ __forceinline__ bool test_face(const double *v, int face) {
+    double A = 0, B = 0, C = 0, D = 0;
+    switch (face < 0 ? -face : face) {
+        case 1: A = v[0]; B = v[4]; C = v[5]; D = v[1]; break;
+        case 2: A = v[1]; B = v[5]; C = v[6]; D = v[2]; break;
+        case 3: A = v[2]; B = v[6]; C = v[7]; D = v[3]; break;
+        case 4: A = v[3]; B = v[7]; C = v[4]; D = v[0]; break;
+        case 5: A = v[0]; B = v[3]; C = v[2]; D = v[1]; break;
+        case 6: A = v[4]; B = v[7]; C = v[6]; D = v[5]; break;
+        default: break;
+    }
+    const double t = A * C - B * D;
+    if (t > -MC_EPS && t < MC_EPS) return face >= 0;
+    return (double)face * A * t >= 0;
+}
+
+__device__ const signed char MC_TI_EDGES[12][8] = {
+    {0, 1, 3, 2, 7, 6, 4, 5}, {1, 2, 0, 3, 4, 7, 5, 6}, {2, 3, 1, 0, 5, 4, 6, 7}, {3, 0, 2, 1, 6, 5, 7, 4},
+    {4, 5, 7, 6, 3, 2, 0, 1}, {5, 6, 4, 7, 0, 3, 1, 2}, {6, 7, 5, 4, 1, 0, 2, 3}, {7, 4, 6, 5, 2, 1, 3, 0},
+    {0, 4, 3, 7, 2, 6, 1, 5}, {1, 5, 0, 4, 3, 7, 2, 6}, {2, 6, 1, 5, 0, 4, 3, 7}, {3, 7, 2, 6, 1, 5, 0, 4}};
+
+__device__ __forceinline__ bool test_internal(const double *v, int mccase, int config, int subconfig, int s) {
+    double t, At = 0, Bt = 0, Ct = 0, Dt = 0;
+    if (mccase == 4 || mccase == 10) {
+        const double a = (v[4] - v[0]) * (v[6] - v[2]) - (v[7] - v[3]) * (v[5] - v[1]);
+        const double b = v[2] * (v[4] - v[0]) + v[0] * (v[6] - v[2]) - v[1] * (v[7] - v[3]) - v[3] * (v[5] - v[1]);
+        t = -b / (2 * a + MC_EPS);
+        if (t < 0 || t > 1) return s > 0;
+        At = v[0] + (v[4] - v[0]) * t;
+        Bt = v[3] + (v[7] - v[3]) * t;
+        Ct = v[2] + (v[6] - v[2]) * t;
+        Dt = v[1] + (v[5] - v[1]) * t;
+    } else {
+        int edge = -1;
+        if (mccase == 6) edge = T1(TEST6, config)[2];
+        else if (mccase == 7) edge = T1(TEST7, config)[4];
+        else if (mccase == 12) edge = T1(TEST12, config)[3];
+        else if (mccase == 13) edge = T2(TILING13_5_1, config, subconfig)[0];
+        if (edge < 0 || edge > 11) return s < 0;
+        const signed char *e = MC_TI_EDGES[edge];
+        t = v[e[0]] / (v[e[0]] - v[e[1]] + MC_EPS);
+        At = 0;
+        Bt = v[e[2]] + (v[e[3]] - v[e[2]]) * t;
+        Ct = v[e[4]] + (v[e[5]] - v[e[4]]) * t;
+        Dt = v[e[6]] + (v[e[7]] - v[e[6]]) * t;
+    }
+    int test = 0;
+    if (At >= 0) test += 1;
+    if (Bt >= 0) test += 2;
+    if (Ct >= 0) test += 4;
+    if (Dt >= 0) test += 8;
+    switch (test) {
+        case 0: case 1: case 2: case 3: case 4: case 6: case 8: case 9: case 12: return s > 0;
+        case 5: if (At * Ct - Bt * Dt < MC_EPS) return s > 0; break;
+        case 10: if (At * Ct - Bt * Dt >= MC_EPS) return s > 0; break;
+        case 7: case 11: case 13: case 14: case 15: return s < 0;
+        default: break;
+    }
+    return false;  // the Cython function falls off its end here (returns 0); Lewiner's C++ returns s < 0
+}
+
+// MC33 case dispatch (Lewiner's process_cube): which triangle list does this cube get?
+__device__ __forceinline__ Tiling select_tiling(const double *v, int index) {
+    Tiling r;
+    r.row = nullptr;
+    r.nt = 0;
+    const int mccase = MCL_CASES[2 * index], config = MCL_CASES[2 * index + 1];
+    int sub = 0;
+    switch (mccase) {
+        case 1: r.row = T1(TILING1, config); r.nt = 1; break;
+        case 2: r.row = T1(TILING2, config); r.nt = 2; break;
+        case 3:
+            if (test_face(v, MCL_TEST3[config])) { r.row = T1(TILING3_2, config); r.nt = 4; }
+            else { r.row = T1(TILING3_1, config); r.nt = 2; }
+            break;
+        case 4:
+            if (test_internal(v, mccase, config, sub, MCL_TEST4[config])) { r.row = T1(TILING4_1, config); r.nt = 2; }
+            else { r.row = T1(TILING4_2, config); r.nt = 6; }
+            break;
+        case 5: r.row = T1(TILING5, config); r.nt = 3; break;
+        case 6:
+            if (test_face(v, T1(TEST6, config)[0])) { r.row = T1(TILING6_2, config); r.nt = 5; }
+            else if (test_internal(v, mccase, config, sub, T1(TEST6, config)[1])) { r.row = T1(TILING6_1_1, config); r.nt = 3; }
+            else { r.row = T1(TILING6_1_2, config); r.nt = 9; }
+            break;
+        case 7:
+            if (test_face(v, T1(TEST7, config)[0])) sub += 1;
+            if (test_face(v, T1(TEST7, config)[1])) sub += 2;
+            if (test_face(v, T1(TEST7, config)[2])) sub += 4;
+            switch (sub) {
+                case 0: r.row = T1(TILING7_1, config); r.nt = 3; break;
+                case 1: r.row = T2(TILING7_2, config, 0); r.nt = 5; break;
+                case 2: r.row = T2(TILING7_2, config, 1); r.nt = 5; break;
+                case 3: r.row = T2(TILING7_3, config, 0); r.nt = 9; break;
+                case 4: r.row = T2(TILING7_2, config, 2); r.nt = 5; break;
+                case 5: r.row = T2(TILING7_3, config, 1); r.nt = 9; break;
+                case 6: r.row = T2(TILING7_3, config, 2); r.nt = 9; break;
+                default:
+                    if (test_internal(v, mccase, config, sub, T1(TEST7, config)[3])) { r.row = T1(TILING7_4_2, config); r.nt = 9; }
+                    else { r.row = T1(TILING7_4_1, config); r.nt = 5; }
+                    break;
+            }
+            break;
+        case 8: r.row = T1(TILING8, config); r.nt = 2; break;
+        case 9: r.row = T1(TILING9, config); r.nt = 4; break;
+        case 10:
+            if (test_face(v, T1(TEST10, config)[0])) {
+                if (test_face(v, T1(TEST10, config)[1])) { r.row = T1(TILING10_1_1_, config); r.nt = 4; }
+                else { r.row = T1(TILING10_2, config); r.nt = 8; }
+            } else {
+                if (test_face(v, T1(TEST10, config)[1])) { r.row = T1(TILING10_2_, config); r.nt = 8; }
+                else if (test_internal(v, mccase, config, sub, T1(TEST10, config)[2])) { r.row = T1(TILING10_1_1, config); r.nt = 4; }
+                else { r.row = T1(TILING10_1_2, config); r.nt = 8; }
+            }
+            break;
+        case 11: r.row = T1(TILING11, config); r.nt = 4; break;
+        case 12:
+            if (test_face(v, T1(TEST12, config)[0])) {
+                if (test_face(v, T1(TEST12, config)[1])) { r.row = T1(TILING12_1_1_, config); r.nt = 4; }
+                else { r.row = T1(TILING12_2, config); r.nt = 8; }
+            } else {
+                if (test_face(v, T1(TEST12, config)[1])) { r.row = T1(TILING12_2_, config); r.nt = 8; }
+                else if (test_internal(v, mccase, config, sub, T1(TEST12, config)[2])) { r.row = T1(TILING12_1_1, config); r.nt = 4; }
+                else { r.row = T1(TILING12_1_2, config); r.nt = 8; }
+            }
+            break;
+        case 13:
+            for (int k = 0; k < 6; ++k)
+                if (test_face(v, T1(TEST13, config)[k])) sub += 1 << k;
+            sub = MCL_SUBCONFIG13[sub];
+            if (sub == 0) { r.row = T1(TILING13_1, config); r.nt = 4; }
+            else if (sub <= 6) { r.row = T2(TILING13_2, config, sub - 1); r.nt = 6; }
+            else if (sub <= 18) { r.row = T2(TILING13_3, config, sub - 7); r.nt = 10; }
+            else if (sub <= 22) { r.row = T2(TILING13_4, config, sub - 19); r.nt = 12; }
+            else if (sub <= 26) {
+                sub -= 23;
+                if (test_internal(v, mccase, config, sub, T1(TEST13, config)[6])) { r.row = T2(TILING13_5_1, config, sub); r.nt = 6; }
+                else { r.row = T2(TILING13_5_2, config, sub); r.nt = 10; }
+            } else if (sub <= 38) { r.row = T2(TILING13_3_, config, sub - 27); r.nt = 10; }
+            else if (sub <= 44) { r.row = T2(TILING13_2_, config, sub - 39); r.nt = 6; }
+            else if (sub == 45) { r.row = T1(TILING13_1_, config); r.nt = 4; }
+            break;
+        case 14: r.row = T1(TILING14, config); r.nt = 4; break;
+        default: break;
+    }
+    return r;
+}
+
+// which of the 13 "edges" (12 = centre) of cell (x,y,z) does the cell itself create (bit mask)
+__device__ __forceinline__ unsigned owned_mask(int x, int y, int z) {
+    unsigned m = (1u << 5) | (1u << 6) | (1u << 10) | (1u << 12);
+    if (y == 0) m |= (1u << 4) | (1u << 9);
+    if (z == 0) m |= (1u << 2) | (1u << 1);
+    if (x == 0) m |= (1u << 7) | (1u << 11);
+    if (y == 0 && z == 0) m |= 1u << 0;
+    if (x == 0 && z == 0) m |= 1u << 3;
+    if (x == 0 && y == 0) m |= 1u << 8;
+    return m;
+}
+
+struct Cell {
+    double v[8];
+    int index;
+};
+
+__device__ __forceinline__ void load_cell(const float *__restrict__ vol, const Dims &d, int x, int y, int z, double level,
+                                          Cell &c, float &lo, float &hi) {
+    const size_t sy = (size_t)d.nx, sz = (size_t)d.nx * d.ny;
+    const float *p = vol + (size_t)z * sz + (size_t)y * sy + x;
+    const float f[8] = {p[0], p[1], p[sy + 1], p[sy], p[sz], p[sz + 1], p[sz + sy + 1], p[sz + sy]};
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c.v[k] = (double)f[k] - level;
+        if (c.v[k] > 0.0) idx |= 1 << k;
+        lo = fminf(lo, f[k]);
+        hi = fmaxf(hi, f[k]);
+    }
+    c.index = idx;
+}
+
+__device__ __forceinline__ void cell_xyz(const Dims &d, long long c, int &x, int &y, int &z) {
+    x = (int)(c % d.cx);
+    const long long r = c / d.cx;
+    y = (int)(r % d.cy);
+    z = (int)(r / d.cy);
+}
+
+// counts of one cell: triangles, vertices it creates
+__device__ __forceinline__ void count_cell(const Tiling &t, unsigned own, int &nt, int &nv) {
+    nt = t.nt;
+    unsigned seen = 0;
+    for (int i = 0; i < 3 * t.nt; ++i) seen |= 1u << t.row[i];
+    nv = __popc(seen & own);
+}
+
+// block-wide exclusive scan of one int per thread (256 threads), returns exclusive prefix; total via out param
+__device__ __forceinline__ int block_exscan(int val, int *lds /* [4] */, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(incl, o);
+        if (lane >= o) incl += n;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    total = lds[0] + lds[1] + lds[2] + lds[3];
+    return base + incl - val;
+}
+
+// ---------------------------------------------------------------- pass 1
+__global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restrict__ vol, Dims d, double level,
+                                                           int2 *__restrict__ block_counts, unsigned *__restrict__ minmax) {
+    __shared__ int red[2][4];
+    __shared__ float redf[2][4];
+    const long long c0 = (long long)blockIdx.x * CELLS_PER_BLOCK;
+    int nt_sum = 0, nv_sum = 0;
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
+        const long long c = c0 + r * THREADS + threadIdx.x;
+        if (c >= d.ncells) break;
+        int x, y, z;
+        cell_xyz(d, c, x, y, z);
+        Cell cell;
+        load_cell(vol, d, x, y, z, level, cell, lo, hi);
+        if (cell.index != 0 && cell.index != 255) {
+            const Tiling t = select_tiling(cell.v, cell.index);
+            int nt, nv;
+            count_cell(t, owned_mask(x, y, z), nt, nv);
+            nt_sum += nt;
+            nv_sum += nv;
+        }
+    }
+    // block reduce
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nt_sum += __shfl_xor(nt_sum, o);
+        nv_sum += __shfl_xor(nv_sum, o);
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if (lane == 0) { red[0][wave] = nv_sum; red[1][wave] = nt_sum; redf[0][wave] = lo; redf[1][wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_counts[blockIdx.x] = make_int2(red[0][0] + red[0][1] + red[0][2] + red[0][3],
+                                             red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        lo = fminf(fminf(redf[0][0], redf[0][1]), fminf(redf[0][2], redf[0][3]));
+        hi = fmaxf(fmaxf(redf[1][0], redf[1][1]), fmaxf(redf[1][2], redf[1][3]));
+        // order-preserving float -> uint key so that atomicMin/Max work for any sign
+        auto key = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        atomicMin(&minmax[0], key(lo));
+        atomicMax(&minmax[1], key(hi));
+    }
+}
+
+// ---------------------------------------------------------------- pass 2: exclusive scan of the block sums (one workgroup)
+__global__ __launch_bounds__(1024) void mc_scan_kernel(const int2 *__restrict__ counts, int2 *__restrict__ offsets, int nblocks,
+                                                       int *__restrict__ totals) {
+    __shared__ int wsum[2][16];
+    __shared__ int carry[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        int2 v = (i < nblocks) ? counts[i] : make_int2(0, 0);
+        int a = v.x, b = v.y;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int na = __shfl_up(a, o), nb = __shfl_up(b, o);
+            if (lane >= o) { a += na; b += nb; }
+        }
+        if (lane == 63) { wsum[0][wave] = a; wsum[1][wave] = b; }
+        __syncthreads();
+        int pa = carry[0], pb = carry[1];
+        for (int w = 0; w < wave; ++w) { pa += wsum[0][w]; pb += wsum[1][w]; }
+        if (i < nblocks) offsets[i] = make_int2(pa + a - v.x, pb + b - v.y);
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry[0] = pa + a; carry[1] = pb + b; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = carry[0]; totals[1] = carry[1]; }
+}
+
+// lattice edge of cell edge e: which voxel it starts at and its axis (0 = x, 1 = y, 2 = z); 12 -> table 3
+__device__ __forceinline__ void edge_slot(int e, int x, int y, int z, int &axis, int &vx, int &vy, int &vz) {
+    // EDGE_D*[e][0..1] are the two corner offsets; the edge starts at the smaller one
+    if (e == 12) { axis = 3; vx = x; vy = y; vz = z; return; }
+    const int dx0 = MCL_EDGE_DX[2 * e], dx1 = MCL_EDGE_DX[2 * e + 1];
+    const int dy0 = MCL_EDGE_DY[2 * e], dy1 = MCL_EDGE_DY[2 * e + 1];
+    const int dz0 = MCL_EDGE_DZ[2 * e], dz1 = MCL_EDGE_DZ[2 * e + 1];
+    axis = (dx0 != dx1) ? 0 : ((dy0 != dy1) ? 1 : 2);
+    vx = x + min(dx0, dx1);
+    vy = y + min(dy0, dy1);
+    vz = z + min(dz0, dz1);
+}
+
+// ---------------------------------------------------------------- pass 3a: vertices
+__global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restrict__ vol, Dims d, double level,
+                                                            const int2 *__restrict__ block_offsets,
+                                                            int *__restrict__ evid /* [4][nvox] */, float *__restrict__ verts,
+                                                            float *__restrict__ normals, float *__restrict__ values,
+                                                            int cap_verts) {
+    __shared__ int lds[4];
+    const long long c0 = (long long)blockIdx.x * CELLS_PER_BLOCK;
+    const size_t nvox = (size_t)d.nx * d.ny * d.nz;
+    int running = block_offsets[blockIdx.x].x;
+    for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
+        const long long c = c0 + r * THREADS + threadIdx.x;
+        int x = 0, y = 0, z = 0, nv = 0;
+        Cell cell;
+        Tiling t;
+        t.nt = 0;
+        t.row = nullptr;
+        unsigned own = 0;
+        if (c < d.ncells) {
+            cell_xyz(d, c, x, y, z);
+            float lo = 0, hi = 0;
+            load_cell(vol, d, x, y, z, level, cell, lo, hi);
+            if (cell.index != 0 && cell.index != 255) {
+                t = select_tiling(cell.v, cell.index);
+                own = owned_mask(x, y, z);
+                int nt;
+                count_cell(t, own, nt, nv);
+            }
+        }
+        int total;
+        const int ex = block_exscan(nv, lds, total);
+        if (nv > 0) {
+            int vid = running + ex;
+            unsigned seen = 0;
+            for (int i = 0; i < 3 * t.nt; ++i) {
+                const int e = t.row[i];
+                if (seen & (1u << e)) continue;
+                seen |= 1u << e;
+                if (!(own & (1u << e))) continue;
+                double px, py, pz;
+                if (e == 12) {
+                    const int cx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
+                    double fx = 0, fy = 0, fz = 0, ff = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const double w = 1.0 / (MC_EPS + fabs(cell.v[k]));
+                        fx += cx[k] * w; fy += cy[k] * w; fz += cz[k] * w; ff += w;
+                    }
+                    px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)z + fz / ff;
+                } else {
+                    const int dx1 = MCL_EDGE_DX[2 * e], dx2 = MCL_EDGE_DX[2 * e + 1];
+                    const int dy1 = MCL_EDGE_DY[2 * e], dy2 = MCL_EDGE_DY[2 * e + 1];
+                    const int dz1 = MCL_EDGE_DZ[2 * e], dz2 = MCL_EDGE_DZ[2 * e + 1];
+                    // corner number of (dx,dy,dz): v0..v7 = (0,0,0)(1,0,0)(1,1,0)(0,1,0)(0,0,1)(1,0,1)(1,1,1)(0,1,1)
+                    const int k1 = dz1 * 4 + (dy1 ? (dx1 ? 2 : 3) : (dx1 ? 1 : 0));
+                    const int k2 = dz2 * 4 + (dy2 ? (dx2 ? 2 : 3) : (dx2 ? 1 : 0));
+                    const double w1 = 1.0 / (MC_EPS + fabs(cell.v[k1])), w2 = 1.0 / (MC_EPS + fabs(cell.v[k2]));
+                    double fx = 0, fy = 0, fz = 0, ff = 0;
+                    fx += (double)dx1 * w1; fy += (double)dy1 * w1; fz += (double)dz1 * w1; ff += w1;
+                    fx += (double)dx2 * w2; fy += (double)dy2 * w2; fz += (double)dz2 * w2; ff += w2;
+                    px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)z + fz / ff;
+                }
+                int axis, vx, vy, vz;
+                edge_slot(e, x, y, z, axis, vx, vy, vz);
+                evid[(size_t)axis * nvox + ((size_t)vz * d.ny + vy) * d.nx + vx] = vid;
+                if (vid < cap_verts) {
+                    // output order (axis0, axis1, axis2) = (z, y, x)
+                    verts[3 * (size_t)vid + 0] = (float)pz;
+                    verts[3 * (size_t)vid + 1] = (float)py;
+                    verts[3 * (size_t)vid + 2] = (float)px;
+                    if (normals) { normals[3 * (size_t)vid] = 0.f; normals[3 * (size_t)vid + 1] = 0.f; normals[3 * (size_t)vid + 2] = 0.f; }
+                    if (values) values[vid] = 0.f;
+                }
+                ++vid;
+            }
+        }
+        running += total;
+    }
+}
+
+// ---------------------------------------------------------------- pass 3b: faces, values, normal accumulation
+__global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restrict__ vol, Dims d, double level,
+                                                          const int2 *__restrict__ block_offsets,
+                                                          const int *__restrict__ evid, int *__restrict__ faces,
+                                                          float *__restrict__ normals, float *__restrict__ values,
+                                                          int cap_verts, int cap_faces) {
+    __shared__ int lds[4];
+    const long long c0 = (long long)blockIdx.x * CELLS_PER_BLOCK;
+    const size_t nvox = (size_t)d.nx * d.ny * d.nz;
+    int running = block_offsets[blockIdx.x].y;
+    for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
+        const long long c = c0 + r * THREADS + threadIdx.x;
+        int x = 0, y = 0, z = 0;
+        Cell cell;
+        Tiling t;
+        t.nt = 0;
+        t.row = nullptr;
+        if (c < d.ncells) {
+            cell_xyz(d, c, x, y, z);
+            float lo = 0, hi = 0;
+            load_cell(vol, d, x, y, z, level, cell, lo, hi);
+            if (cell.index != 0 && cell.index != 255) t = select_tiling(cell.v, cell.index);
+        }
+        int total;
+        const int ex = block_exscan(t.nt, lds, total);
+        if (t.nt > 0) {
+            const int tri0 = running + ex;
+            const double *v = cell.v;
+            // per-cell quantities for values / normals (see oracle/mc_oracle.c for the black-box verified quirks)
+            double vlo = 0.0, vhi = 0.0;
+            for (int k = 0; k < 8; ++k) { if (v[k] > vhi) vhi = v[k]; if (v[k] < vlo) vlo = v[k]; }
+            const float vrange = (float)(vhi - vlo);
+            const double g[8][3] = {
+                {v[0] - v[1], v[0] - v[3], v[0] - v[4]}, {v[0] - v[1], v[1] - v[2], v[1] - v[5]},
+                {v[3] - v[2], v[1] - v[2], v[2] - v[6]}, {v[3] - v[2], v[0] - v[3], v[3] - v[7]},
+                {v[4] - v[5], v[4] - v[7], v[0] - v[4]}, {v[4] - v[5], v[5] - v[6], v[1] - v[5]},
+                {v[7] - v[6], v[5] - v[6], v[2] - v[6]}, {v[7] - v[6], v[4] - v[7], v[3] - v[7]}};
+            double c12g[3] = {0, 0, 0};
+            if (normals) {
+                double gy = 0, gz = 0;
+                for (int k = 0; k < 8; ++k) {
+                    const double w = 1.0 / (MC_EPS + fabs(v[k]));
+                    gy += w * g[k][1];
+                    gz += w * g[k][2];
+                }
+                c12g[0] = gz; c12g[1] = gy; c12g[2] = 0.0;  // quirk of the compiled core: (Gz, Gy, 0)
+            }
+            for (int i = 0; i < t.nt; ++i) {
+                int vid[3];
+                for (int j = 0; j < 3; ++j) {
+                    const int e = t.row[3 * i + j];
+                    int axis, vx, vy, vz;
+                    edge_slot(e, x, y, z, axis, vx, vy, vz);
+                    vid[j] = evid[(size_t)axis * nvox + ((size_t)vz * d.ny + vy) * d.nx + vx];
+                    if (vid[j] < cap_verts) {
+                        if (values) atomicMax(reinterpret_cast<int *>(values) + vid[j], __float_as_int(vrange));
+                        if (normals) {
+                            float *n = normals + 3 * (size_t)vid[j];
+                            if (e == 12) {
+                                atomicAdd(n + 0, (float)c12g[0]); atomicAdd(n + 1, (float)c12g[1]); atomicAdd(n + 2, (float)c12g[2]);
+                            } else {
+                                const int dx1 = MCL_EDGE_DX[2 * e], dx2 = MCL_EDGE_DX[2 * e + 1];
+                                const int dy1 = MCL_EDGE_DY[2 * e], dy2 = MCL_EDGE_DY[2 * e + 1];
+                                const int dz1 = MCL_EDGE_DZ[2 * e], dz2 = MCL_EDGE_DZ[2 * e + 1];
+                                const int i1 = dz1 * 4 + dy1 * 2 + dx1, i2 = dz2 * 4 + dy2 * 2 + dx2;  // xyz-bit index
+                                const int k1 = dz1 * 4 + (dy1 ? (dx1 ? 2 : 3) : (dx1 ? 1 : 0));
+                                const int k2 = dz2 * 4 + (dy2 ? (dx2 ? 2 : 3) : (dx2 ? 1 : 0));
+                                const double w1 = 1.0 / (MC_EPS + fabs(v[k1])), w2 = 1.0 / (MC_EPS + fabs(v[k2]));
+                                // the core indexes its corner-number gradient table with the xyz-bit index (quirk)
+                                for (int a = 0; a < 3; ++a) {
+                                    atomicAdd(n + a, (float)(g[i1][a] * w1));
+                                    atomicAdd(n + a, (float)(g[i2][a] * w2));
+                                }
+                            }
+                        }
+                    }
+                }
+                const int tri = tri0 + i;
+                if (tri < cap_faces) {
+                    // rows reversed (gradient_direction='descent')
+                    faces[3 * (size_t)tri + 0] = vid[2];
+                    faces[3 * (size_t)tri + 1] = vid[1];
+                    faces[3 * (size_t)tri + 2] = vid[0];
+                }
+            }
+        }
+        running += total;
+    }
+}
+
+// ---------------------------------------------------------------- pass 4: normalise and flip normals to (axis0, axis1, axis2)
+__global__ void mc_normalize_kernel(float *__restrict__ normals, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float *p = normals + 3 * (size_t)i;
+    const float nx = p[0], ny = p[1], nz = p[2];
+    const double len = sqrt((double)nx * nx + (double)ny * ny + (double)nz * nz);
+    float ox = nx, oy = ny, oz = nz;
+    if (len > 0.0) { ox = (float)(nx / len); oy = (float)(ny / len); oz = (float)(nz / len); }
+    p[0] = oz; p[1] = oy; p[2] = ox;
+}
+
+__global__ void mc_init_minmax(unsigned *mm) { mm[0] = 0xffffffffu; mm[1] = 0u; }
+
+}  // namespace mc
+}  // namespace surs
+
+using namespace surs;
+using namespace surs::mc;
+
+static int mc_nblocks(long long ncells) { return (int)((ncells + CELLS_PER_BLOCK - 1) / CELLS_PER_BLOCK); }
+
+extern "C" size_t surs_mc_workspace_bytes(int n0, int n1, int n2) {
+    if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
+    const long long ncells = (long long)(n0 - 1) * (n1 - 1) * (n2 - 1);
+    const size_t nb = (size_t)mc_nblocks(ncells);
+    const size_t nvox = (size_t)n0 * n1 * n2;
+    return align_up(nb * sizeof(int2), 256) * 2 + 256 + align_up(4 * nvox * sizeof(int), 256);
+}
+
+extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void *workspace,
+                               size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
+                               int32_t *faces, int cap_faces, surs_mc_counts *counts, void *stream) {
+    SURS_REQUIRE(vol && workspace && counts, "null argument");
+    SURS_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
+    SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
+    SURS_REQUIRE((long long)n0 * n1 * n2 < (1ll << 31) * 4, "volume too large");
+    hipStream_t st = as_stream(stream);
+    Dims d;
+    d.nz = n0; d.ny = n1; d.nx = n2;
+    d.cz = n0 - 1; d.cy = n1 - 1; d.cx = n2 - 1;
+    d.ncells = (long long)d.cz * d.cy * d.cx;
+    const int nb = mc_nblocks(d.ncells);
+    char *ws = (char *)workspace;
+    int2 *bcounts = (int2 *)ws; ws += align_up((size_t)nb * sizeof(int2), 256);
+    int2 *boffs = (int2 *)ws; ws += align_up((size_t)nb * sizeof(int2), 256);
+    unsigned *minmax = (unsigned *)ws;
+    int *totals = (int *)(ws + 16); ws += 256;
+    int *evid = (int *)ws;
+
+    hipLaunchKernelGGL(mc_init_minmax, dim3(1), dim3(1), 0, st, minmax);
+    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, bcounts, minmax);
+    SURS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, bcounts, boffs, nb, totals);
+    SURS_LAUNCH_CHECK();
+    struct { unsigned mm[2]; unsigned pad[2]; int tot[2]; } host;
+    SURS_HIP_CHECK(hipMemcpyAsync(&host, minmax, sizeof(host), hipMemcpyDeviceToHost, st));
+    SURS_HIP_CHECK(hipStreamSynchronize(st));
+    auto unkey = [](unsigned k) {
+        unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    counts->vmin = unkey(host.mm[0]);
+    counts->vmax = unkey(host.mm[1]);
+    counts->n_verts = host.tot[0];
+    counts->n_faces = host.tot[1];
+    if (level < (double)counts->vmin || level > (double)counts->vmax)
+        return fail(SURS_E_LEVEL_RANGE, "Surface level must be within volume data range.");
+    if (counts->n_verts == 0) return fail(SURS_E_NO_SURFACE, "No surface found at the given iso value.");
+    if (!verts || !faces) return 0;  // count-only call
+    if (counts->n_verts > cap_verts || counts->n_faces > cap_faces)
+        return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", counts->n_verts, counts->n_faces);
+    hipLaunchKernelGGL(mc_vertex_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, boffs, evid, verts, normals, values,
+                       cap_verts);
+    SURS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mc_face_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, boffs, evid, faces, normals, values,
+                       cap_verts, cap_faces);
+    SURS_LAUNCH_CHECK();
+    if (normals) {
+        hipLaunchKernelGGL(mc_normalize_kernel, dim3(ceil_div(counts->n_verts, 256)), dim3(256), 0, st, normals, counts->n_verts);
+        SURS_LAUNCH_CHECK();
+    }
+    SURS_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}

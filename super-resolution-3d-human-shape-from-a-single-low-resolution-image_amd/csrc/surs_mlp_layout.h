@@ -1,0 +1,81 @@
+// Layout of the packed SurfaceClassifier blob shared by the host packer and the kernels.
+//
+// Architecture (fixed; /root/reference/lib/options.py:88-97, lib/model/SurfaceClassifier.py:30-43):
+//   lr: 321 -> 1024 -> 512 -> (512+321) 256 -> (256+321) 128 -> (128+321) 1
+//   hr: 322 -> ...  (channel 321 = masked sigmoid output of lr)
+// Feature channel order: [ lr map 256 | hr map 64 | z_feat | p_lr ]   (SuRSNet.py:151-154,176-181)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace surs {
+
+constexpr int C_LR = 256, C_HR = 64, C_G = 320;  // gathered channels
+constexpr int C0PAD = 336;                       // feature rows incl. z, p_lr, zero padding (multiple of 16)
+constexpr int D1 = 1024, D2 = 512, D3 = 256, D4 = 128;
+
+// column-constant vector of the grid path (fp32), one per (i,j) column, in this order:
+constexpr int CC_A0_LR = 0, CC_A0_HR = 1024, CC_A2_LR = 2048, CC_A2_HR = 2304, CC_A3_LR = 2560, CC_A3_HR = 2688,
+              CC_A4_LR = 2816, CC_A4_HR = 2817, CC_N = 2818, CC_PAD = 2944;  // 23 * 128
+
+// z-vector block (fp32 offsets in floats), column independent
+constexpr int ZV_W0Z_LR = 0, ZV_W0Z_HR = 1024, ZV_W0P_HR = 2048, ZV_B1_LR = 3072, ZV_B1_HR = 3584,
+              ZV_W2Z_LR = 4096, ZV_W2Z_HR = 4352, ZV_W2P_HR = 4608, ZV_W3Z_LR = 4864, ZV_W3Z_HR = 4992,
+              ZV_W3P_HR = 5120, ZV_W4C_LR = 5248, ZV_W4C_HR = 5376, ZV_W4Z_LR = 5504, ZV_W4Z_HR = 5505,
+              ZV_W4P_HR = 5506, ZV_N = 5632;
+
+// dense cores in MFMA A-fragment order, streamed as fixed 32 KiB slabs (16-bit elements):
+//   per MLP: L1 (512x1024): 32 slabs of [2 k-steps][16 row tiles][64 lanes][8]
+//            L2 core (256x512): 8 slabs of [4 k-steps][8 row tiles][64][8]
+//            L3 core (128x256): 2 slabs of [8 k-steps][4 row tiles][64][8]
+constexpr int SLAB_BYTES = 32768, SLABS_L1 = 32, SLABS_L2 = 8, SLABS_L3 = 2, SLABS_PER_MLP = 42, SLABS_TOTAL = 84;
+
+struct MlpBlobHeader {
+    uint32_t magic;  // 'SURS'
+    uint32_t dtype;  // SURS_BF16 / SURS_F16 of the core slabs
+    // generic fp32 path; per MLP m (0 lr, 1 hr): k-major weights Wt[Kpad][M] of layers 0..3, biases, last layer
+    uint32_t wt[2][4];
+    uint32_t bias[2][4];
+    uint32_t w4[2];  // [128 + 336 + 1] : [y3 part | feature part (zero padded) | bias b4]
+    uint32_t reserved[2];
+    // grid path
+    uint32_t wc;    // fp32 k-major [320][CC_PAD]
+    uint32_t bc;    // fp32 [CC_PAD]
+    uint32_t zvec;  // fp32 [ZV_N]
+    uint32_t core;  // SLABS_TOTAL * SLAB_BYTES
+    uint32_t total_bytes;
+    uint32_t pad[5];
+};
+static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
+constexpr uint32_t MLP_MAGIC = 0x53525553u;
+
+// The offsets depend on nothing but the constants above, so host packer and launch code both derive them here
+// (no device->host read of the header is ever needed).
+inline MlpBlobHeader blob_layout(uint32_t dtype) {
+    MlpBlobHeader h = {};
+    h.magic = MLP_MAGIC;
+    h.dtype = dtype;
+    size_t off = 256;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) / 256 * 256;
+        return (uint32_t)o;
+    };
+    const int mout[4] = {D1, D2, D3, D4};
+    const int kpad[4] = {C0PAD, D1, D2 + C0PAD, D3 + C0PAD};
+    for (int m = 0; m < 2; ++m) {
+        for (int l = 0; l < 4; ++l) {
+            h.wt[m][l] = take((size_t)kpad[l] * mout[l] * 4);
+            h.bias[m][l] = take((size_t)mout[l] * 4);
+        }
+        h.w4[m] = take((size_t)(D4 + C0PAD + 1) * 4);
+    }
+    h.wc = take((size_t)C_G * CC_PAD * 4);
+    h.bc = take((size_t)CC_PAD * 4);
+    h.zvec = take((size_t)ZV_N * 4);
+    h.core = take((size_t)SLABS_TOTAL * SLAB_BYTES);
+    h.total_bytes = (uint32_t)off;
+    return h;
+}
+
+}  // namespace surs

@@ -1,0 +1,162 @@
+// HOST-side repacking of reference state-dict tensors into kernel layouts (no device code).
+//   surs_mlp_pack           SurfaceClassifier x2  (lib/model/SurfaceClassifier.py:30-43)
+//   surs_conv_pack_weights  nn.Conv2d weights     (lib/net_util.py:94-97)
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "surs_common.h"
+#include "surs_mlp_layout.h"
+
+namespace surs {
+
+static uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static uint16_t f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;  // round to nearest even
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+static const int kDims[2][6] = {{321, D1, D2, D3, D4, 1}, {322, D1, D2, D3, D4, 1}};
+
+}  // namespace surs
+
+using namespace surs;
+
+extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], const float *const w_hr[5],
+                                const float *const b_hr[5], int dtype, void *blob) {
+    if (dtype != SURS_BF16 && dtype != SURS_F16) dtype = SURS_BF16;
+    MlpBlobHeader h = blob_layout((uint32_t)dtype);
+    const size_t off = h.total_bytes;
+    const int kin_main[4] = {0, D1, D2, D3};  // width of the y part for layers 0..3 (layer 0 has none)
+    if (!blob) return off;
+
+    const float *const *W[2] = {w_lr, w_hr};
+    const float *const *B[2] = {b_lr, b_hr};
+    char *base = (char *)blob;
+    memset(base, 0, off);
+    memcpy(base, &h, sizeof(h));
+
+    for (int m = 0; m < 2; ++m) {
+        const int c0 = kDims[m][0];
+        for (int l = 0; l < 4; ++l) {
+            const int mo = kDims[m][l + 1];
+            const int ymain = kin_main[l];
+            const int kin = (l == 0) ? c0 : (l == 1 ? D1 : ymain + c0);  // Conv1d in_channels
+            float *wt = (float *)(base + h.wt[m][l]);
+            // reference weight row o: [ y part (ymain) | feature part (c0) ] for l >= 2; all features for l = 0
+            for (int o = 0; o < mo; ++o)
+                for (int k = 0; k < kin; ++k) wt[(size_t)k * mo + o] = W[m][l][(size_t)o * kin + k];
+            memcpy(base + h.bias[m][l], B[m][l], (size_t)mo * 4);
+        }
+        float *w4 = (float *)(base + h.w4[m]);
+        memcpy(w4, W[m][4], (size_t)(D4 + c0) * 4);
+        w4[D4 + C0PAD] = B[m][4][0];
+    }
+    // ---- grid path: column-constant matrix, k-major [320][CC_PAD]
+    {
+        float *wc = (float *)(base + h.wc);
+        float *bc = (float *)(base + h.bc);
+        auto put_rows = [&](int cc0, const float *w, int rows, int kin, int col0, const float *b) {
+            for (int o = 0; o < rows; ++o) {
+                for (int k = 0; k < C_G; ++k) wc[(size_t)k * CC_PAD + cc0 + o] = w[(size_t)o * kin + col0 + k];
+                bc[cc0 + o] = b[o];
+            }
+        };
+        put_rows(CC_A0_LR, W[0][0], D1, 321, 0, B[0][0]);
+        put_rows(CC_A0_HR, W[1][0], D1, 322, 0, B[1][0]);
+        put_rows(CC_A2_LR, W[0][2], D3, D2 + 321, D2, B[0][2]);
+        put_rows(CC_A2_HR, W[1][2], D3, D2 + 322, D2, B[1][2]);
+        put_rows(CC_A3_LR, W[0][3], D4, D3 + 321, D3, B[0][3]);
+        put_rows(CC_A3_HR, W[1][3], D4, D3 + 322, D3, B[1][3]);
+        put_rows(CC_A4_LR, W[0][4], 1, D4 + 321, D4, B[0][4]);
+        put_rows(CC_A4_HR, W[1][4], 1, D4 + 322, D4, B[1][4]);
+    }
+    // ---- z-vectors
+    {
+        float *zv = (float *)(base + h.zvec);
+        for (int o = 0; o < D1; ++o) {
+            zv[ZV_W0Z_LR + o] = W[0][0][(size_t)o * 321 + 320];
+            zv[ZV_W0Z_HR + o] = W[1][0][(size_t)o * 322 + 320];
+            zv[ZV_W0P_HR + o] = W[1][0][(size_t)o * 322 + 321];
+        }
+        memcpy(zv + ZV_B1_LR, B[0][1], D2 * 4);
+        memcpy(zv + ZV_B1_HR, B[1][1], D2 * 4);
+        for (int o = 0; o < D3; ++o) {
+            zv[ZV_W2Z_LR + o] = W[0][2][(size_t)o * (D2 + 321) + D2 + 320];
+            zv[ZV_W2Z_HR + o] = W[1][2][(size_t)o * (D2 + 322) + D2 + 320];
+            zv[ZV_W2P_HR + o] = W[1][2][(size_t)o * (D2 + 322) + D2 + 321];
+        }
+        for (int o = 0; o < D4; ++o) {
+            zv[ZV_W3Z_LR + o] = W[0][3][(size_t)o * (D3 + 321) + D3 + 320];
+            zv[ZV_W3Z_HR + o] = W[1][3][(size_t)o * (D3 + 322) + D3 + 320];
+            zv[ZV_W3P_HR + o] = W[1][3][(size_t)o * (D3 + 322) + D3 + 321];
+            zv[ZV_W4C_LR + o] = W[0][4][o];
+            zv[ZV_W4C_HR + o] = W[1][4][o];
+        }
+        zv[ZV_W4Z_LR] = W[0][4][D4 + 320];
+        zv[ZV_W4Z_HR] = W[1][4][D4 + 320];
+        zv[ZV_W4P_HR] = W[1][4][D4 + 321];
+    }
+    // ---- dense cores in MFMA A-fragment order
+    {
+        uint16_t *core = (uint16_t *)(base + h.core);
+        auto cvt = [&](float f) { return dtype == SURS_F16 ? f32_to_f16(f) : f32_to_bf16(f); };
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = kDims[m][0];
+            uint16_t *p = core + (size_t)m * SLABS_PER_MLP * (SLAB_BYTES / 2);
+            // L1: natural k order inside a k-step
+            for (int s = 0; s < D1 / 16; ++s)
+                for (int T = 0; T < D2 / 32; ++T)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = lane & 31, hh = lane >> 5;
+                            p[(((size_t)s * 16 + T) * 64 + lane) * 8 + j] =
+                                cvt(W[m][1][(size_t)(32 * T + r) * D1 + 16 * s + 8 * hh + j]);
+                        }
+            p += (size_t)SLABS_L1 * (SLAB_BYTES / 2);
+            // L2 / L3 cores: k order of an accumulator tile reused as B operand
+            for (int s = 0; s < D2 / 16; ++s)
+                for (int T = 0; T < D3 / 32; ++T)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = lane & 31, hh = lane >> 5;
+                            const int kin = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+                            p[(((size_t)s * 8 + T) * 64 + lane) * 8 + j] =
+                                cvt(W[m][2][(size_t)(32 * T + r) * (D2 + c0) + kin]);
+                        }
+            p += (size_t)SLABS_L2 * (SLAB_BYTES / 2);
+            for (int s = 0; s < D3 / 16; ++s)
+                for (int T = 0; T < D4 / 32; ++T)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = lane & 31, hh = lane >> 5;
+                            const int kin = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+                            p[(((size_t)s * 4 + T) * 64 + lane) * 8 + j] =
+                                cvt(W[m][3][(size_t)(32 * T + r) * (D3 + c0) + kin]);
+                        }
+        }
+    }
+    return off;
+}
+
+extern "C" size_t surs_conv_pack_weights(const float *w, int cout, int cin, int ksize, float *out) {
+    // kernel layout [tap][cin_pad][cout_pad], cin_pad multiple of 16, cout_pad multiple of 64
+    const int cin_pad = (cin + 15) / 16 * 16, cout_pad = (cout + 63) / 64 * 64, taps = ksize * ksize;
+    const size_t n = (size_t)taps * cin_pad * cout_pad;
+    if (!out) return n;
+    memset(out, 0, n * sizeof(float));
+    for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < taps; ++t)
+                out[((size_t)t * cin_pad + c) * cout_pad + o] = w[((size_t)o * cin + c) * taps + t];
+    return n;
+}

@@ -1,0 +1,737 @@
+// Point evaluator for gfx950 (MI355X): project -> in-image mask -> bilinear gather -> z-feat ->
+// SurfaceClassifier lr -> sigmoid*mask -> SurfaceClassifier hr -> sigmoid*mask.
+//
+// Replaces (reference, /root/reference):
+//   orthogonal        lib/geometry.py:15-31        index (grid_sample)  lib/geometry.py:4-12
+//   DepthNormalizer   lib/model/DepthNormalizer.py:18
+//   query_mr/query_sr lib/model/SuRSNet.py:131-187   get_preds  lib/model/BaseSuRSNet.py:80-85
+//   SurfaceClassifier.forward  lib/model/SurfaceClassifier.py:53-81
+//   create_grid / eval_grid / eval_func   lib/sdf.py:4-52, lib/mesh_util.py:16-34   (grid entry point)
+//
+// Two arithmetic modes:
+//   fp32  (parity mode, any points): gather kernel -> channel-major feature matrix F[336][N]; each MLP layer is
+//         one launch of a 128x128x16 LDS-tiled GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chains) with the
+//         skip-concat done as a second K segment instead of a materialised torch.cat.
+//   bf16/f16 (grid mode): all voxels of a (i,j) column share their 320 gathered features, so the feature part of
+//         layers 0,2,3,4 is a per-column constant (computed in fp32 by the same GEMM, 0.1 % of the work) and
+//         only the dense cores 1024->512, 512->256, 256->128 run per voxel - on v_mfma_f32_32x32x16_{bf16,f16},
+//         activations never leaving registers (an accumulator tile is the next layer's B operand), weights
+//         streamed L2 -> LDS by LDS-DMA in 32 KiB slabs shared by the 4 waves of the workgroup.
+#include <hip/hip_runtime.h>
+
+#include "surs_common.h"
+#include "surs_mlp_layout.h"
+
+namespace surs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------------
+// point generation + projection shared by the gather kernel
+// ------------------------------------------------------------------------------------------------
+struct PointSource {
+    // mode 0: explicit points [3][n] (ld = n_total);  mode 1: grid voxels, flat index base+t, z fastest;
+    // mode 2: grid columns, flat column index base+t = i*ry + j (k = 0)
+    int mode;
+    const float *pts;
+    long long ld;
+    long long base;
+    int ry, rz;
+    double mat[12];  // create_grid's coords_matrix rows 0..2
+    float calib[12];
+    float zmul, zdiv;
+};
+
+__device__ __forceinline__ void make_point(const PointSource &s, long long t, float &px, float &py, float &pz) {
+    if (s.mode == 0) {
+        px = s.pts[t];
+        py = s.pts[s.ld + t];
+        pz = s.pts[2 * s.ld + t];
+    } else {
+        long long f = s.base + t;
+        double i, j, k;
+        if (s.mode == 1) {
+            k = (double)(f % s.rz);
+            j = (double)((f / s.rz) % s.ry);
+            i = (double)(f / ((long long)s.rz * s.ry));
+        } else {
+            k = 0.0;
+            j = (double)(f % s.ry);
+            i = (double)(f / s.ry);
+        }
+        // np.matmul(coords_matrix[:3,:3], idx) + coords_matrix[:3,3:4] in float64, then .float()
+        px = (float)(((s.mat[0] * i + s.mat[1] * j) + s.mat[2] * k) + s.mat[3]);
+        py = (float)(((s.mat[4] * i + s.mat[5] * j) + s.mat[6] * k) + s.mat[7]);
+        pz = (float)(((s.mat[8] * i + s.mat[9] * j) + s.mat[10] * k) + s.mat[11]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather: F[c][n] for c < 320 (bilinear, zeros padding, align_corners=True), F[320][n] = z_feat,
+//         F[321][n] = 0 (p_lr slot), mask[n] = in_img, zproj[n] = projected Z (for the column kernel: Z at k = 0)
+// One workgroup = 64 points; wave w gathers points 16w..16w+15 with lanes = channels (coalesced 256 B per
+// tap), transposes through LDS and stores with lanes = points (coalesced).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long n, const float *__restrict__ feat_lr,
+                                                     int hl, int wl, const float *__restrict__ feat_hr, int hh,
+                                                     int wh, float *__restrict__ F, long long ldf,
+                                                     float *__restrict__ mask, float *__restrict__ zproj) {
+    __shared__ float tile[64][65];
+    __shared__ float sx[64], sy[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long n0 = (long long)blockIdx.x * 64;
+    if (tid < 64) {
+        long long t = n0 + tid;
+        float X = 2.0f, Y = 2.0f;  // outside
+        if (t < n) {
+            float px, py, pz;
+            make_point(src, t, px, py, pz);
+            const float *c = src.calib;
+            X = c[3] + ((c[0] * px + c[1] * py) + c[2] * pz);
+            Y = c[7] + ((c[4] * px + c[5] * py) + c[6] * pz);
+            const float Z = c[11] + ((c[8] * px + c[9] * py) + c[10] * pz);
+            const float in = (X >= -1.0f && X <= 1.0f && Y >= -1.0f && Y <= 1.0f) ? 1.0f : 0.0f;
+            mask[t] = in;
+            if (zproj) zproj[t] = Z;
+            F[(long long)C_G * ldf + t] = Z * src.zmul / src.zdiv;
+            F[(long long)(C_G + 1) * ldf + t] = 0.0f;
+        }
+        sx[tid] = X;
+        sy[tid] = Y;
+    }
+    __syncthreads();
+    // 5 channel chunks of 64: 4 from the lr map, 1 from the hr map
+    for (int chunk = 0; chunk < 5; ++chunk) {
+        const bool is_hr = chunk == 4;
+        const float *feat = is_hr ? feat_hr : feat_lr;
+        const int H = is_hr ? hh : hl, W = is_hr ? wh : wl, C = is_hr ? C_HR : C_LR;
+        const int c0 = is_hr ? 0 : chunk * 64;
+        for (int q = 0; q < 16; ++q) {
+            const int p = wave * 16 + q;
+            const float u = sx[p], v = sy[p];
+            const float ix = ((u + 1.0f) / 2.0f) * (float)(W - 1);
+            const float iy = ((v + 1.0f) / 2.0f) * (float)(H - 1);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
+            const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
+            const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H,
+                       vy1 = y1 >= 0 && y1 < H;
+            float a = 0.0f;
+            const long long ch = c0 + lane;
+            if (vy0 && vx0) a += feat[((long long)y0 * W + x0) * C + ch] * wnw;
+            if (vy0 && vx1) a += feat[((long long)y0 * W + x1) * C + ch] * wne;
+            if (vy1 && vx0) a += feat[((long long)y1 * W + x0) * C + ch] * wsw;
+            if (vy1 && vx1) a += feat[((long long)y1 * W + x1) * C + ch] * wse;
+            tile[lane][p] = a;
+        }
+        __syncthreads();
+        const int cbase = is_hr ? C_LR : chunk * 64;
+        for (int q = 0; q < 16; ++q) {
+            const int ch = wave * 16 + q;
+            if (n0 + lane < n) F[(long long)(cbase + ch) * ldf + n0 + lane] = tile[ch][lane];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 GEMM on MFMA:  Y[m][n] = act( sum_k Wt[k][m] * X[k][n] + bias[m] ),  k over two segments (X1 then X2)
+//   M, N multiples of 128; K1, K2 multiples of 16.  128x128 block tile, BK = 16, 4 waves as 2x2, each wave
+//   64x64 = 2x2 tiles of v_mfma_f32_32x32x2_f32.  Operands are k-major in global memory and in LDS, so global
+//   loads are 512 B coalesced per row and LDS fragment reads are conflict-free consecutive dwords.
+// ------------------------------------------------------------------------------------------------
+template <bool TRANSPOSED_OUT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ Wt, int M,
+                                                       const float *__restrict__ X1, int K1, long long ld1,
+                                                       const float *__restrict__ X2, int K2, long long ld2,
+                                                       const float *__restrict__ bias, int act,
+                                                       float *__restrict__ Y, long long ldy) {
+    __shared__ __attribute__((aligned(16))) float As[2][16][128];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long n0 = (long long)blockIdx.x * 128;
+    const int m0 = blockIdx.y * 128;
+    const int ktiles = (K1 + K2) / 16;
+    const int lrow = tid >> 5, lcol = (tid & 31) * 4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 ra[2], rb[2];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * 16;
+        const float *X;
+        long long ld;
+        int kx;
+        if (k0 < K1) { X = X1; ld = ld1; kx = k0; } else { X = X2; ld = ld2; kx = k0 - K1; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lrow + 8 * i;
+            ra[i] = *reinterpret_cast<const f32x4 *>(Wt + (long long)(k0 + row) * M + m0 + lcol);
+            rb[i] = *reinterpret_cast<const f32x4 *>(X + (long long)(kx + row) * ld + n0 + lcol);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lrow + 8 * i;
+            *reinterpret_cast<f32x4 *>(&As[buf][row][lcol]) = ra[i];
+            *reinterpret_cast<f32x4 *>(&Bs[buf][row][lcol]) = rb[i];
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) load_tile(kt + 1);
+        const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[buf][2 * kk + kh][wm * 64 + i * 32 + li];
+                b[i] = Bs[buf][2 * kk + kh][wn * 64 + i * 32 + li];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < ktiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: acc[i][j][r] is row m = (r&3) + 8*(r>>2) + 4*(lane>>5), column n = lane&31 of its 32x32 tile
+    const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = m0 + wm * 64 + i * 32 + 8 * g + 4 * kh;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][4 * g + r] + (bias ? bias[m + r] : 0.0f);
+                    if (act == 1) t = t > 0.0f ? t : 0.01f * t;
+                    v[r] = t;
+                }
+                if (TRANSPOSED_OUT) {
+                    *reinterpret_cast<f32x4 *>(Y + n * ldy + m) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Y[(long long)(m + r) * ldy + n] = v[r];
+                }
+            }
+        }
+}
+
+// last layer (Cout = 1) + sigmoid * mask.  One thread per point, coalesced over points.
+//   logit = b4 + w4[0:128].Y3[:,n] + w4[128:128+336].F[:,n];  pred = mask * sigmoid(logit)
+__global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__ w4,
+                                                       const float *__restrict__ Y3, const float *__restrict__ F,
+                                                       long long ld, long long n, const float *__restrict__ mask,
+                                                       float *__restrict__ pred, float *__restrict__ logit,
+                                                       float *__restrict__ p_slot) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float acc = w4[D4 + C0PAD];  // b4
+    for (int k = 0; k < D4; ++k) acc = fmaf(w4[k], Y3[(long long)k * ld + t], acc);
+    for (int k = 0; k < C_G + 2; ++k) acc = fmaf(w4[D4 + k], F[(long long)k * ld + t], acc);
+    const float p = mask[t] * (1.0f / (1.0f + expf(-acc)));
+    pred[t] = p;
+    if (logit) logit[t] = acc;
+    if (p_slot) p_slot[t] = p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration of the fp32 path
+// ------------------------------------------------------------------------------------------------
+struct Fp32Workspace {
+    float *F, *Y0, *Y1, *Y2, *Y3, *mask;
+    long long np;  // padded point count (multiple of 128)
+};
+
+static size_t fp32_ws_bytes(long long np) { return (size_t)np * (C0PAD + D1 + D2 + D3 + D4 + 1) * sizeof(float) + 4096; }
+
+static Fp32Workspace carve_fp32(void *ws, long long np) {
+    Fp32Workspace w;
+    float *p = (float *)ws;
+    w.np = np;
+    w.F = p; p += (size_t)C0PAD * np;
+    w.Y0 = p; p += (size_t)D1 * np;
+    w.Y1 = p; p += (size_t)D2 * np;
+    w.Y2 = p; p += (size_t)D3 * np;
+    w.Y3 = p; p += (size_t)D4 * np;
+    w.mask = p;
+    return w;
+}
+
+static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, int M, const float *X1, int K1, long long ld1,
+                       const float *X2, int K2, long long ld2, const float *bias, int act, float *Y, long long ldy,
+                       long long np) {
+    dim3 grid((unsigned)(np / 128), (unsigned)(M / 128));
+    if (transposed)
+        hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+// runs gather + both MLPs for `n` points described by src; outputs may be offset pointers
+static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, const float *feat_lr, int hl, int wl,
+                           const float *feat_hr, int hh, int wh, const char *blob, const MlpBlobHeader &h,
+                           const Fp32Workspace &w, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr) {
+    const long long np = w.np;
+    // rows 322..335 of F meet zero weights and must be finite: the caller zeroes them once (zero_pad_rows);
+    // rows < 322 are fully written for t < n; columns n..np-1 only feed outputs that are never read
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
+                       hh, wh, w.F, np, w.mask, (float *)nullptr);
+    SURS_LAUNCH_CHECK();
+    for (int m = 0; m < 2; ++m) {
+        auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
+        auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
+        int rc;
+        if ((rc = launch_gemm(st, false, WT(0), D1, w.F, C0PAD, np, nullptr, 0, 0, BI(0), 1, w.Y0, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(1), D2, w.Y0, D1, np, nullptr, 0, 0, BI(1), 1, w.Y1, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(2), D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(3), D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
+        hipLaunchKernelGGL(mlp_last_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                           (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
+                           m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr);
+        SURS_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid column kernel (bf16 / f16 MFMA)
+// ------------------------------------------------------------------------------------------------
+template <int DT> struct HalfT;
+template <> struct HalfT<SURS_BF16> {
+    typedef __bf16 elem;
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 vec2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct HalfT<SURS_F16> {
+    typedef _Float16 elem;
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 vec2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct GridArgs {
+    const float *cc;       // [ncols][CC_PAD] column constants
+    const float *colmask;  // [ncols]
+    const float *zvec;     // [ZV_N]
+    const char *core;      // SLABS_TOTAL slabs
+    float *vol_hr, *vol_lr;  // [ncols][rz]
+    int ncols, rz;
+    double z0, dz;  // world z of voxel k = (float)(dz*k + z0)
+    float c22, c23;  // Z(k) = c23 + c22 * z(k)   (calib[2][0] = calib[2][1] = 0 in column mode)
+    float zmul, zdiv;
+};
+
+constexpr int GRID_LDS_RING = 2 * SLAB_BYTES;
+constexpr int GRID_LDS_BYTES = GRID_LDS_RING + (CC_PAD + ZV_N) * 4;
+
+__device__ __forceinline__ float lrelu01(float x) { return fmaxf(x, 0.01f * x); }
+
+// every wave waits for its own LDS-DMA pieces, then the workgroup barrier publishes the slab
+__device__ __forceinline__ void slab_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// Issue the LDS-DMA of the next 32 KiB slab of the weight stream: 4 waves x 8 pieces of 1 KiB (64 lanes x 16 B).
+// `gsrc` is this lane's running source pointer (stream base + wave*8192 + lane*16); it advances by one slab per
+// call and wraps after SLABS_TOTAL, so no slab address is loop invariant (hipcc would hoist and spill hundreds).
+struct SlabStream {
+    const char *gsrc;
+    int count;  // slabs issued since the last wrap
+};
+__device__ __forceinline__ void stage_slab(SlabStream &st, char *lds_dst_wave) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st.gsrc + i * 1024),
+                                         (__attribute__((address_space(3))) void *)(lds_dst_wave + i * 1024), 16, 0, 0);
+    st.gsrc += SLAB_BYTES;
+}
+
+// LDS byte offsets of the constant region (after the slab ring)
+constexpr int LDS_CC = GRID_LDS_RING;             // column constants [CC_PAD] fp32
+constexpr int LDS_ZV = GRID_LDS_RING + CC_PAD * 4;  // z-vectors [ZV_N] fp32
+
+// All LDS addresses in the hot loops are (one per-lane base register) + (compile-time immediate): the per-lane
+// parts are made opaque so that hipcc neither re-associates them into hundreds of distinct hoisted address
+// registers (which it then spills) nor loses the ds_read `offset:` folding.
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int DT, int M /* 0 lr, 1 hr */>
+__device__ __forceinline__ float grid_mlp(SlabStream &st, char *smem, int wave, int lane, float zf, float p_in) {
+    typedef HalfT<DT> H;
+    typedef typename H::vec8 vec8;
+    constexpr int A0 = LDS_CC + 4 * (M ? CC_A0_HR : CC_A0_LR), A2 = LDS_CC + 4 * (M ? CC_A2_HR : CC_A2_LR),
+                  A3 = LDS_CC + 4 * (M ? CC_A3_HR : CC_A3_LR), A4 = LDS_CC + 4 * (M ? CC_A4_HR : CC_A4_LR);
+    constexpr int W0Z = LDS_ZV + 4 * (M ? ZV_W0Z_HR : ZV_W0Z_LR), W0P = LDS_ZV + 4 * ZV_W0P_HR,
+                  B1 = LDS_ZV + 4 * (M ? ZV_B1_HR : ZV_B1_LR), W2Z = LDS_ZV + 4 * (M ? ZV_W2Z_HR : ZV_W2Z_LR),
+                  W2P = LDS_ZV + 4 * ZV_W2P_HR, W3Z = LDS_ZV + 4 * (M ? ZV_W3Z_HR : ZV_W3Z_LR),
+                  W3P = LDS_ZV + 4 * ZV_W3P_HR, W4C = LDS_ZV + 4 * (M ? ZV_W4C_HR : ZV_W4C_LR),
+                  W4Z = LDS_ZV + 4 * (M ? ZV_W4Z_HR : ZV_W4Z_LR), W4P = LDS_ZV + 4 * ZV_W4P_HR;
+    const unsigned h16 = opaque((unsigned)(lane >> 5) * 16u);   // accumulator rows: channel 4h within a group of 8
+    const unsigned lane16 = opaque((unsigned)lane * 16u);       // A fragments: 16 B per lane
+    char *cst = smem + h16;                                     // + immediate: constants indexed by channel
+    char *frag = smem + lane16;                                 // + immediate: fragment (ks, T) of a slab
+    char *dma = smem + opaque((unsigned)wave * 8192u);          // + immediate: this wave's share of a ring buffer
+    auto ld4 = [&](int byte_off) { return *reinterpret_cast<const f32x4 *>(cst + byte_off); };
+    auto ldfrag = [&](int byte_off) { return *reinterpret_cast<const vec8 *>(frag + byte_off); };
+
+    // ---------------- layer 1: 1024 -> 512, B operand generated on the fly from the column constants
+    // accumulator register r of row tile T is channel 32T + (r&3) + 8(r>>2) + 4h: 4 consecutive per group g = r>>2
+    f32x16 acc[16];
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = ld4(B1 + 4 * (32 * T + 8 * g));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[T][4 * g + r] = b[r];
+        }
+#pragma unroll 1
+    for (int sl = 0; sl < SLABS_L1; sl += 2) {
+        // channels of this lane's B fragment: 16*(2*(sl+half)+ks) + 8h + j  ->  bytes 128*sl + 2*h16 + imm
+        char *kb = smem + opaque(128u * (unsigned)sl + 2u * h16);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            stage_slab(st, dma + (half ^ 1) * SLAB_BYTES);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int imm = 64 * (2 * half + ks) + 16 * q;
+                    const f32x4 c = *reinterpret_cast<const f32x4 *>(kb + A0 + imm);
+                    const f32x4 wz = *reinterpret_cast<const f32x4 *>(kb + W0Z + imm);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaf(zf, wz[r], c[r]);
+                    if (M) {
+                        const f32x4 wp = *reinterpret_cast<const f32x4 *>(kb + W0P + imm);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaf(p_in, wp[r], v[4 * q + r]);
+                    }
+                }
+                vec8 bfrag;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bfrag[j] = (typename H::elem)lrelu01(v[j]);
+#pragma unroll
+                for (int T = 0; T < 16; ++T)
+                    acc[T] = H::mfma(ldfrag(half * SLAB_BYTES + (ks * 16 + T) * 1024), bfrag, acc[T]);
+            }
+            slab_barrier();
+        }
+    }
+    // y1 as B fragments: k-step s' = 2T + u takes registers 8u..8u+7 of tile T
+    vec8 y1[32];
+#pragma unroll
+    for (int T = 0; T < 16; ++T)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y1[2 * T + u][j] = (typename H::elem)lrelu01(acc[T][8 * u + j]);
+
+    // ---------------- layer 2 core: 512 -> 256, accumulator preloaded with the column/z part
+    f32x16 acc2[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int off = 4 * (32 * T + 8 * g);
+            const f32x4 c = ld4(A2 + off), wz = ld4(W2Z + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc2[T][4 * g + r] = fmaf(zf, wz[r], c[r]);
+            if (M) {
+                const f32x4 wp = ld4(W2P + off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[T][4 * g + r] = fmaf(p_in, wp[r], acc2[T][4 * g + r]);
+            }
+        }
+#pragma unroll
+    for (int sl = 0; sl < SLABS_L2; ++sl) {
+        stage_slab(st, dma + ((sl & 1) ^ 1) * SLAB_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int T = 0; T < 8; ++T)
+                acc2[T] = H::mfma(ldfrag((sl & 1) * SLAB_BYTES + (ks * 8 + T) * 1024), y1[4 * sl + ks], acc2[T]);
+        slab_barrier();
+    }
+    vec8 y2[16];
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y2[2 * T + u][j] = (typename H::elem)lrelu01(acc2[T][8 * u + j]);
+
+    // ---------------- layer 3 core: 256 -> 128
+    f32x16 acc3[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int off = 4 * (32 * T + 8 * g);
+            const f32x4 c = ld4(A3 + off), wz = ld4(W3Z + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc3[T][4 * g + r] = fmaf(zf, wz[r], c[r]);
+            if (M) {
+                const f32x4 wp = ld4(W3P + off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc3[T][4 * g + r] = fmaf(p_in, wp[r], acc3[T][4 * g + r]);
+            }
+        }
+#pragma unroll
+    for (int sl = 0; sl < SLABS_L3; ++sl) {
+        // the slab after this MLP's last one is the first slab of the other MLP (the stream wraps around)
+        stage_slab(st, dma + ((sl & 1) ^ 1) * SLAB_BYTES);
+        if (M == 1 && sl == SLABS_L3 - 2) st.gsrc -= (size_t)SLABS_TOTAL * SLAB_BYTES;  // next stage fetches slab 0
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+                acc3[T] = H::mfma(ldfrag((sl & 1) * SLAB_BYTES + (ks * 4 + T) * 1024), y2[8 * sl + ks], acc3[T]);
+        slab_barrier();
+    }
+    // ---------------- layer 4: 128 -> 1 on the VALU (fp32); the two halves of the channel set live in lanes l, l^32
+    float part = 0.0f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = ld4(W4C + 4 * (32 * T + 8 * g));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(w[r], lrelu01(acc3[T][4 * g + r]), part);
+        }
+    part += __shfl_xor(part, 32);
+    float y4 = fmaf(zf, *reinterpret_cast<const float *>(smem + W4Z), *reinterpret_cast<const float *>(smem + A4));
+    if (M) y4 = fmaf(p_in, *reinterpret_cast<const float *>(smem + W4P), y4);
+    return y4 + part;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *colc = reinterpret_cast<float *>(smem + GRID_LDS_RING);
+    float *zv = colc + CC_PAD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < ZV_N; i += 256) zv[i] = a.zvec[i];
+    // first slab of the stream
+    SlabStream st;
+    st.gsrc = a.core + wave * 8192 + lane * 16;
+    st.count = 0;
+    stage_slab(st, smem + wave * 8192);
+    const int nzc = (a.rz + 127) / 128;
+    for (int col = blockIdx.x; col < a.ncols; col += gridDim.x) {
+        __syncthreads();  // everyone is done with the previous column's constants (and slab 0 has landed)
+        const float *src = a.cc + (size_t)col * CC_PAD;
+        for (int i = tid; i < CC_N; i += 256) colc[i] = src[i];
+        const float cmask = a.colmask[col];
+        __syncthreads();
+        for (int zc = 0; zc < nzc; ++zc) {
+            const int k = zc * 128 + wave * 32 + (lane & 31);
+            const double zt = a.dz * (double)k;
+            const float zw = (float)(zt + a.z0);
+            const float Z = a.c23 + a.c22 * zw;
+            const float zf = Z * a.zmul / a.zdiv;
+            const float l_lr = grid_mlp<DT, 0>(st, smem, wave, lane, zf, 0.0f);
+            const float p_lr = cmask * (1.0f / (1.0f + expf(-l_lr)));
+            const float l_hr = grid_mlp<DT, 1>(st, smem, wave, lane, zf, p_lr);
+            const float p_hr = cmask * (1.0f / (1.0f + expf(-l_hr)));
+            if (k < a.rz) {
+                float *dst = (lane < 32) ? a.vol_lr : a.vol_hr;
+                dst[(size_t)col * a.rz + k] = (lane < 32) ? p_lr : p_hr;
+            }
+        }
+    }
+    __syncthreads();  // drain the last prefetch before the workgroup retires
+}
+
+}  // namespace surs
+
+using namespace surs;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
+    SURS_HIP_CHECK(hipMemsetAsync(w.F + (size_t)(C_G + 2) * w.np, 0, (size_t)(C0PAD - C_G - 2) * w.np * sizeof(float), st));
+    return 0;
+}
+
+extern "C" size_t surs_query_workspace_bytes(int max_points) {
+    long long np = (long long)ceil_div(max_points, 128) * 128;
+    return fp32_ws_bytes(np);
+}
+
+static void fill_calib(PointSource &s, const float *calib, float zmul, float zdiv) {
+    for (int i = 0; i < 12; ++i) s.calib[i] = calib[i];
+    s.zmul = zmul;
+    s.zdiv = zdiv;
+}
+
+extern "C" int surs_query_points(const float *points, int n, const float *calib, float zmul, float zdiv,
+                                 const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                                 const void *mlp_blob, void *workspace, size_t workspace_bytes, float *pred_hr,
+                                 float *pred_lr, float *logit_hr, float *logit_lr, void *stream) {
+    SURS_REQUIRE(points && calib && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
+    SURS_REQUIRE(n >= 0 && hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
+    if (n == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    const long long np = (long long)ceil_div(n, 128) * 128;
+    SURS_REQUIRE(workspace_bytes >= fp32_ws_bytes(np), "workspace too small: need %zu bytes", fp32_ws_bytes(np));
+    const MlpBlobHeader h = blob_layout(SURS_BF16);
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.mode = 0;
+    src.pts = points;
+    src.ld = n;
+    fill_calib(src, calib, zmul, zdiv);
+    Fp32Workspace w = carve_fp32(workspace, np);
+    int rc = zero_pad_rows(st, w);
+    if (rc) return rc;
+    return run_points_fp32(st, src, n, feat_lr, hl, wl, feat_hr, hh, wh, (const char *)mlp_blob, h, w, pred_hr, pred_lr,
+                           logit_hr, logit_lr);
+}
+
+// grid batches: fp32 mode evaluates GRID_BATCH voxels per pass; column mode COL_BATCH columns per pass
+static const long long GRID_BATCH = 65536;
+static const long long COL_BATCH = 16384;
+
+static size_t col_ws_bytes(long long ncb) {
+    // F rows 0..335 for the column gather + CC + mask
+    return (size_t)ncb * (C0PAD + CC_PAD + 1) * sizeof(float) + 4096;
+}
+
+extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
+    (void)ry; (void)rz;
+    if (dtype == SURS_F32) return fp32_ws_bytes(GRID_BATCH);
+    return col_ws_bytes(COL_BATCH);
+}
+
+extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
+                               float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                               const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *vol_hr,
+                               float *vol_lr, void *stream) {
+    SURS_REQUIRE(mat && calib && feat_lr && feat_hr && mlp_blob && workspace && vol_hr && vol_lr, "null argument");
+    SURS_REQUIRE(i1 >= i0 && ry > 0 && rz > 0, "bad grid range");
+    SURS_REQUIRE(workspace_bytes >= surs_query_grid_workspace_bytes(ry, rz, dtype), "workspace too small");
+    if (i1 == i0) return 0;
+    hipStream_t st = as_stream(stream);
+    const MlpBlobHeader h = blob_layout((uint32_t)dtype);
+    int rc = 0;
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.ry = ry;
+    src.rz = rz;
+    for (int i = 0; i < 12; ++i) src.mat[i] = mat[i];
+    fill_calib(src, calib, zmul, zdiv);
+    const char *blob = (const char *)mlp_blob;
+
+    if (dtype == SURS_F32) {
+        const long long total = (long long)(i1 - i0) * ry * rz;
+        Fp32Workspace w = carve_fp32(workspace, GRID_BATCH);
+        if ((rc = zero_pad_rows(st, w))) return rc;
+        src.mode = 1;
+        for (long long b0 = 0; b0 < total; b0 += GRID_BATCH) {
+            const long long nb = (total - b0 < GRID_BATCH) ? total - b0 : GRID_BATCH;
+            src.base = (long long)i0 * ry * rz + b0;
+            rc = run_points_fp32(st, src, nb, feat_lr, hl, wl, feat_hr, hh, wh, blob, h, w, vol_hr + b0, vol_lr + b0,
+                                 nullptr, nullptr);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    SURS_REQUIRE(dtype == SURS_BF16 || dtype == SURS_F16, "unknown dtype %d", dtype);
+    // column mode needs: projected X,Y independent of k; world z a function of k only
+    const float cX = (float)(calib[0] * mat[2] + calib[1] * mat[6] + calib[2] * mat[10]);
+    const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
+    if (cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f)
+        return fail(SURS_E_UNSUPPORTED,
+                    "column kernel needs an axis-aligned orthographic sweep (X,Y independent of k); use SURS_F32");
+    const long long ncols = (long long)(i1 - i0) * ry;
+    float *F = (float *)workspace;
+    float *CC = F + (size_t)C0PAD * COL_BATCH;
+    float *cmask = CC + (size_t)CC_PAD * COL_BATCH;
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[dtype]) {
+        if (dtype == SURS_BF16)
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
+        else
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_F16>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
+        attr_set[dtype] = true;
+    }
+    src.mode = 2;
+    for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
+        const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
+        const long long ncp = (long long)ceil_div(nc, 128) * 128;
+        src.base = (long long)i0 * ry + c0;
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr);
+        SURS_LAUNCH_CHECK();
+        rc = launch_gemm(st, true, (const float *)(blob + h.wc), CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
+                         (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
+        if (rc) return rc;
+        GridArgs a;
+        a.cc = CC;
+        a.colmask = cmask;
+        a.zvec = (const float *)(blob + h.zvec);
+        a.core = blob + h.core;
+        a.vol_hr = vol_hr + (size_t)c0 * rz;
+        a.vol_lr = vol_lr + (size_t)c0 * rz;
+        a.ncols = (int)nc;
+        a.rz = rz;
+        a.z0 = mat[11];
+        a.dz = mat[10];
+        a.c22 = calib[10];
+        a.c23 = calib[11];
+        a.zmul = zmul;
+        a.zdiv = zdiv;
+        const unsigned grid = (unsigned)((nc < cus) ? nc : cus);
+        if (dtype == SURS_BF16)
+            hipLaunchKernelGGL(grid_mlp_kernel<SURS_BF16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
+        SURS_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,253 @@
+"""Thin torch-tensor wrappers over the C ABI (include/surs.h).
+
+PyTorch is used for device memory and streams only; every function here hands raw
+device pointers to libsurs_hip.so.  Tensors must live on the current CUDA (HIP)
+device.  Nothing here computes on the CPU and nothing falls back.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BF16, DTYPES, F16, F32, check, lib  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor expected"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), "contiguous float32 tensor expected"
+    return t
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("surs_amd needs a HIP device (MI355X); there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def device_info():
+    cu = C.c_int(0)
+    arch = C.create_string_buffer(32)
+    check(lib().surs_device_info(C.byref(cu), arch))
+    return cu.value, arch.value.decode()
+
+
+# ------------------------------------------------------------------ NHWC image tensors
+
+class Img:
+    """NHWC fp32 device image: a view (h, w, c) into a buffer with channel pitch ld."""
+    __slots__ = ("buf", "h", "w", "c", "ld", "off")
+
+    def __init__(self, h, w, c, ld=None, buf=None, off=0, device=None):
+        ld = c if ld is None else ld
+        if buf is None:
+            buf = torch.empty(h * w * ld, dtype=torch.float32, device=device or require_gpu())
+        self.buf, self.h, self.w, self.c, self.ld, self.off = buf, h, w, c, ld, off
+
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 4 * self.off)
+
+    def slice(self, c0, c):
+        """channels [c0, c0+c) of the same pixels (the reference's torch.cat, in place)."""
+        return Img(self.h, self.w, c, self.ld, self.buf, self.off + c0)
+
+    def to_nchw(self):
+        out = torch.empty((1, self.c, self.h, self.w), dtype=torch.float32, device=self.buf.device)
+        check(lib().surs_nhwc_to_nchw(self.ptr(), self.c, self.h, self.w, self.ld, _ptr(out), _stream()))
+        return out
+
+    @staticmethod
+    def from_nchw(t, ld=None):
+        t = _f32c(t.reshape(t.shape[-3:]).contiguous())
+        c, h, w = t.shape
+        img = Img(h, w, c, ld, device=t.device)
+        check(lib().surs_nchw_to_nhwc(_ptr(t), c, h, w, img.ptr(), img.ld, _stream()))
+        return img
+
+
+class ConvWeights:
+    """Packed conv weights ([tap][cin_pad][cout_pad]) + bias on the device."""
+
+    def __init__(self, w, b, device):
+        w = np.ascontiguousarray(w, np.float32)
+        self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
+        n = lib().surs_conv_pack_weights(None, self.cout, self.cin, self.k, None)
+        packed = np.empty(n, np.float32)
+        lib().surs_conv_pack_weights(w.ctypes.data_as(C.c_void_p), self.cout, self.cin, self.k,
+                                     packed.ctypes.data_as(C.c_void_p))
+        self.w = torch.from_numpy(packed).to(device)
+        self.b = torch.from_numpy(np.ascontiguousarray(b, np.float32)).to(device) if b is not None else None
+
+
+def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope=0.0, residual=None):
+    pad = cw.k // 2
+    ho, wo = (x.h + 2 * pad - cw.k) // stride + 1, (x.w + 2 * pad - cw.k) // stride + 1
+    assert x.c == cw.cin
+    if out is None:
+        out = Img(ho, wo, cw.cout, device=x.buf.device)
+    assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
+    check(lib().surs_conv2d_nhwc(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(cw.w), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
+                                 stride, _ptr(in_scale), _ptr(in_shift), act, slope,
+                                 residual.ptr() if residual is not None else None,
+                                 residual.ld if residual is not None else 0, _stream()))
+    return out
+
+
+def groupnorm_coeffs(x, gamma, beta, groups=32, eps=1e-5):
+    scale = torch.empty(x.c, dtype=torch.float32, device=x.buf.device)
+    shift = torch.empty_like(scale)
+    check(lib().surs_groupnorm_coeffs(x.ptr(), x.h * x.w, x.c, x.ld, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale),
+                                      _ptr(shift), _stream()))
+    return scale, shift
+
+
+def scale_shift_act(x, scale, shift, relu, out=None):
+    out = out or Img(x.h, x.w, x.c, device=x.buf.device)
+    check(lib().surs_scale_shift_act(x.ptr(), x.h * x.w, x.c, x.ld, _ptr(scale), _ptr(shift), int(relu), out.ptr(), out.ld,
+                                     _stream()))
+    return out
+
+
+def avgpool2(x, out=None):
+    out = out or Img(x.h // 2, x.w // 2, x.c, device=x.buf.device)
+    check(lib().surs_avgpool2(x.ptr(), x.h, x.w, x.c, x.ld, out.ptr(), out.ld, _stream()))
+    return out
+
+
+def bicubic_up2(x, align_corners, addend=None, out=None):
+    out = out or Img(2 * x.h, 2 * x.w, x.c, device=x.buf.device)
+    check(lib().surs_bicubic_up2(x.ptr(), x.h, x.w, x.c, x.ld, int(bool(align_corners)),
+                                 addend.ptr() if addend is not None else None, addend.ld if addend is not None else 0,
+                                 out.ptr(), out.ld, _stream()))
+    return out
+
+
+def pixel_shuffle2(x, slope, out=None):
+    out = out or Img(2 * x.h, 2 * x.w, x.c // 4, device=x.buf.device)
+    check(lib().surs_pixel_shuffle2(x.ptr(), x.h, x.w, x.c, x.ld, slope, out.ptr(), out.ld, _stream()))
+    return out
+
+
+def add3(a, b, c=None, out=None):
+    out = out or Img(a.h, a.w, a.c, device=a.buf.device)
+    check(lib().surs_add3(a.ptr(), a.ld, b.ptr(), b.ld, c.ptr() if c is not None else None, c.ld if c is not None else 0,
+                          a.h * a.w, a.c, out.ptr(), out.ld, _stream()))
+    return out
+
+
+# ------------------------------------------------------------------ point evaluator
+
+def pack_mlp(sd, dtype, device):
+    """Pack mlp_lr / mlp_hr from a (numpy) state dict into the device blob of surs_mlp_pack."""
+    keep = []
+
+    def arrs(prefix):
+        ws, bs = (C.c_void_p * 5)(), (C.c_void_p * 5)()
+        for l in range(5):
+            w = np.ascontiguousarray(np.asarray(sd[prefix + "conv%d.weight" % l], np.float32).reshape(
+                np.asarray(sd[prefix + "conv%d.weight" % l]).shape[0], -1))
+            b = np.ascontiguousarray(np.asarray(sd[prefix + "conv%d.bias" % l], np.float32))
+            keep.extend([w, b])
+            ws[l], bs[l] = w.ctypes.data, b.ctypes.data
+        return ws, bs
+
+    expect = {"mlp_lr.": [(1024, 321), (512, 1024), (256, 833), (128, 577), (1, 449)],
+              "mlp_hr.": [(1024, 322), (512, 1024), (256, 834), (128, 578), (1, 450)]}
+    for prefix, shapes in expect.items():
+        for l, s in enumerate(shapes):
+            got = tuple(np.asarray(sd[prefix + "conv%d.weight" % l]).shape[:2])
+            if got != s:
+                raise ValueError("unsupported SurfaceClassifier shape %s%d: %s (the kernels are built for the "
+                                 "reference's default mlp_dim / res_layers)" % (prefix, l, got))
+    wl, bl = arrs("mlp_lr.")
+    wh, bh = arrs("mlp_hr.")
+    code = DTYPES[dtype] if isinstance(dtype, str) else dtype
+    core = BF16 if code == F32 else code
+    n = lib().surs_mlp_pack(wl, bl, wh, bh, core, None)
+    host = np.zeros(n, np.uint8)
+    lib().surs_mlp_pack(wl, bl, wh, bh, core, host.ctypes.data_as(C.c_void_p))
+    return torch.from_numpy(host).to(device), core
+
+
+class Workspace:
+    """Grow-only device scratch buffer."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_logits=False):
+    """points [3,N] f32 device tensor; calib: 12 floats (host); feat_*: Img with ld == c.  Returns pred_hr, pred_lr[, logits]."""
+    points = _f32c(points)
+    n = points.shape[1]
+    dev = points.device
+    outs = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(4 if want_logits else 2)]
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    need = lib().surs_query_workspace_bytes(n)
+    w = ws.get(need)
+    assert feat_lr.ld == feat_lr.c == 256 and feat_hr.ld == feat_hr.c == 64
+    check(lib().surs_query_points(_ptr(points), n, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
+                                  feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), _ptr(w), w.numel(), _ptr(outs[0]),
+                                  _ptr(outs[1]), _ptr(outs[2]) if want_logits else None,
+                                  _ptr(outs[3]) if want_logits else None, _stream()))
+    return tuple(outs)
+
+
+def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None):
+    """Dense sweep of grid slab [i0, i1): returns (vol_hr, vol_lr) float32 device tensors [(i1-i0), ry, rz]."""
+    dev = blob.device
+    if vol_hr is None:
+        vol_hr = torch.empty((i1 - i0, ry, rz), dtype=torch.float32, device=dev)
+        vol_lr = torch.empty_like(vol_hr)
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    code = DTYPES[dtype] if isinstance(dtype, str) else dtype
+    need = lib().surs_query_grid_workspace_bytes(ry, rz, code)
+    w = ws.get(need)
+    check(lib().surs_query_grid(i0, i1, ry, rz, m, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
+                                feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), code, _ptr(w), w.numel(), _ptr(vol_hr),
+                                _ptr(vol_lr), _stream()))
+    return vol_hr, vol_lr
+
+
+# ------------------------------------------------------------------ marching cubes
+
+def marching_cubes_lewiner(vol, level, ws, want_normals=True):
+    """vol: float32 device tensor [n0,n1,n2].  Returns device tensors (verts [V,3] f32, faces [F,3] i32, normals, values).
+    Raises ValueError / RuntimeError like skimage.measure.marching_cubes_lewiner."""
+    if vol.dim() != 3:
+        raise ValueError("Input volume should be a 3D numpy array.")
+    if min(vol.shape) < 2:
+        raise ValueError("Input array must be at least 2x2x2.")
+    vol = _f32c(vol.to(torch.float32).contiguous())
+    n0, n1, n2 = vol.shape
+    w = ws.get(lib().surs_mc_workspace_bytes(n0, n1, n2))
+    counts = _lib.McCounts()
+    check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), None, None, None, 0, None, 0,
+                                C.byref(counts), _stream()))
+    nv, nf = counts.n_verts, counts.n_faces
+    dev = vol.device
+    verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
+    normals = torch.empty((nv, 3), dtype=torch.float32, device=dev) if want_normals else None
+    values = torch.empty((nv,), dtype=torch.float32, device=dev) if want_normals else None
+    check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), _ptr(verts), _ptr(normals),
+                                _ptr(values), nv, _ptr(faces), nf, C.byref(counts), _stream()))
+    return verts, faces, normals, values

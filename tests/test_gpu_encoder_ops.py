@@ -1,0 +1,89 @@
+"""GPU parity of the encoder primitives (through the C ABI) against the C oracle on seeded inputs.
+fp32 MFMA fmaf chains vs the oracle's fp32 sums: relative tolerance 2e-5 of the output range."""
+import numpy as np
+import pytest
+import torch
+
+import common
+from surs_amd import prng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import gpu_common as g
+    import oracle
+    from surs_amd import native
+    return dict(g=g, native=native, oracle=oracle, dev=g.dev())
+
+
+def _img(env, x):
+    return env["g"].upload_nhwc(x)
+
+
+def _chw(img):
+    return img.to_nchw()[0].cpu().numpy()
+
+
+@pytest.mark.parametrize("cin,cout,h,w,k,stride,bias", [
+    (3, 32, 37, 45, 3, 1, True),      # head: cin not a multiple of 4, ragged tile
+    (32, 32, 64, 64, 3, 2, True),     # strided down conv
+    (64, 128, 33, 31, 3, 1, True),
+    (256, 128, 16, 16, 3, 1, False),  # ConvBlock conv1 (bias free)
+    (64, 64, 40, 24, 1, 1, True),     # 1x1
+    (512, 512, 8, 8, 3, 1, True),     # bott2 at the smallest size
+    (32, 3, 20, 20, 3, 1, True),      # last: cout 3
+])
+def test_conv(env, cin, cout, h, w, k, stride, bias):
+    nat, orc = env["native"], env["oracle"]
+    x = prng.uniform("cx", cin * 7 + h, (cin, h, w), -1, 1)
+    wt = prng.uniform("cw", cout * 3 + cin, (cout, cin, k, k), -0.2, 0.2)
+    b = prng.uniform("cb", cout, (cout,), -0.5, 0.5) if bias else None
+    ref = orc.conv2d(x, wt, b, stride)
+    cw = nat.ConvWeights(wt, b, env["dev"])
+    y = _chw(nat.conv2d(_img(env, x), cw, stride=stride))
+    assert y.shape == ref.shape
+    assert common.rel_err(y, ref) < 2e-5
+
+
+def test_conv_fused_groupnorm_relu_lrelu_residual_slice(env):
+    """ConvBlock-style use: GN coefficients -> conv with fused GN-apply+ReLU prologue, LeakyReLU epilogue,
+    residual add, output written into a channel slice of a wider tensor (the reference's torch.cat)."""
+    nat, orc = env["native"], env["oracle"]
+    cin, cout, h, w = 64, 32, 24, 20
+    x = prng.uniform("gx", 1, (cin, h, w), -2, 3)
+    gamma, beta = prng.uniform("gg", 1, (cin,), 0.5, 1.5), prng.uniform("gb", 1, (cin,), -0.3, 0.3)
+    wt = prng.uniform("gw", 1, (cout, cin, 3, 3), -0.1, 0.1)
+    res = prng.uniform("gr", 1, (cout, h, w), -1, 1)
+    ref = orc.lrelu(orc.conv2d(orc.relu(orc.group_norm(x, gamma, beta)), wt), 0.2) + res
+    X = _img(env, x)
+    sc, sh = nat.groupnorm_coeffs(X, torch.from_numpy(gamma).to(env["dev"]), torch.from_numpy(beta).to(env["dev"]))
+    wide = nat.Img(h, w, 96, device=env["dev"])
+    wide.buf.zero_()
+    nat.conv2d(X, nat.ConvWeights(wt, None, env["dev"]), out=wide.slice(64, 32), in_scale=sc, in_shift=sh, act=1, slope=0.2,
+               residual=_img(env, res))
+    full = _chw(wide)
+    assert common.rel_err(full[64:], ref) < 2e-5
+    assert np.all(full[:64] == 0)
+    # GroupNorm apply alone
+    y = _chw(nat.scale_shift_act(X, sc, sh, True))
+    assert common.rel_err(y, orc.relu(orc.group_norm(x, gamma, beta))) < 2e-5
+
+
+def test_pool_bicubic_shuffle_add(env):
+    nat, orc = env["native"], env["oracle"]
+    x = prng.uniform("px", 2, (64, 18, 26), -1, 1)
+    X = _img(env, x)
+    assert np.array_equal(_chw(nat.avgpool2(X)), orc.avg_pool2(x))
+    for ac in (True, False):
+        assert common.rel_err(_chw(nat.bicubic_up2(X, ac)), orc.bicubic_up2(x, ac)) < 1e-6
+    add = prng.uniform("pa", 3, (64, 36, 52), -1, 1)
+    assert common.rel_err(_chw(nat.bicubic_up2(X, True, addend=_img(env, add))), add + orc.bicubic_up2(x, True)) < 1e-6
+    assert np.array_equal(_chw(nat.pixel_shuffle2(X, 0.2)), orc.lrelu(orc.pixel_shuffle2(x), 0.2))
+    y = prng.uniform("py", 4, (64, 18, 26), -1, 1)
+    z = prng.uniform("pz", 5, (64, 18, 26), -1, 1)
+    assert np.array_equal(_chw(nat.add3(X, _img(env, y), _img(env, z))), (x + y) + z)
+    assert np.array_equal(_chw(nat.add3(X, _img(env, y))), x + y)
+    t = torch.from_numpy(x[None]).to(env["dev"])
+    assert np.array_equal(_chw(nat.Img.from_nchw(t)), x)

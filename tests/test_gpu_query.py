@@ -1,0 +1,92 @@
+"""GPU parity of the point evaluator (through the C ABI) against the reference's golden outputs and the oracle.
+Tolerances: fp32 mode 1e-4 on occupancies and pre-sigmoid logits (BASELINE.json north_star);
+bf16 / fp16 grid mode has its own, looser bound, stated per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+ZMUL, ZDIV = 1024 // 2, 200.0
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import gpu_common as g
+    from surs_amd import native
+    fl, fh = common.synth_features()
+    return dict(g=g, native=native, fl=fl, fh=fh, Fl=g.upload_nhwc(fl), Fh=g.upload_nhwc(fh), ws=native.Workspace(g.dev()))
+
+
+def _q(s, pts, calib):
+    nat = s["native"]
+    p = torch.from_numpy(np.ascontiguousarray(pts)).to(s["g"].dev())
+    outs = nat.query_points(p, np.asarray(calib, np.float32).reshape(-1)[:12], ZMUL, ZDIV, s["Fl"], s["Fh"],
+                            s["g"].blob("bf16"), s["ws"], want_logits=True)
+    return [o.cpu().numpy() for o in outs]
+
+
+def test_query_50k_vs_reference(setup, golden_dir):
+    from surs_amd import weights
+    g = np.load(os.path.join(golden_dir, "query.npz"))
+    phr, plr, lhr, llr = _q(setup, weights.synthetic_points(50000, seed=2), common.CALIB)
+    assert np.abs(phr - g["a_pred_hr"]).max() < 1e-4
+    assert np.abs(plr - g["a_pred_lr"]).max() < 1e-4
+    assert np.abs(lhr - g["a_logit_hr"]).max() < 1e-4
+    assert np.abs(llr - g["a_logit_lr"]).max() < 1e-4
+    assert ((phr == 0) == (g["a_pred_hr"] == 0)).all()
+
+
+def test_query_general_calib_ragged_and_edges(setup, golden_dir):
+    from surs_amd import weights
+    g = np.load(os.path.join(golden_dir, "query.npz"))
+    phr, plr, lhr, llr = _q(setup, weights.synthetic_points(4099, seed=5), g["b_calib"])
+    assert np.abs(phr - g["b_pred_hr"]).max() < 1e-4 and np.abs(plr - g["b_pred_lr"]).max() < 1e-4
+    assert np.abs(lhr - g["b_logit_hr"]).max() < 2e-4
+    phr, plr, _, _ = _q(setup, g["c_points"], common.CALIB)
+    assert np.abs(phr - g["c_pred_hr"]).max() < 1e-4 and np.abs(plr - g["c_pred_lr"]).max() < 1e-4
+    assert phr[5] == 0 and phr[6] == 0 and phr[0] > 0
+    # single point and empty input
+    one = _q(setup, g["c_points"][:, :1], common.CALIB)
+    assert abs(one[0][0] - g["c_pred_hr"][0]) < 1e-4
+    empty = _q(setup, np.zeros((3, 0), np.float32), common.CALIB)
+    assert empty[0].shape == (0,)
+
+
+def _grid(s, R, dtype, i0=0, i1=None):
+    import oracle
+    nat = s["native"]
+    mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)
+    i1 = R if i1 is None else i1
+    vh, vl = nat.query_grid(i0, i1, R, R, mat[:3].reshape(-1), common.CALIB.reshape(-1)[:12], ZMUL, ZDIV, s["Fl"], s["Fh"],
+                            s["g"].blob("f16" if dtype == "fp16" else "bf16"), dtype, s["ws"])
+    return vh.cpu().numpy(), vl.cpu().numpy()
+
+
+def test_grid_fp32_vs_oracle(setup):
+    import oracle
+    R = 24
+    vh, vl = _grid(setup, R, "fp32")
+    pts = oracle.grid_points(R, [-0.5] * 3, [0.5] * 3)
+    phr, plr = oracle.query(common.state_dict(), pts, common.CALIB, setup["fl"], setup["fh"], 1024, 200.0)
+    assert np.abs(vh.reshape(-1) - phr).max() < 1e-4
+    assert np.abs(vl.reshape(-1) - plr).max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
+def test_grid_column_kernel_vs_fp32(setup, dtype, tol):
+    """Reduced-precision column kernel vs the fp32 path on the same grid (ragged R: 40 is not a multiple of the
+    128-voxel z tile, and 40*40 columns is not a multiple of the column batch)."""
+    R = 40
+    vh32, vl32 = _grid(setup, R, "fp32")
+    vh, vl = _grid(setup, R, dtype)
+    eh, el = np.abs(vh - vh32).max(), np.abs(vl - vl32).max()
+    print("column kernel %s: max|d| hr %.3e lr %.3e, mean|d| hr %.3e" % (dtype, eh, el, np.abs(vh - vh32).mean()))
+    assert eh < tol and el < tol
+    # slab consistency: evaluating [i0,i1) separately gives identical bits (multi-GPU sharding property)
+    a, _ = _grid(setup, R, dtype, 8, 24)
+    assert np.array_equal(a, vh[8:24])
