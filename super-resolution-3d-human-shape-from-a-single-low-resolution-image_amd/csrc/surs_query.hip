@@ -605,9 +605,10 @@ extern "C" int surs_query_points(const float *points, int n, const float *calib,
                                  const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
                                  const void *mlp_blob, void *workspace, size_t workspace_bytes, float *pred_hr,
                                  float *pred_lr, float *logit_hr, float *logit_lr, void *stream) {
+    SURS_REQUIRE(n >= 0, "negative point count");
+    if (n == 0) return 0;  // empty batch: nothing to do (pointers may be null)
     SURS_REQUIRE(points && calib && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
-    SURS_REQUIRE(n >= 0 && hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
-    if (n == 0) return 0;
+    SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
     hipStream_t st = as_stream(stream);
     const long long np = (long long)ceil_div(n, 128) * 128;
     SURS_REQUIRE(workspace_bytes >= fp32_ws_bytes(np), "workspace too small: need %zu bytes", fp32_ws_bytes(np));
