@@ -146,6 +146,10 @@ int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void
                     float *verts, float *normals, float *values, int cap_verts, int32_t *faces, int cap_faces,
                     surs_mc_counts *counts, void *stream);
 
+/* out[i] = mat[:3,:3] @ verts[i] + mat[:3,3] in float64 (mat HOST [12] doubles, rows 0..2 of the 4x4 index->world
+ * matrix): the vertex transform of lib/mesh_util.py:42-43,47-48.  verts fp32 [n][3], out fp64 [n][3]. */
+int surs_transform_points(const float *verts, int n, const double *mat, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

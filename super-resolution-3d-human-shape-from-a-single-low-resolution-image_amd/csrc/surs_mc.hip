@@ -538,6 +538,16 @@ __global__ void mc_normalize_kernel(float *__restrict__ normals, int n) {
 
 __global__ void mc_init_minmax(unsigned *mm) { mm[0] = 0xffffffffu; mm[1] = 0u; }
 
+// verts_world = mat[:3,:3] @ v + mat[:3,3]  in float64 (lib/mesh_util.py:42-43,47-48)
+struct Affine { double m[12]; };
+__global__ void transform_points_kernel(const float *__restrict__ v, int n, Affine a, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = v[3 * (size_t)i], y = v[3 * (size_t)i + 1], z = v[3 * (size_t)i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) out[3 * (size_t)i + r] = ((a.m[4 * r] * x + a.m[4 * r + 1] * y) + a.m[4 * r + 2] * z) + a.m[4 * r + 3];
+}
+
 }  // namespace mc
 }  // namespace surs
 
@@ -609,5 +619,15 @@ extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double 
         SURS_LAUNCH_CHECK();
     }
     SURS_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int surs_transform_points(const float *verts, int n, const double *mat, double *out, void *stream) {
+    if (n == 0) return 0;
+    SURS_REQUIRE(verts && mat && out && n > 0, "bad argument");
+    Affine a;
+    for (int i = 0; i < 12; ++i) a.m[i] = mat[i];
+    hipLaunchKernelGGL(transform_points_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), verts, n, a, out);
+    SURS_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,160 @@
+"""Image encoder orchestration: which kernel runs on which tensor, in the reference's order.
+
+Host code only sequences calls into the C ABI (native.py); all arithmetic is in csrc/surs_encoder.hip.
+Mirrors, layer for layer:
+  SuRSSR_v3.forward           /root/reference/lib/model/SuRSSR_v3.py:143-181   (ResBlock: lib/model/common.py:14-33)
+  HGFilter.forward low_res    lib/model/HGFilters.py:183-206  (ConvBlock :57-74, HourGlass :96-117)
+  HGFilter.forward high_res   lib/model/HGFilters.py:179-181
+torch.cat is never materialised: producers write into channel slices of the concatenated tensor.
+"""
+import numpy as np
+import torch
+
+from . import native
+from .native import Img
+
+
+class EncoderWeights:
+    """Device-side packed weights of every conv / GroupNorm that is live at eval time."""
+
+    def __init__(self, sd, opt, device):
+        self.device = device
+        self.conv = {}
+        self.gn = {}
+        self.opt = opt
+
+        def get(k):
+            v = sd[k]
+            return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+        def add_conv(name, bias=True):
+            self.conv[name] = native.ConvWeights(get(name + ".weight"), get(name + ".bias") if bias else None, device)
+
+        def add_gn(name):
+            self.gn[name] = (torch.from_numpy(np.ascontiguousarray(get(name + ".weight"), np.float32)).to(device),
+                             torch.from_numpy(np.ascontiguousarray(get(name + ".bias"), np.float32)).to(device))
+
+        def add_block(prefix):
+            for c in ("conv1", "conv2", "conv3"):
+                add_conv(prefix + c, bias=False)
+            for g in ("bn1", "bn2", "bn3"):
+                add_gn(prefix + g)
+
+        S = "super_resolution."
+        names = ["head.0", "bottleneck.0", "bott2.0", "ups2.0", "ups3.0", "ups4.0", "last.0", "last.2"]
+        for i, nb in zip((1, 2, 3), opt.n_block):
+            names += ["down%d.0" % i, "tail%d.0" % i, "tail%d.2" % i]
+            for b in range(nb):
+                names += ["body%d.%d.body.0" % (i, b), "body%d.%d.body.2" % (i, b)]
+        for n in names:
+            add_conv(S + n)
+        add_conv("image_filter_hr.conv5")
+        L = "image_filter_lr."
+        add_block(L + "conv2.")
+        for s in range(opt.num_stack_lr):
+            def gen(level):
+                add_block(L + "m%d.b1_%d." % (s, level))
+                add_block(L + "m%d.b2_%d." % (s, level))
+                if level > 1:
+                    gen(level - 1)
+                else:
+                    add_block(L + "m%d.b2_plus_%d." % (s, level))
+                add_block(L + "m%d.b3_%d." % (s, level))
+            gen(opt.hg_depth)
+            add_block(L + "top_m_%d." % s)
+            add_conv(L + "conv_last%d" % s)
+            add_gn(L + "bn_end%d" % s)
+            add_conv(L + "l%d" % s)
+            if s < opt.num_stack_lr - 1:
+                add_conv(L + "bl%d" % s)
+                add_conv(L + "al%d" % s)
+
+
+LRELU = dict(act=1, slope=0.2)
+RELU = dict(act=1, slope=0.0)
+
+
+def super_res(W, x):
+    """x: Img [H,W,3].  Returns (img_SR [2H,2W,3], new2 = feature_lr [H/2,W/2,256], new_fin = feature_hr [2H,2W,64])."""
+    opt, P, cv = W.opt, "super_resolution.", native.conv2d
+    if x.h % 4 or x.w % 4:
+        raise ValueError("input image height/width must be multiples of 4 (three stride-2 stages), got %dx%d" % (x.h, x.w))
+    dev = x.buf.device
+    H2, W2 = 2 * x.h, 2 * x.w
+    fin = Img(H2, W2, 64, device=dev)             # cat(h, up3)
+    new3 = Img(x.h, x.w, 128, device=dev)          # cat(d1_f, up2)
+    new2 = Img(x.h // 2, x.w // 2, 256, device=dev)  # cat(d2_f, up1)   -> feature_lr
+    new1 = Img(x.h // 4, x.w // 4, 512, device=dev)  # cat(d3_f, bo)
+    up = native.bicubic_up2(x, False)
+    h = cv(up, W.conv[P + "head.0"], out=fin.slice(0, 32), **LRELU)
+
+    def stage(i, src, dst):
+        d = cv(src, W.conv[P + "down%d.0" % i], stride=2, **LRELU)
+        if opt.residual:
+            for b in range(opt.n_block[i - 1]):
+                t = cv(d, W.conv[P + "body%d.%d.body.0" % (i, b)], **RELU)
+                d = cv(t, W.conv[P + "body%d.%d.body.2" % (i, b)], residual=d)
+        d = cv(d, W.conv[P + "tail%d.0" % i], **LRELU)
+        return cv(d, W.conv[P + "tail%d.2" % i], out=dst, **LRELU)
+
+    d1_f = stage(1, h, new3.slice(0, 64))
+    d2_f = stage(2, d1_f, new2.slice(0, 128))
+    d3_f = stage(3, d2_f, new1.slice(0, 256))
+    cv(d3_f, W.conv[P + "bottleneck.0"], out=new1.slice(256, 256), **LRELU)
+    # conv -> LeakyReLU -> PixelShuffle -> LeakyReLU (the second LeakyReLU is fused into the shuffle)
+    native.pixel_shuffle2(cv(new1, W.conv[P + "bott2.0"], **LRELU), 0.2, out=new2.slice(128, 128))
+    native.pixel_shuffle2(cv(new2, W.conv[P + "ups2.0"], **LRELU), 0.2, out=new3.slice(64, 64))
+    native.pixel_shuffle2(cv(new3, W.conv[P + "ups3.0"], **LRELU), 0.2, out=fin.slice(32, 32))
+    new_fin = cv(fin, W.conv[P + "ups4.0"], **LRELU)
+    img_sr = cv(cv(new_fin, W.conv[P + "last.0"], **LRELU), W.conv[P + "last.2"])
+    return img_sr, new2, new_fin
+
+
+def conv_block(W, prefix, x):
+    """ConvBlock with in_planes == out_planes: cat(o1, o2, o3) + x, GroupNorm+ReLU fused into each conv's staging."""
+    c = x.c
+    out = Img(x.h, x.w, c, device=x.buf.device)
+    o1, o2, o3 = out.slice(0, c // 2), out.slice(c // 2, c // 4), out.slice(3 * c // 4, c // 4)
+    sc, sh = native.groupnorm_coeffs(x, *W.gn[prefix + "bn1"])
+    native.conv2d(x, W.conv[prefix + "conv1"], out=o1, in_scale=sc, in_shift=sh)
+    sc, sh = native.groupnorm_coeffs(o1, *W.gn[prefix + "bn2"])
+    native.conv2d(o1, W.conv[prefix + "conv2"], out=o2, in_scale=sc, in_shift=sh)
+    sc, sh = native.groupnorm_coeffs(o2, *W.gn[prefix + "bn3"])
+    native.conv2d(o2, W.conv[prefix + "conv3"], out=o3, in_scale=sc, in_shift=sh)
+    return native.add3(out, x, out=out)
+
+
+def hourglass(W, prefix, depth, x):
+    def fwd(level, inp):
+        up1 = conv_block(W, prefix + "b1_%d." % level, inp)
+        low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp))
+        low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1)
+        low3 = conv_block(W, prefix + "b3_%d." % level, low2)
+        return native.bicubic_up2(low3, True, addend=up1)   # up1 + up2
+    return fwd(depth, x)
+
+
+def filter_lr(W, feature_lr, keep_all=False):
+    """Returns the list of stack outputs (only the last one unless keep_all, as SuRSNet.filter_lr does in eval)."""
+    opt, P = W.opt, "image_filter_lr."
+    if feature_lr.h % (1 << opt.hg_depth) or feature_lr.w % (1 << opt.hg_depth):
+        raise ValueError("feature_lr size must be a multiple of 2^hg_depth")
+    previous = conv_block(W, P + "conv2.", feature_lr)
+    outs = []
+    for i in range(opt.num_stack_lr):
+        hg = hourglass(W, P + "m%d." % i, opt.hg_depth, previous)
+        ll = conv_block(W, P + "top_m_%d." % i, hg)
+        t = native.conv2d(ll, W.conv[P + "conv_last%d" % i])
+        sc, sh = native.groupnorm_coeffs(t, *W.gn[P + "bn_end%d" % i])
+        # ll = relu(bn_end(conv_last(ll))) is consumed only by 1x1 convs: fused into their staging
+        tmp_out = native.conv2d(t, W.conv[P + "l%d" % i], in_scale=sc, in_shift=sh)
+        outs.append(tmp_out)
+        if i < opt.num_stack_lr - 1:
+            bl = native.conv2d(t, W.conv[P + "bl%d" % i], in_scale=sc, in_shift=sh)
+            al = native.conv2d(tmp_out, W.conv[P + "al%d" % i])
+            previous = native.add3(previous, bl, al)
+    return outs if keep_all else outs[-1:]
+
+
+def filter_hr(W, feature_hr):
+    return [native.conv2d(feature_hr, W.conv["image_filter_hr.conv5"])]

@@ -1,0 +1,76 @@
+"""reconstruction() and the OBJ writers: same signatures and return values as the reference
+(/root/reference/lib/mesh_util.py:8-89), implemented on the device:
+
+    create_grid -> eval_grid (dense sweep, surs_query_grid) -> 2x Lewiner marching cubes (surs_mc_lewiner)
+    -> index->world transform (surs_transform_points).
+
+The occupancy volumes never leave the GPU; only the meshes are copied to the host.  `use_octree=True` is the
+reference's default in gen_mesh but its coarse-to-fine interpolation (with the shared-`dirty` artefact, SURVEY.md
+A.5) is a later row of the scope table: for now both settings run the dense sweep, which evaluates the network at
+every voxel (the octree's own ground truth).
+"""
+import numpy as np
+import torch
+
+from . import native
+from .sdf import create_grid
+
+
+def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, i0=0, i1=None, precision=None):
+    """Dense occupancy volumes of grid slab [i0, i1) as float32 device tensors (vol_hr, vol_lr), and the grid matrix."""
+    _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
+    i1 = resolution if i1 is None else i1
+    calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
+    fl, fh = net.features()
+    zmul, zdiv = net._zscale()
+    prec = precision or getattr(opt, "precision", "fp32")
+    blob = net._mlp_blob()
+    if prec != "fp32" and native.DTYPES[prec] != net._core_dtype:
+        raise ValueError("network was packed for %s, reconstruction asked for %s: set opt.precision before loading" %
+                         (net.precision, prec))
+    try:
+        vh, vl = native.query_grid(i0, i1, resolution, resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec,
+                                   net._workspace())
+    except native._lib.SursError as e:
+        if e.code != -3:
+            raise
+        # general calibration / grid transform: the column kernel does not apply, evaluate in fp32
+        vh, vl = native.query_grid(i0, i1, resolution, resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, "fp32",
+                                   net._workspace())
+    return vh, vl, mat
+
+
+def mesh_from_volume(net, vol, mat, level=0.5):
+    """marching_cubes_lewiner(vol, level) + index->world transform; numpy outputs like the reference."""
+    v, f, n, val = native.marching_cubes_lewiner(vol, level, net._workspace())
+    vw = native.transform_points(v, mat[:3].reshape(-1))
+    return vw.cpu().numpy(), f.cpu().numpy(), n.cpu().numpy(), val.cpu().numpy()
+
+
+def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
+                   transform=None):
+    """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy)."""
+    vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+    return mesh_from_volume(net, vh, mat) + mesh_from_volume(net, vl, mat)
+
+
+def _obj_text(verts, faces):
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64) + 1
+    vs = "".join("v %.4f %.4f %.4f\n" % (a, b, c) for a, b, c in v)
+    fs = "".join("f %d %d %d\n" % (a, c, b) for a, b, c in f)   # winding swapped: f0 f2 f1, 1-based
+    return vs + fs
+
+
+def save_obj_mesh(mesh_path, verts, faces):
+    """Same bytes as the reference writer (lib/mesh_util.py:53-61)."""
+    with open(mesh_path, "w") as fh:
+        fh.write(_obj_text(verts, faces))
+
+
+def save_obj_mesh_with_color(mesh_path, verts, faces, colors):
+    with open(mesh_path, "w") as fh:
+        for v, c in zip(verts, colors):
+            fh.write("v %.4f %.4f %.4f %.4f %.4f %.4f\n" % (v[0], v[1], v[2], c[0], c[1], c[2]))
+        for f in np.asarray(faces, np.int64) + 1:
+            fh.write("f %d %d %d\n" % (f[0], f[2], f[1]))

@@ -1,0 +1,203 @@
+"""SuRSNet: the drop-in boundary.
+
+Same public surface as the reference's `SuRSNet(BaseSuRSNet)` as consumed by eval_SuRS.py / gen_mesh /
+reconstruction (/root/reference/lib/model/SuRSNet.py:44-187, lib/model/BaseSuRSNet.py:20-26,80-85;
+SURVEY.md section 8b): name, num_views, to(), eval(), train(), state_dict(), load_state_dict(), parameters(),
+super_res(), filter_hr(), filter_lr(), query_mr(), query_sr(), get_preds().
+
+It is NOT a torch.nn.Module: parameters are a flat ordered dict keyed exactly like the reference's state dict
+(all 553 keys, strict), and every forward method sequences hand-written HIP kernels through the C ABI.  There is
+no training path (backward is out of scope) and no CPU path: methods raise without a GPU / built library.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import encoder, native, weights
+
+
+def _as_nchw_view(img):
+    """zero-copy NCHW-shaped (channels_last strided) torch view of an NHWC Img with ld == c."""
+    assert img.ld == img.c and img.off == 0
+    return img.buf.view(1, img.h, img.w, img.c).permute(0, 3, 1, 2)
+
+
+def _as_img(t):
+    """torch [1,C,H,W] (any layout) or [C,H,W] -> NHWC Img; zero-copy when it already is channels_last."""
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    assert t.dim() == 4 and t.shape[0] == 1 and t.dtype == torch.float32
+    _, c, h, w = t.shape
+    p = t.permute(0, 2, 3, 1)
+    if p.is_contiguous() and t.is_cuda:
+        return native.Img(h, w, c, c, p.reshape(-1))
+    dev = native.require_gpu()
+    return native.Img.from_nchw(t.to(dev).contiguous())
+
+
+class SuRSNet:
+    def __init__(self, opt, projection_mode="orthogonal", error_term=None):
+        if projection_mode != "orthogonal":
+            raise NotImplementedError("only the orthogonal projection is on the reference's eval path "
+                                      "(EvalDataset_LR_v2.py:136)")
+        self.name = "base"
+        self.opt = opt
+        self.num_views = opt.num_views
+        self.training = True
+        self.device = torch.device("cpu")
+        self.precision = getattr(opt, "precision", "fp32")
+        self._spec = weights.state_dict_spec(opt)
+        # reference init: normal(0, 0.02) conv weights, zero bias, GroupNorm 1/0 (lib/net_util.py:99-132); here the
+        # constructor leaves deterministic synthetic weights in place until load_state_dict() replaces them
+        self._sd = OrderedDict((k, torch.from_numpy(v)) for k, v in weights.synthetic_state_dict(opt, seed=0).items())
+        self._enc = None
+        self._blob = None
+        self._ws = None
+        self.im_feat_list_lr = []
+        self.im_feat_list_hr = []
+        self.im_SR = self.feature_lr = self.feature_hr = None
+        self.preds_lr = self.preds_hr = None
+        self.intermediate_preds_list_lr = []
+        self.intermediate_preds_list_hr = []
+        self._mr_points = None
+
+    # ------------------------------------------------------------------ nn.Module-like plumbing
+    def to(self, device=None, **kw):
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cuda" and device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            self.device = device
+            self._enc = self._blob = None
+        return self
+
+    def cuda(self, index=None):
+        return self.to(torch.device("cuda", index if index is not None else torch.cuda.current_device()))
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    def load_state_dict(self, sd, strict=True):
+        want = {k: tuple(s) for k, s, _ in self._spec}
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict for SuRSNet: missing %s, unexpected %s" %
+                               (missing[:5], unexpected[:5]))
+        new = OrderedDict()
+        for k, shape in want.items():
+            if k in sd:
+                v = sd[k]
+                v = v.detach().to("cpu", torch.float32) if torch.is_tensor(v) else torch.from_numpy(np.asarray(v, np.float32))
+                if tuple(v.shape) != shape:
+                    raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(v.shape), shape))
+                new[k] = v.contiguous()
+            else:
+                new[k] = self._sd[k]
+        self._sd = new
+        self._enc = self._blob = None
+        return self
+
+    # ------------------------------------------------------------------ lazily packed device state
+    def _device(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("SuRSNet has no CPU path: call .to(device=torch.device('cuda:N')) first")
+        return self.device
+
+    def _encoder_weights(self):
+        if self._enc is None:
+            self._enc = encoder.EncoderWeights(self._sd, self.opt, self._device())
+        return self._enc
+
+    def _mlp_blob(self):
+        if self._blob is None:
+            self._blob, self._core_dtype = native.pack_mlp({k: v.numpy() for k, v in self._sd.items() if k.startswith("mlp_")},
+                                                           self.precision, self._device())
+        return self._blob
+
+    def _workspace(self):
+        if self._ws is None:
+            self._ws = native.Workspace(self._device())
+        return self._ws
+
+    # ------------------------------------------------------------------ encoder
+    def super_res(self, images):
+        """images [V,3,H,W] -> (img_SR [V,3,2H,2W], feature_lr [V,256,H/2,W/2], feature_hr [V,64,2H,2W])."""
+        W = self._encoder_weights()
+        outs = [encoder.super_res(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
+        cat = lambda i: torch.cat([_as_nchw_view(o[i]) for o in outs], 0) if len(outs) > 1 else _as_nchw_view(outs[0][i])
+        self.im_SR, self.feature_lr, self.feature_hr = cat(0), cat(1), cat(2)
+        return self.im_SR, self.feature_lr, self.feature_hr
+
+    def filter_lr(self, images):
+        W = self._encoder_weights()
+        per_view = [encoder.filter_lr(W, _as_img(images[v:v + 1]), keep_all=self.training) for v in range(images.shape[0])]
+        n_out = len(per_view[0])
+        self._feat_lr_imgs = [[pv[i] for pv in per_view] for i in range(n_out)]
+        self.im_feat_list_lr = [torch.cat([_as_nchw_view(pv[i]) for pv in per_view], 0) if len(per_view) > 1
+                                else _as_nchw_view(per_view[0][i]) for i in range(n_out)]
+
+    def filter_hr(self, images):
+        W = self._encoder_weights()
+        per_view = [encoder.filter_hr(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
+        self._feat_hr_imgs = [[pv[0] for pv in per_view]]
+        self.im_feat_list_hr = [torch.cat([_as_nchw_view(pv[0]) for pv in per_view], 0) if len(per_view) > 1
+                                else _as_nchw_view(per_view[0][0])]
+
+    def features(self):
+        """(Img feat_lr, Img feat_hr) of view 0, last stack: what the query kernels read."""
+        if not self.im_feat_list_lr or not self.im_feat_list_hr:
+            raise RuntimeError("filter_lr / filter_hr must run before a query")
+        return _as_img(self.im_feat_list_lr[-1][0:1]), _as_img(self.im_feat_list_hr[0][0:1])
+
+    # ------------------------------------------------------------------ query
+    def _zscale(self):
+        return float(self.opt.loadSize // 2), float(self.opt.z_size)
+
+    def _query(self, points, calibs, transforms):
+        if transforms is not None:
+            raise NotImplementedError("image-space `transforms` are never passed on the eval path (lib/geometry.py:27-30)")
+        if points.shape[0] != 1 or self.num_views != 1:
+            raise NotImplementedError("multi-view queries (num_views > 1) are not built yet (SURVEY.md 8f-4)")
+        dev = self._device()
+        pts = points[0].to(dev, torch.float32).contiguous()
+        calib = calibs[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
+        fl, fh = self.features()
+        zmul, zdiv = self._zscale()
+        phr, plr = native.query_points(pts, calib, zmul, zdiv, fl, fh, self._mlp_blob(), self._workspace())
+        return phr.view(1, 1, -1), plr.view(1, 1, -1)
+
+    def query_mr(self, points, calibs, transforms=None, labels=None):
+        """Evaluates both classifiers in one fused pass; preds_hr is kept for the following query_sr."""
+        phr, plr = self._query(points, calibs, transforms)
+        self._mr_points, self._mr_hr = points, phr
+        self.intermediate_preds_list_lr = [plr]
+        self.preds_lr = plr
+
+    def query_sr(self, points, calibs, transforms=None, labels=None):
+        if self._mr_points is None:
+            raise RuntimeError("query_sr needs the preceding query_mr (it consumes its lr predictions, SuRSNet.py:179)")
+        same = points is self._mr_points or (points.shape == self._mr_points.shape and bool(torch.equal(points, self._mr_points)))
+        if not same:
+            raise NotImplementedError("query_sr on points other than the preceding query_mr's is not supported: the "
+                                      "fused kernel feeds each point its own lr prediction")
+        self.intermediate_preds_list_hr = [self._mr_hr]
+        self.preds_hr = self._mr_hr
+
+    def get_preds(self):
+        return self.preds_hr, self.preds_lr
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward/backward is out of scope of the inference hot path")

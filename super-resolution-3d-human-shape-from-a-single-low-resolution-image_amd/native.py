@@ -251,3 +251,11 @@ def marching_cubes_lewiner(vol, level, ws, want_normals=True):
     check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), _ptr(verts), _ptr(normals),
                                 _ptr(values), nv, _ptr(faces), nf, C.byref(counts), _stream()))
     return verts, faces, normals, values
+
+
+def transform_points(verts, mat):
+    """float64 [V,3] device tensor = mat[:3,:3] @ v + mat[:3,3] (the reference's np.matmul step, on the device)."""
+    out = torch.empty((verts.shape[0], 3), dtype=torch.float64, device=verts.device)
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+    check(lib().surs_transform_points(_ptr(verts), verts.shape[0], m, _ptr(out), _stream()))
+    return out

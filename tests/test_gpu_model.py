@@ -1,0 +1,123 @@
+"""GPU parity of the drop-in boundary (SuRSNet / reconstruction / gen_mesh) against goldens captured from the
+reference: encoder features (relative 1e-4 of the tensor's range, every tap), query through the facade (1e-4),
+dense reconstruction fields (1e-4), meshes from the reference's own field (bit-exact), OBJ bytes."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common
+from surs_amd import weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def net():
+    from surs_amd import model
+    dev = torch.device("cuda:0")
+    n = model.SuRSNet(common.opt()).to(device=dev)
+    n.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    n.eval()
+    return n
+
+
+@pytest.mark.parametrize("H", [64, 96])
+def test_encoder_vs_reference(net, H, golden_dir):
+    g = np.load(os.path.join(golden_dir, "encoder_h%d.npz" % H))
+    img = torch.from_numpy(weights.synthetic_image(H, seed=1)).to("cuda:0")
+    img_sr, f_lr, f_hr = net.super_res(img)
+    assert tuple(img_sr.shape) == (1, 3, 2 * H, 2 * H) and tuple(f_lr.shape) == (1, 256, H // 2, H // 2)
+    assert tuple(f_hr.shape) == (1, 64, 2 * H, 2 * H)
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    assert len(net.im_feat_list_lr) == 1 and len(net.im_feat_list_hr) == 1   # eval keeps the last stack only
+    im_lr, im_hr = net.im_feat_list_lr[0][0].cpu().numpy(), net.im_feat_list_hr[0][0].cpu().numpy()
+    img_sr, f_lr, f_hr = img_sr[0].cpu().numpy(), f_lr[0].cpu().numpy(), f_hr[0].cpu().numpy()
+    s2, s4 = (lambda a: a[..., ::2, ::2]), (lambda a: a[..., ::4, ::4])
+    tol = 1e-4
+    assert common.rel_err(s2(img_sr), g["img_sr_sub"]) < tol
+    assert common.rel_err(f_lr if H == 64 else s2(f_lr), g["feature_lr"]) < tol
+    assert common.rel_err(s4(f_hr), g["feature_hr_sub"]) < tol
+    assert common.rel_err(f_hr.mean((1, 2)), g["feature_hr_mean"]) < tol
+    assert common.rel_err(im_lr if H == 64 else s2(im_lr), g["im_feat_lr"]) < tol
+    assert common.rel_err(s4(im_hr), g["im_feat_hr_sub"]) < tol
+
+
+def test_encoder_taps_vs_oracle(net):
+    """Bisecting aid: every stack's hourglass / output against the oracle at H=64."""
+    import oracle
+    from surs_amd import encoder, native
+    sd = common.state_dict()
+    img = weights.synthetic_image(64, seed=1)
+    _, o_lr, _ = oracle.super_res(sd, img[0])
+    taps = {}
+    oracle.filter_lr(sd, o_lr, taps=taps)
+    _, f_lr, _ = net.super_res(torch.from_numpy(img).to("cuda:0"))
+    was = net.training
+    net.train(True)
+    net.filter_lr(f_lr)   # training mode keeps all stack outputs
+    net.train(was)
+    assert len(net.im_feat_list_lr) == 3
+    for i in range(3):
+        assert common.rel_err(net.im_feat_list_lr[i][0].cpu().numpy(), taps["out%d" % i]) < 1e-4
+    net.eval()
+    net.filter_lr(f_lr)
+
+
+def test_query_facade_vs_reference(net, golden_dir):
+    g = np.load(os.path.join(golden_dir, "query.npz"))
+    fl, fh = common.synth_features()
+    net.im_feat_list_lr = [torch.from_numpy(fl[None]).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None]).to("cuda:0")]
+    pts = torch.from_numpy(weights.synthetic_points(50000, seed=2)[None]).to("cuda:0")
+    calib = torch.from_numpy(common.CALIB[None]).to("cuda:0")
+    net.query_mr(pts, calib)
+    net.query_sr(pts, calib)
+    phr, plr = net.get_preds()
+    assert tuple(phr.shape) == (1, 1, 50000)
+    assert np.abs(phr.detach().cpu().numpy()[0, 0] - g["a_pred_hr"]).max() < 1e-4
+    assert np.abs(plr.detach().cpu().numpy()[0, 0] - g["a_pred_lr"]).max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        net.query_sr(pts + 1.0, calib)
+
+
+@pytest.mark.parametrize("R", [32, 48])
+def test_reconstruction_vs_reference(net, R, golden_dir):
+    from surs_amd import mesh_util
+    g = np.load(os.path.join(golden_dir, "recon_r%d.npz" % R))
+    img = torch.from_numpy(weights.synthetic_image(64, seed=1)).to("cuda:0")
+    _, f_lr, f_hr = net.super_res(img)
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    calib = torch.from_numpy(common.CALIB[None]).to("cuda:0")
+    b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
+    vh, vl, mat = mesh_util.eval_volumes(common.opt(), net, calib, R, b_min, b_max)
+    assert np.abs(vh.cpu().numpy() - g["sdf_hr"]).max() < 1e-4
+    assert np.abs(vl.cpu().numpy() - g["sdf_lr"]).max() < 1e-4
+    # mesh stage on the reference's own field: indices bit-exact, world vertices (float64) exact
+    for tag in ("hr", "lr"):
+        v, f, n, val = mesh_util.mesh_from_volume(net, torch.from_numpy(g["sdf_" + tag]).to("cuda:0"), mat)
+        assert f.dtype == np.int32 and v.dtype == np.float64
+        assert np.array_equal(f, g["faces_" + tag])
+        assert np.array_equal(v, g["verts_" + tag])
+    out = mesh_util.reconstruction(common.opt(), net, torch.device("cuda:0"), calib, R, b_min, b_max, use_octree=False)
+    assert len(out) == 8
+    assert abs(len(out[0]) - len(g["verts_hr"])) <= max(8, len(g["verts_hr"]) // 100)
+    # OBJ writer: same bytes as the reference's writer for the reference's mesh
+    txt = mesh_util._obj_text(g["verts_hr"], g["faces_hr"])
+    assert hashlib.sha256(txt.encode()).hexdigest() == str(g["obj_hr_sha256"])
+
+
+def test_gen_mesh_writes_both_objs(net, tmp_path):
+    from surs_amd import train_util
+    opt = common.opt()
+    opt.resolution = 24
+    data = {"img_LR": torch.from_numpy(weights.synthetic_image(64, seed=1)), "b_min": np.array([-0.5] * 3),
+            "b_max": np.array([0.5] * 3), "name": ("subject", ".png")}
+    train_util.gen_mesh(opt, net, torch.device("cuda:0"), data, str(tmp_path / "subject.obj"))
+    for tag in ("HR", "LR"):
+        lines = open(tmp_path / ("subject_%s.obj" % tag)).read().splitlines()
+        assert lines[0].startswith("v ") and lines[-1].startswith("f ")

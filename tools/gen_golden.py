@@ -168,8 +168,14 @@ def gen_recon():
             ns.mesh_util.eval_grid = orig
         print("recon R=%d %.1fs verts %s faces %s | lr %s %s; sdf_hr range %.3f..%.3f" %
               (R, time.time() - t, vh.shape, fh.shape, vl.shape, fl_.shape, cap["hr"].min(), cap["hr"].max()))
+        # the reference's own OBJ writer (lib/mesh_util.py:53-61) on the HR mesh: digest of the file bytes
+        import hashlib, tempfile
+        with tempfile.TemporaryDirectory() as d:
+            ns.mesh_util.save_obj_mesh(os.path.join(d, "m.obj"), vh, fh)
+            obj_sha = hashlib.sha256(open(os.path.join(d, "m.obj"), "rb").read()).hexdigest()
         np.savez_compressed(os.path.join(GOLD, "recon_r%d.npz" % R), sdf_hr=cap["hr"].astype(np.float32),
-                            sdf_lr=cap["lr"].astype(np.float32), verts_hr=vh, faces_hr=fh, verts_lr=vl, faces_lr=fl_)
+                            sdf_lr=cap["lr"].astype(np.float32), verts_hr=vh, faces_hr=fh, verts_lr=vl, faces_lr=fl_,
+                            obj_hr_sha256=np.array(obj_sha))
 
 
 if __name__ == "__main__":
