@@ -127,6 +127,12 @@ int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const flo
                     int dtype, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr, void *stream);
 size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype);
 
+/* Measurement aid (not on the reference's path): when enabled, every launch of the dominant kernel of
+ * surs_query_grid's reduced-precision mode is bracketed by HIP events on its launch stream.  surs_profile_read
+ * returns the number of timed launches, the sum of their durations (ms) and the voxels they evaluated, and resets. */
+int surs_profile_enable(int on);
+int surs_profile_read(double *launches, double *total_ms, double *points);
+
 /* ------------------------------------------------------------------ Lewiner marching cubes */
 
 typedef struct {

@@ -52,6 +52,8 @@ _SIGS = {
     "surs_query_points": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "surs_query_grid": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "surs_query_grid_workspace_bytes": (_sz, [_i, _i, _i]),
+    "surs_profile_enable": (C.c_int, [_i]),
+    "surs_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "surs_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "surs_transform_points": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
     "surs_mc_lewiner": (C.c_int, [_vp, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(McCounts), _vp]),

@@ -19,6 +19,9 @@
 //         streamed L2 -> LDS by LDS-DMA in 32 KiB slabs shared by the 4 waves of the workgroup.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+#include <vector>
+
 #include "surs_common.h"
 #include "surs_mlp_layout.h"
 
@@ -626,6 +629,45 @@ extern "C" int surs_query_points(const float *points, int n, const float *calib,
                            logit_hr, logit_lr);
 }
 
+// ------------------------------------------------------------------------------------------------
+// optional per-launch timing of the dominant kernel (grid_mlp_kernel) with HIP events on the launch stream:
+// what bench.py's roofline figure is computed from
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GridProf {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<double> pts;
+} g_prof;
+}  // namespace
+
+extern "C" int surs_profile_enable(int on) {
+    for (auto &e : g_prof.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    g_prof.ev.clear();
+    g_prof.pts.clear();
+    g_prof.on = on != 0;
+    return 0;
+}
+
+// launches: number of timed grid_mlp_kernel launches since enable; total_ms: sum of their durations;
+// points: voxels they evaluated.  Synchronises on the recorded events and resets the counters.
+extern "C" int surs_profile_read(double *launches, double *total_ms, double *points) {
+    double ms = 0, p = 0;
+    for (size_t i = 0; i < g_prof.ev.size(); ++i) {
+        SURS_HIP_CHECK(hipEventSynchronize(g_prof.ev[i].second));
+        float t = 0;
+        SURS_HIP_CHECK(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
+        ms += t;
+        p += g_prof.pts[i];
+    }
+    if (launches) *launches = (double)g_prof.ev.size();
+    if (total_ms) *total_ms = ms;
+    if (points) *points = p;
+    const bool on = g_prof.on;
+    surs_profile_enable(on);
+    return 0;
+}
+
 // grid batches: fp32 mode evaluates GRID_BATCH voxels per pass; column mode COL_BATCH columns per pass
 static const long long GRID_BATCH = 65536;
 static const long long COL_BATCH = 16384;
@@ -728,11 +770,22 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.zmul = zmul;
         a.zdiv = zdiv;
         const unsigned grid = (unsigned)((nc < cus) ? nc : cus);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_prof.on) {
+            SURS_HIP_CHECK(hipEventCreate(&e0));
+            SURS_HIP_CHECK(hipEventCreate(&e1));
+            SURS_HIP_CHECK(hipEventRecord(e0, st));
+        }
         if (dtype == SURS_BF16)
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_BF16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         else
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         SURS_LAUNCH_CHECK();
+        if (g_prof.on) {
+            SURS_HIP_CHECK(hipEventRecord(e1, st));
+            g_prof.ev.emplace_back(e0, e1);
+            g_prof.pts.push_back((double)nc * rz);
+        }
     }
     return 0;
 }
