@@ -19,6 +19,8 @@
 //         streamed L2 -> LDS by LDS-DMA in 32 KiB slabs shared by the 4 waves of the workgroup.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -581,6 +583,8 @@ __global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
     __syncthreads();  // drain the last prefetch before the workgroup retires
 }
 
+#include "surs_grid_v2.inc"
+
 }  // namespace surs
 
 using namespace surs;
@@ -733,8 +737,18 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
+    // SURS_GRID_KERNEL=1 selects the simple (non-pipelined) kernel: kept as the bitwise regression reference
+    static int kver = -1;
+    if (kver < 0) {
+        const char *e = getenv("SURS_GRID_KERNEL");
+        kver = (e && e[0] == '1') ? 1 : 2;
+    }
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[dtype]) {
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_BF16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_F16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
         if (dtype == SURS_BF16)
             SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
@@ -776,7 +790,12 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             SURS_HIP_CHECK(hipEventCreate(&e1));
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
-        if (dtype == SURS_BF16)
+        if (kver == 2) {
+            if (dtype == SURS_BF16)
+                hipLaunchKernelGGL(grid_mlp_kernel_v2<SURS_BF16>, dim3(grid), dim3(256), GRID2_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(grid_mlp_kernel_v2<SURS_F16>, dim3(grid), dim3(256), GRID2_LDS_BYTES, st, a);
+        } else if (dtype == SURS_BF16)
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_BF16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         else
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);

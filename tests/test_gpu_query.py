@@ -90,3 +90,20 @@ def test_grid_column_kernel_vs_fp32(setup, dtype, tol):
     # slab consistency: evaluating [i0,i1) separately gives identical bits (multi-GPU sharding property)
     a, _ = _grid(setup, R, dtype, 8, 24)
     assert np.array_equal(a, vh[8:24])
+
+
+def test_pipelined_kernel_bitwise_equals_simple_kernel():
+    """The software-pipelined column kernel (3-slab ring, counted vmcnt) must produce the same bits as the simple
+    one-barrier-per-slab kernel, and the same bits on every launch (race screen), for ragged and multi-tile grids."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    outs = {}
+    for ver in ("1", "2"):
+        env = dict(os.environ, SURS_GRID_KERNEL=ver)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "grid_hash.py")], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[ver] = [l for l in r.stdout.splitlines() if l.startswith(("bf16", "fp16"))]
+        assert len(outs[ver]) == 4 and all("stable" in l and "UNSTABLE" not in l for l in outs[ver]), outs[ver]
+    assert outs["1"] == outs["2"], (outs["1"], outs["2"])

@@ -1,0 +1,27 @@
+"""Runs the reduced-precision grid sweep a few times (profiling target for rocprofv3 --pmc)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+import gpu_common as g  # noqa: E402
+import oracle  # noqa: E402
+from surs_amd import native  # noqa: E402
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+fl, fh = common.synth_features(hl=256, hh=1024)
+Fl, Fh = g.upload_nhwc(fl), g.upload_nhwc(fh)
+ws = native.Workspace(g.dev())
+mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+b = g.blob("f16" if dt == "fp16" else "bf16")
+vh = torch.empty((R, R, R), dtype=torch.float32, device=g.dev())
+vl = torch.empty_like(vh)
+for _ in range(3):
+    native.query_grid(0, R, R, R, mat, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, b, dt, ws, vh, vl)
+torch.cuda.synchronize()
+print("done")
