@@ -85,8 +85,9 @@ def main():
         full_lr = sdist.gather_slabs(vl, R, 0)
         ev[3].record()
         if rank == 0:
-            mh = mesh_util.mesh_from_volume(net, full_hr, mat)
-            ml = mesh_util.mesh_from_volume(net, full_lr, mat)
+            # gen_mesh keeps vertices and faces only (lib/train_util.py:72)
+            mh = mesh_util.mesh_from_volume(net, full_hr, mat, want_normals=False)
+            ml = mesh_util.mesh_from_volume(net, full_lr, mat, want_normals=False)
             last["verts_hr"], last["faces_hr"], last["verts_lr"], last["faces_lr"] = len(mh[0]), len(mh[1]), len(ml[0]), len(ml[1])
         ev[4].record()
         if timed:
@@ -144,7 +145,7 @@ def main():
                        "reconstruction_s": ms_per_step / 1e3,
                        "stage_ms_rank0": {k: v / args.steps for k, v in stage_ms.items()},
                        "mesh": dict(last), "parallelism": "slab%d" % world},
-            "roofline": {"kernel": "grid_mlp_kernel<%s>" % args.precision, "bound": "mfma", "achieved": achieved, "peak": peak,
+            "roofline": {"kernel": "grid_mlp_kernel_v2<%s>" % args.precision, "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts_per_launch,
                          "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": 2752512},

@@ -40,18 +40,20 @@ def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=Non
     return vh, vl, mat
 
 
-def mesh_from_volume(net, vol, mat, level=0.5):
-    """marching_cubes_lewiner(vol, level) + index->world transform; numpy outputs like the reference."""
-    v, f, n, val = native.marching_cubes_lewiner(vol, level, net._workspace())
+def mesh_from_volume(net, vol, mat, level=0.5, want_normals=True):
+    """marching_cubes_lewiner(vol, level) + index->world transform; numpy outputs like the reference.
+    want_normals=False skips normals/values (gen_mesh discards them: lib/train_util.py:72) and returns None for them."""
+    ws = net._workspace()
+    v, f, n, val = native.marching_cubes_lewiner(vol, level, ws, want_normals=want_normals)
     vw = native.transform_points(v, mat[:3].reshape(-1))
-    return vw.cpu().numpy(), f.cpu().numpy(), n.cpu().numpy(), val.cpu().numpy()
+    return tuple(ws.to_host([vw, f, n, val]))
 
 
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
-                   transform=None):
+                   transform=None, want_normals=True):
     """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy)."""
     vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
-    return mesh_from_volume(net, vh, mat) + mesh_from_volume(net, vl, mat)
+    return mesh_from_volume(net, vh, mat, want_normals=want_normals) + mesh_from_volume(net, vl, mat, want_normals=want_normals)
 
 
 def _obj_text(verts, faces):

@@ -180,17 +180,33 @@ def pack_mlp(sd, dtype, device):
 
 
 class Workspace:
-    """Grow-only device scratch buffer."""
+    """Grow-only device scratch buffer; remembers mesh capacities between extractions."""
 
     def __init__(self, device):
         self.device = device
         self.buf = None
+        self.mc_capacity = None   # (verts, faces) of the last extraction: sizes the next one without a counting pass
 
     def get(self, nbytes):
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = None
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self.buf
+
+    def to_host(self, tensors):
+        """device tensors -> numpy arrays backed by pinned host memory (one sync for the whole batch).  Each array owns
+        its pinned block (torch's caching host allocator recycles it once the array is garbage collected), so the
+        results stay valid like the reference's freshly allocated arrays, without a second host copy."""
+        outs = []
+        for t in tensors:
+            if t is None:
+                outs.append(None)
+                continue
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            outs.append(h)
+        torch.cuda.current_stream().synchronize()
+        return [o.numpy() if o is not None else None for o in outs]
 
 
 def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_logits=False):
@@ -240,17 +256,32 @@ def marching_cubes_lewiner(vol, level, ws, want_normals=True):
     n0, n1, n2 = vol.shape
     w = ws.get(lib().surs_mc_workspace_bytes(n0, n1, n2))
     counts = _lib.McCounts()
-    check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), None, None, None, 0, None, 0,
-                                C.byref(counts), _stream()))
-    nv, nf = counts.n_verts, counts.n_faces
     dev = vol.device
-    verts = torch.empty((nv, 3), dtype=torch.float32, device=dev)
-    faces = torch.empty((nf, 3), dtype=torch.int32, device=dev)
-    normals = torch.empty((nv, 3), dtype=torch.float32, device=dev) if want_normals else None
-    values = torch.empty((nv,), dtype=torch.float32, device=dev) if want_normals else None
-    check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), _ptr(verts), _ptr(normals),
-                                _ptr(values), nv, _ptr(faces), nf, C.byref(counts), _stream()))
-    return verts, faces, normals, values
+
+    def run(cap_v, cap_f):
+        verts = torch.empty((cap_v, 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((cap_f, 3), dtype=torch.int32, device=dev)
+        normals = torch.empty((cap_v, 3), dtype=torch.float32, device=dev) if want_normals else None
+        values = torch.empty((cap_v,), dtype=torch.float32, device=dev) if want_normals else None
+        rc = lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), _ptr(verts), _ptr(normals),
+                                   _ptr(values), cap_v, _ptr(faces), cap_f, C.byref(counts), _stream())
+        return rc, verts, faces, normals, values
+
+    if ws.mc_capacity is None:
+        # first extraction with this workspace: counting pass (no outputs) to size the buffers
+        check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), None, None, None, 0, None, 0,
+                                    C.byref(counts), _stream()))
+        cap = (counts.n_verts, counts.n_faces)
+    else:
+        cap = ws.mc_capacity
+    rc, verts, faces, normals, values = run(*cap)
+    if rc == -6:   # SURS_E_CAPACITY: the counts are filled in, retry with exact sizes
+        rc, verts, faces, normals, values = run(counts.n_verts, counts.n_faces)
+    check(rc)
+    nv, nf = counts.n_verts, counts.n_faces
+    ws.mc_capacity = (int(nv * 1.125) + 1024, int(nf * 1.125) + 2048)
+    return (verts[:nv], faces[:nf], normals[:nv] if normals is not None else None,
+            values[:nv] if values is not None else None)
 
 
 def transform_points(verts, mat):

@@ -21,7 +21,7 @@ def gen_mesh(opt, net, cuda, data, save_path, use_octree=True):
     calib_tensor = gen_calib().to(device=cuda)   # the dataset's own calib is ignored, as in the reference
     verts_hr, faces_hr, _, _, verts_lr, faces_lr, _, _ = reconstruction(
         opt, net, cuda, calib_tensor, opt.resolution, data["b_min"], data["b_max"], use_octree=use_octree,
-        num_samples=opt.num_samples)
+        num_samples=opt.num_samples, want_normals=False)   # normals / values are discarded here, as in the reference
     save_obj_mesh(save_path[:-4] + "_HR.obj", verts_hr, faces_hr)
     save_obj_mesh(save_path[:-4] + "_LR.obj", verts_lr, faces_lr)
     return verts_hr, faces_hr, verts_lr, faces_lr
