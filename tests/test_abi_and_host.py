@@ -1,0 +1,116 @@
+"""CPU-only checks: the C ABI library loads and exports every symbol include/surs.h declares (no compute calls),
+the host-side mirror of the reference interface (flags, state dict, grid matrix, OBJ writer) behaves like the
+reference, and nothing in the product package imports the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import common
+from surs_amd import mesh_util, model, options, sdf, weights
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "surs.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(surs_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from surs_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == names           # the ctypes binding covers the whole header
+    assert _lib.lib().surs_abi_version() == 1
+
+
+def test_conv_weight_packing_layout():
+    import ctypes as C
+    from surs_amd import _lib
+    w = np.arange(5 * 3 * 9, dtype=np.float32).reshape(5, 3, 3, 3)
+    n = _lib.lib().surs_conv_pack_weights(None, 5, 3, 3, None)
+    assert n == 9 * 16 * 64
+    out = np.empty(n, np.float32)
+    _lib.lib().surs_conv_pack_weights(w.ctypes.data_as(C.c_void_p), 5, 3, 3, out.ctypes.data_as(C.c_void_p))
+    out = out.reshape(9, 16, 64)
+    assert out[4, 2, 3] == w[3, 2, 1, 1] and out[8, 0, 4] == w[4, 0, 2, 2]
+    assert np.all(out[:, 3:, :] == 0) and np.all(out[:, :, 5:] == 0)
+
+
+def test_options_mirror_reference_defaults():
+    opt = options.BaseOptions().parse([])
+    assert (opt.loadSize, opt.resolution, opt.num_samples, opt.z_size, opt.threshold) == (512, 512, 50000, 200.0, 0.05)
+    assert opt.mlp_dim_lr == [321, 1024, 512, 256, 128, 1] and opt.mlp_dim_hr[0] == 322
+    assert opt.mlp_res_layers_lr == [2, 3, 4] and opt.n_block == [2, 2, 2] and not opt.residual and not opt.no_residual
+    assert (opt.hg_depth, opt.hg_dim, opt.num_stack_lr, opt.num_stack_hr, opt.norm, opt.num_views) == (2, 256, 3, 1, "group", 1)
+    # README test command of the reference parses unchanged
+    o = options.BaseOptions().parse("--dataroot d --results_path r --loadSize 1024 --resolution 256 --load_netG_checkpoint_path "
+                                    "w --name n --residual --b_min -0.5 -0.5 -0.5 --b_max 0.5 0.5 0.5".split())
+    assert o.b_max == [0.5, 0.5, 0.5] and o.residual and o.loadSize == 1024
+
+
+def test_state_dict_roundtrip_is_strict():
+    net = model.SuRSNet(common.opt())
+    sd = net.state_dict()
+    assert len(sd) == 553 and net.name == "base" and net.num_views == 1
+    net.load_state_dict(sd)
+    bad = dict(sd)
+    bad.pop("mlp_hr.conv4.bias")
+    with pytest.raises(RuntimeError, match="missing"):
+        net.load_state_dict(bad)
+    bad = dict(sd)
+    bad["extra.weight"] = sd["mlp_hr.conv4.bias"]
+    with pytest.raises(RuntimeError, match="unexpected"):
+        net.load_state_dict(bad)
+    bad = dict(sd)
+    bad["mlp_lr.conv0.weight"] = sd["mlp_lr.conv0.weight"][:, :300]
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        net.load_state_dict(bad)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net.features() if False else net._device()
+    # the shared GroupNorm of a ConvBlock's downsample branch aliases bn4 in the reference's state dict
+    assert np.array_equal(sd["image_filter_lr.conv4.downsample.0.weight"].numpy(), sd["image_filter_lr.conv4.bn4.weight"].numpy())
+
+
+def test_synthetic_inputs_are_deterministic():
+    a = weights.synthetic_state_dict(common.opt(), seed=0)
+    b = common.state_dict(0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    img = weights.synthetic_image(64, seed=1)
+    assert img.shape == (1, 3, 64, 64) and img[0, 0, 0, 0] == 0 and abs(img).max() <= 1
+    assert np.array_equal(img, weights.synthetic_image(64, seed=1))
+    assert not np.array_equal(img, weights.synthetic_image(64, seed=2))
+
+
+def test_create_grid_matrix_matches_reference_formula():
+    import oracle
+    _, m = sdf.create_grid(48, 48, 48, np.array([-0.5, -0.4, -0.3]), np.array([0.5, 0.6, 0.7]))
+    assert np.array_equal(m, oracle.coords_matrix(48, [-0.5, -0.4, -0.3], [0.5, 0.6, 0.7]))
+    t = np.eye(4)
+    t[0, 3] = 2.0
+    _, m2 = sdf.create_grid(8, 8, 8, np.zeros(3), np.ones(3), transform=t)
+    assert m2[0, 3] == 2.0 and m2[0, 0] == 1 / 8
+
+
+def test_obj_writer_format(tmp_path):
+    v = np.array([[0.12345, -1.0, 2.00004], [1e-5, 3.14159, -0.00005]])
+    f = np.array([[0, 1, 1], [1, 0, 0]], np.int32)
+    p = tmp_path / "m.obj"
+    mesh_util.save_obj_mesh(str(p), v, f)
+    assert p.read_text() == "v 0.1235 -1.0000 2.0000\nv 0.0000 3.1416 -0.0001\nf 1 2 2\nf 2 1 1\n".replace("0.1235", "%.4f" % 0.12345)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "super-resolution-3d-human-shape-from-a-single-low-resolution-image_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", ".inc")):
+                txt = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, fn
