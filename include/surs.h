@@ -127,6 +127,28 @@ int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const flo
                     int dtype, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr, void *stream);
 size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype);
 
+/* Octree sweep (eval_grid_octree, lib/sdf.py:55-120), one level at a time; volumes are float64 [R][R][R] like the
+ * reference's numpy arrays, `dirty` is uint8 [R][R][R].
+ *   surs_octree_select     lattice points of stride `reso` that are still dirty -> idx[] (flat voxel indices, any
+ *                          order), count (host; synchronises)                                 sdf.py:68-71
+ *   surs_query_grid_indexed evaluate those voxels (fp32 arithmetic, as surs_query_points)       sdf.py:73
+ *   surs_octree_scatter    sdf[idx] = pred, dirty[idx] = 0                                     sdf.py:73-74
+ *   surs_octree_cells      the cell walk: blocks whose 8 corners span < threshold are set to (max+min)/2 and marked
+ *                          clean, HR and LR sharing the one dirty mask                          sdf.py:81-117
+ *   surs_f64_to_f32        the cast marching_cubes_lewiner applies to its input */
+int surs_octree_select(const unsigned char *dirty, int R, int reso, long long *idx, int cap, int *count_dev, int *count_host,
+                       void *stream);
+int surs_query_grid_indexed(const long long *idx, int n, int ry, int rz, const double *mat, const float *calib, float zmul,
+                            float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                            const void *mlp_blob, void *workspace, size_t workspace_bytes, float *pred_hr, float *pred_lr,
+                            void *stream);
+int surs_octree_scatter(const long long *idx, int n, const float *pred_hr, const float *pred_lr, double *sdf_hr, double *sdf_lr,
+                        unsigned char *dirty, void *stream);
+size_t surs_octree_workspace_bytes(int R, int reso);
+int surs_octree_cells(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, double threshold, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int surs_f64_to_f32(const double *a, float *b, long long n, void *stream);
+
 /* Measurement aid (not on the reference's path): when enabled, every launch of the dominant kernel of
  * surs_query_grid's reduced-precision mode is bracketed by HIP events on its launch stream.  surs_profile_read
  * returns the number of timed launches, the sum of their durations (ms) and the voxels they evaluated, and resets. */

@@ -299,5 +299,49 @@ def reconstruction_dense(sd, feat_lr, feat_hr, calib, res, b_min, b_max, load_si
     return out
 
 
+def eval_grid_octree(res, b_min, b_max, eval_func, threshold=0.05, init_resolution=64, trace=None):
+    """eval_grid_octree (/root/reference/lib/sdf.py:55-120), vectorised per level instead of the reference's Python
+    triple loop.  The cell walk is order independent (a cell writes only its own block; the corners it reads are the
+    min-corners of cells later in the loop order), so deciding all cells of a level from the arrays as evaluated and
+    then applying the fills gives the same arrays - tests/test_oracle_octree.py checks that against the reference's
+    loop.  eval_func(points[3,n] float64) -> (hr[n], lr[n]).  Keeps the shared-`dirty` quirk.
+    Returns float64 (sdf_hr, sdf_lr) of shape [res]*3."""
+    R = res
+    bmin, bmax = np.asarray(b_min, np.float64), np.asarray(b_max, np.float64)
+    scale = (bmax - bmin) / R
+    sdf_hr, sdf_lr = np.zeros((R, R, R)), np.zeros((R, R, R))
+    dirty = np.ones((R, R, R), dtype=bool)
+    grid_mask = np.zeros((R, R, R), dtype=bool)
+    reso = R // init_resolution
+    while reso > 0:
+        grid_mask[0:R:reso, 0:R:reso, 0:R:reso] = True
+        test = np.logical_and(grid_mask, dirty)
+        ii, jj, kk = np.nonzero(test)
+        pts = np.stack([scale[0] * ii + bmin[0], scale[1] * jj + bmin[1], scale[2] * kk + bmin[2]])
+        hr, lr = eval_func(pts)
+        sdf_hr[test], sdf_lr[test] = hr, lr
+        dirty[test] = False
+        if reso <= 1:
+            break
+        if trace is not None:
+            trace.append(("evaluated", reso, sdf_hr.copy(), sdf_lr.copy(), dirty.copy()))
+        c = np.arange(0, R - reso, reso)
+        if len(c):
+            X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+            active = dirty[X + reso // 2, Y + reso // 2, Z + reso // 2]
+            for sdf in (sdf_hr, sdf_lr):
+                corners = np.stack([sdf[X + a * reso, Y + b * reso, Z + d * reso] for a in (0, 1) for b in (0, 1) for d in (0, 1)])
+                vmin, vmax = corners.min(0), corners.max(0)
+                flat = active & ((vmax - vmin) < threshold)
+                mid = (vmax + vmin) / 2
+                for x, y, z, m in zip(X[flat], Y[flat], Z[flat], mid[flat]):
+                    sdf[x:x + reso, y:y + reso, z:z + reso] = m
+                    dirty[x:x + reso, y:y + reso, z:z + reso] = False
+        if trace is not None:
+            trace.append(("cells", reso, sdf_hr.copy(), sdf_lr.copy(), dirty.copy()))
+        reso //= 2
+    return sdf_hr, sdf_lr
+
+
 def num_threads():
     return int(lib().orc_num_threads())

@@ -38,9 +38,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 struct PointSource {
     // mode 0: explicit points [3][n] (ld = n_total);  mode 1: grid voxels, flat index base+t, z fastest;
-    // mode 2: grid columns, flat column index base+t = i*ry + j (k = 0)
+    // mode 2: grid columns, flat column index base+t = i*ry + j (k = 0);  mode 3: grid voxels listed in idx[t]
     int mode;
     const float *pts;
+    const long long *idx;
     long long ld;
     long long base;
     int ry, rz;
@@ -55,9 +56,9 @@ __device__ __forceinline__ void make_point(const PointSource &s, long long t, fl
         py = s.pts[s.ld + t];
         pz = s.pts[2 * s.ld + t];
     } else {
-        long long f = s.base + t;
+        long long f = (s.mode == 3) ? s.idx[t] : s.base + t;
         double i, j, k;
-        if (s.mode == 1) {
+        if (s.mode == 1 || s.mode == 3) {
             k = (double)(f % s.rz);
             j = (double)((f / s.rz) % s.ry);
             i = (double)(f / ((long long)s.rz * s.ry));
@@ -807,4 +808,34 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         }
     }
     return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// octree support (lib/sdf.py:55-120): evaluate the grid voxels listed in idx[] (fp32 arithmetic)
+// ------------------------------------------------------------------------------------------------
+extern "C" int surs_query_grid_indexed(const long long *idx, int n, int ry, int rz, const double *mat, const float *calib,
+                                       float zmul, float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr,
+                                       int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,
+                                       float *pred_hr, float *pred_lr, void *stream) {
+    SURS_REQUIRE(n >= 0, "negative point count");
+    if (n == 0) return 0;
+    SURS_REQUIRE(idx && mat && calib && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
+    hipStream_t st = as_stream(stream);
+    const long long np = (long long)ceil_div(n, 128) * 128;
+    SURS_REQUIRE(workspace_bytes >= fp32_ws_bytes(np), "workspace too small: need %zu bytes", fp32_ws_bytes(np));
+    const MlpBlobHeader h = blob_layout(SURS_BF16);
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.mode = 3;
+    src.idx = idx;
+    src.ry = ry;
+    src.rz = rz;
+    for (int i = 0; i < 12; ++i) src.mat[i] = mat[i];
+    fill_calib(src, calib, zmul, zdiv);
+    Fp32Workspace w = carve_fp32(workspace, np);
+    int rc = zero_pad_rows(st, w);
+    if (rc) return rc;
+    return run_points_fp32(st, src, n, feat_lr, hl, wl, feat_hr, hh, wh, (const char *)mlp_blob, h, w, pred_hr, pred_lr, nullptr,
+                           nullptr);
 }

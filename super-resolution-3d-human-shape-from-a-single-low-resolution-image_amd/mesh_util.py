@@ -4,10 +4,10 @@
     create_grid -> eval_grid (dense sweep, surs_query_grid) -> 2x Lewiner marching cubes (surs_mc_lewiner)
     -> index->world transform (surs_transform_points).
 
-The occupancy volumes never leave the GPU; only the meshes are copied to the host.  `use_octree=True` is the
-reference's default in gen_mesh but its coarse-to-fine interpolation (with the shared-`dirty` artefact, SURVEY.md
-A.5) is a later row of the scope table: for now both settings run the dense sweep, which evaluates the network at
-every voxel (the octree's own ground truth).
+The occupancy volumes never leave the GPU; only the meshes are copied to the host.  `use_octree=True` (the
+reference's default in gen_mesh) runs the reference's coarse-to-fine sweep (lib/sdf.py:55-120) level by level on the
+device, shared-`dirty` artefact included, with the fp32 kernels; `use_octree=False` runs the dense
+sweep in `opt.precision` - on this hardware the dense bf16 sweep is both faster and free of the artefact.
 """
 import numpy as np
 import torch
@@ -40,10 +40,23 @@ def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=Non
     return vh, vl, mat
 
 
+def eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, init_resolution=64):
+    """eval_grid_octree: float64 device volumes (sdf_hr, sdf_lr) and the grid matrix."""
+    _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
+    calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
+    fl, fh = net.features()
+    zmul, zdiv = net._zscale()
+    vh, vl = native.octree_volumes(resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, net._mlp_blob(), net._workspace(),
+                                   opt.threshold, init_resolution)
+    return vh, vl, mat
+
+
 def mesh_from_volume(net, vol, mat, level=0.5, want_normals=True):
     """marching_cubes_lewiner(vol, level) + index->world transform; numpy outputs like the reference.
     want_normals=False skips normals/values (gen_mesh discards them: lib/train_util.py:72) and returns None for them."""
     ws = net._workspace()
+    if vol.dtype == torch.float64:
+        vol = native.f64_to_f32(vol)   # marching_cubes_lewiner converts its input to float32
     v, f, n, val = native.marching_cubes_lewiner(vol, level, ws, want_normals=want_normals)
     vw = native.transform_points(v, mat[:3].reshape(-1))
     return tuple(ws.to_host([vw, f, n, val]))
@@ -52,7 +65,10 @@ def mesh_from_volume(net, vol, mat, level=0.5, want_normals=True):
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
                    transform=None, want_normals=True):
     """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy)."""
-    vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+    if use_octree:
+        vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+    else:
+        vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     return mesh_from_volume(net, vh, mat, want_normals=want_normals) + mesh_from_volume(net, vl, mat, want_normals=want_normals)
 
 

@@ -290,3 +290,50 @@ def transform_points(verts, mat):
     m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
     check(lib().surs_transform_points(_ptr(verts), verts.shape[0], m, _ptr(out), _stream()))
     return out
+
+
+# ------------------------------------------------------------------ octree sweep (lib/sdf.py:55-120)
+
+def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, threshold, init_resolution=64, num_samples=None):
+    """eval_grid_octree on the device: float64 volumes (sdf_hr, sdf_lr) [R,R,R] like the reference's arrays.
+    Host code only walks the levels; selection, evaluation (fp32 kernels), scatter and the cell pass are kernels."""
+    dev = blob.device
+    n3 = R * R * R
+    sdf_hr = torch.zeros(n3, dtype=torch.float64, device=dev)
+    sdf_lr = torch.zeros(n3, dtype=torch.float64, device=dev)
+    dirty = torch.ones(n3, dtype=torch.uint8, device=dev)
+    cnt_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    reso = R // init_resolution
+    batch = 262144
+    while reso > 0:
+        nl = (R + reso - 1) // reso
+        cap = nl * nl * nl
+        idx = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt = C.c_int(0)
+        check(lib().surs_octree_select(_ptr(dirty), R, reso, _ptr(idx), cap, _ptr(cnt_dev), C.byref(cnt), _stream()))
+        n = cnt.value
+        phr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        plr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        w = ws.get(lib().surs_query_workspace_bytes(min(n, batch)))
+        for b0 in range(0, n, batch):
+            nb = min(batch, n - b0)
+            check(lib().surs_query_grid_indexed(C.c_void_p(idx.data_ptr() + 8 * b0), nb, R, R, m, cal, float(zmul), float(zdiv),
+                                                feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
+                                                _ptr(blob), _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * b0),
+                                                C.c_void_p(plr.data_ptr() + 4 * b0), _stream()))
+        check(lib().surs_octree_scatter(_ptr(idx), n, _ptr(phr), _ptr(plr), _ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), _stream()))
+        if reso <= 1:
+            break
+        w = ws.get(lib().surs_octree_workspace_bytes(R, reso))
+        check(lib().surs_octree_cells(_ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), R, reso, float(threshold), _ptr(w), w.numel(),
+                                      _stream()))
+        reso //= 2
+    return sdf_hr.view(R, R, R), sdf_lr.view(R, R, R)
+
+
+def f64_to_f32(a):
+    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    check(lib().surs_f64_to_f32(_ptr(a), _ptr(out), a.numel(), _stream()))
+    return out

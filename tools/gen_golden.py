@@ -178,6 +178,63 @@ def gen_recon():
                             obj_hr_sha256=np.array(obj_sha))
 
 
+def gen_octree():
+    """eval_grid_octree of the reference: (i) an analytic field (exact restatement check of the cell logic),
+    (ii) the network at R=128 (the default init_resolution=64 -> levels 2, 1)."""
+    import types
+    ns = rh.load_reference()
+    bmin, bmax = np.array([-0.5] * 3), np.array([0.5] * 3)
+
+    def field(points):
+        x, y, z = points
+        a = 0.5 + 0.4 * np.sin(7 * x + 1) * np.cos(5 * y) * np.sin(3 * z + 0.5) + 0.05 * np.sin(40 * x * y)
+        b = 0.5 + 0.3 * np.cos(6 * x) * np.sin(4 * y + 1) * np.cos(5 * z)
+        return a, b
+
+    out = {}
+    for tag, R, thr, init in (("a", 48, 0.05, 12), ("b", 40, 0.12, 20)):
+        coords, mat = ns.sdf.create_grid(R, R, R, bmin, bmax)
+        hr, lr = ns.sdf.eval_grid_octree(types.SimpleNamespace(threshold=thr), coords,
+                                         lambda p: tuple(v[None, None, :] for v in field(p)), init_resolution=init,
+                                         num_samples=50000)
+        out[tag + "_hr"], out[tag + "_lr"] = hr, lr
+        out[tag + "_cfg"] = np.array([R, thr, init])
+        print("octree analytic", tag, R, "zero frac lr", float((lr == 0).mean()))
+    np.savez_compressed(os.path.join(GOLD, "octree_analytic.npz"), **out)
+
+    net, opt_ref, sd = make_net()
+    img = weights.synthetic_image(64, seed=1)
+    with torch.no_grad(), rh.quiet():
+        img_sr, f_lr, f_hr = net.super_res(torch.from_numpy(img.copy()))
+        net.filter_hr(f_hr)
+        net.filter_lr(f_lr)
+    calib = torch.from_numpy(CALIB[None].copy())
+    R = 128
+    cap = {}
+    orig = ns.sdf.eval_grid_octree
+
+    def spy(opt, coords, eval_func, **kw):
+        a, b = orig(opt, coords, eval_func, **kw)
+        cap["hr"], cap["lr"] = a, b
+        return a, b
+
+    ns.mesh_util.eval_grid_octree = spy
+    t = time.time()
+    try:
+        with torch.no_grad(), rh.quiet():
+            vh, fh, _, _, vl, fl_, _, _ = ns.mesh_util.reconstruction(opt_ref, net, torch.device("cpu"), calib, R, bmin, bmax,
+                                                                      use_octree=True, num_samples=50000)
+    finally:
+        ns.mesh_util.eval_grid_octree = orig
+    hr, lr = cap["hr"].astype(np.float32), cap["lr"].astype(np.float32)
+    print("octree net R=128 %.1fs: verts hr %d lr %d; lr zeros %.4f; hr zeros %.4f" %
+          (time.time() - t, len(vh), len(vl), float((lr == 0).mean()), float((hr == 0).mean())))
+    np.savez_compressed(os.path.join(GOLD, "octree_r128.npz"), hr_sub=hr[::2, ::2, ::2], lr_sub=lr[1::2, ::2, 1::2],
+                        n_verts=np.array([len(vh), len(vl)]), n_faces=np.array([len(fh), len(fl_)]),
+                        zero_frac=np.array([float((hr == 0).mean()), float((lr == 0).mean())]),
+                        mean=np.array([float(hr.mean()), float(lr.mean())]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     what = sys.argv[1:] or ["keys", "query", "encoder", "recon"]
