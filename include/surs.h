@@ -149,6 +149,12 @@ int surs_octree_cells(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int 
                       size_t workspace_bytes, void *stream);
 int surs_f64_to_f32(const double *a, float *b, long long n, void *stream);
 
+/* HOST: write a Wavefront OBJ exactly as save_obj_mesh does (lib/mesh_util.py:53-61): 'v %.4f %.4f %.4f' per vertex,
+ * then 'f a c b' per face with 1-based indices and the winding swapped.  verts float64 [n_verts][3], faces int32
+ * [n_faces][3] (host pointers).  threads <= 0: use all hardware threads for the formatting. */
+int surs_save_obj_mesh(const char *path, const double *verts, long long n_verts, const int32_t *faces, long long n_faces,
+                       int threads);
+
 /* Measurement aid (not on the reference's path): when enabled, every launch of the dominant kernel of
  * surs_query_grid's reduced-precision mode is bracketed by HIP events on its launch stream.  surs_profile_read
  * returns the number of timed launches, the sum of their durations (ms) and the voxels they evaluated, and resets. */

@@ -58,6 +58,7 @@ _SIGS = {
     "surs_octree_workspace_bytes": (_sz, [_i, _i]),
     "surs_octree_cells": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_double, _vp, _sz, _vp]),
     "surs_f64_to_f32": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),
+    "surs_save_obj_mesh": (C.c_int, [C.c_char_p, _vp, C.c_longlong, _vp, C.c_longlong, _i]),
     "surs_profile_enable": (C.c_int, [_i]),
     "surs_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "surs_mc_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -647,7 +647,7 @@ struct GridProf {
 }  // namespace
 
 extern "C" int surs_profile_enable(int on) {
-    for (auto &e : g_prof.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto &e : g_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     g_prof.ev.clear();
     g_prof.pts.clear();
     g_prof.on = on != 0;

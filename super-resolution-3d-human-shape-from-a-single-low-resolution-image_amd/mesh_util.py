@@ -81,9 +81,13 @@ def _obj_text(verts, faces):
 
 
 def save_obj_mesh(mesh_path, verts, faces):
-    """Same bytes as the reference writer (lib/mesh_util.py:53-61)."""
-    with open(mesh_path, "w") as fh:
-        fh.write(_obj_text(verts, faces))
+    """Same bytes as the reference writer (lib/mesh_util.py:53-61), formatted natively and in parallel
+    (surs_save_obj_mesh); `_obj_text` is the plain-Python statement of the format, kept for the tests."""
+    import ctypes as C
+    v = np.ascontiguousarray(verts, np.float64).reshape(-1, 3)
+    f = np.ascontiguousarray(faces, np.int32).reshape(-1, 3)
+    native.check(native.lib().surs_save_obj_mesh(str(mesh_path).encode(), v.ctypes.data_as(C.c_void_p), len(v),
+                                                 f.ctypes.data_as(C.c_void_p), len(f), 0))
 
 
 def save_obj_mesh_with_color(mesh_path, verts, faces, colors):

@@ -114,10 +114,32 @@ def test_reconstruction_vs_reference(net, R, golden_dir):
 def test_gen_mesh_writes_both_objs(net, tmp_path):
     from surs_amd import train_util
     opt = common.opt()
-    opt.resolution = 24
+    opt.resolution = 64   # gen_mesh uses the octree like the reference; below 64 its level loop never runs (all-zero
+    #                       volume -> "Surface level must be within volume data range", in the reference too)
     data = {"img_LR": torch.from_numpy(weights.synthetic_image(64, seed=1)), "b_min": np.array([-0.5] * 3),
             "b_max": np.array([0.5] * 3), "name": ("subject", ".png")}
     train_util.gen_mesh(opt, net, torch.device("cuda:0"), data, str(tmp_path / "subject.obj"))
     for tag in ("HR", "LR"):
         lines = open(tmp_path / ("subject_%s.obj" % tag)).read().splitlines()
         assert lines[0].startswith("v ") and lines[-1].startswith("f ")
+    opt.resolution = 24
+    with pytest.raises(ValueError, match="within volume data range"):
+        train_util.gen_mesh(opt, net, torch.device("cuda:0"), data, str(tmp_path / "tiny.obj"))
+
+
+def test_eval_driver_end_to_end(tmp_path):
+    """python -m surs_amd.apps.eval_SuRS with reference-style flags (synthetic image + weights), octree and dense."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for extra in ([], ["--no_octree", "--precision", "bf16"]):
+        out = tmp_path / ("run%d" % len(extra))
+        r = subprocess.run([sys.executable, "-m", "surs_amd.apps.eval_SuRS", "--synthetic", "--residual", "--loadSize", "128",
+                            "--resolution", "128", "--results_path", str(out), "--name", "exp", "--b_min", "-0.5", "-0.5", "-0.5",
+                            "--b_max", "0.5", "0.5", "0.5", "--num_samples", "50000", "--threshold", "0.05"] + extra,
+                           cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        for tag in ("HR", "LR"):
+            path = out / "exp" / ("synthetic_0000_%s.obj" % tag)
+            lines = open(path).read().splitlines()
+            assert lines[0].startswith("v ") and lines[-1].startswith("f ") and len(lines) > 100
