@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsurs_hip.so")
+LIB_PATH = os.environ.get("SURS_LIB_PATH") or os.path.join(_HERE, "libsurs_hip.so")   # override: timing experiments only
 _lib = None
 
 F32, BF16, F16 = 0, 1, 2
