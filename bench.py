@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--resolution", type=int, default=RES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--image", default="noise", choices=["smooth", "noise"],
+                    help="synthetic input: white noise x mask (SURVEY 8d, default) or band-limited; with random-init weights both give a noise-like field")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -63,7 +65,8 @@ def main():
     net = model.SuRSNet(opt).to(device=dev)
     net.load_state_dict(sd)
     net.eval()
-    image = torch.from_numpy(weights.synthetic_image(IMG, seed=1)).to(dev)
+    make_image = weights.smooth_image if args.image == "smooth" else weights.synthetic_image
+    image = torch.from_numpy(make_image(IMG, seed=1)).to(dev)
     calib = train_util.gen_calib().to(dev)
     b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
     lib = _lib.lib()
@@ -141,7 +144,7 @@ def main():
             "config": {"workload": "BASELINE configs[%d]: one 512x512 synthetic image, %d^3 grid, bf16 MFMA classifier cores, "
                                    "HIP marching cubes x2%s" % (2 if world == 1 else 3, R,
                                                                  "" if world == 1 else ", x-slab per rank + RCCL gather"),
-                       "resolution": R, "image": IMG, "queries_per_step": int(queries),
+                       "resolution": R, "image": IMG, "image_kind": args.image, "queries_per_step": int(queries),
                        "reconstruction_s": ms_per_step / 1e3,
                        "stage_ms_rank0": {k: v / args.steps for k, v in stage_ms.items()},
                        "mesh": dict(last), "parallelism": "slab%d" % world},

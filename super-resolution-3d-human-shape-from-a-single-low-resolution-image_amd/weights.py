@@ -189,6 +189,25 @@ def synthetic_image(h, w=None, seed=1):
     return (img * mask).astype(np.float32)
 
 
+def smooth_image(h, w=None, seed=1, waves=6):
+    """[1,3,H,W] float32 in [-1,1] times the same mask as synthetic_image, but band-limited (a few low-frequency
+    cosines with seeded phases) like a photograph rather than white noise: the occupancy field it induces has a
+    surface of body-like extent instead of one crossing in nearly every voxel column.  Used by bench.py."""
+    w = h if w is None else w
+    p = prng.uniform("smooth_image", seed, (3, waves, 4), 0.0, 1.0).astype(np.float64)
+    yy, xx = np.mgrid[:h, :w].astype(np.float64)
+    yy, xx = yy / h, xx / w
+    img = np.zeros((3, h, w))
+    for c in range(3):
+        for k in range(waves):
+            fx, fy = 1 + 5 * p[c, k, 0], 1 + 5 * p[c, k, 1]
+            img[c] += np.cos(2 * np.pi * (fx * xx + fy * yy + p[c, k, 2])) * (0.4 + 0.6 * p[c, k, 3])
+    img = img / np.abs(img).max()
+    mask = np.zeros((1, h, w))
+    mask[:, h // 8: 7 * h // 8, w // 4: 3 * w // 4] = 1.0
+    return (img * mask)[None].astype(np.float32)
+
+
 def synthetic_points(n, seed=2, lo=-0.55, hi=0.55):
     """[3,N] float32 points; about 17 % fall outside the image for +-0.55."""
     return prng.uniform("synthetic_points", seed, (3, n), lo, hi)
