@@ -7,9 +7,12 @@ seeded random-init weights; `value` is queries per second over the whole job.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1: the grid is split into contiguous x-slabs, one per rank (strong scaling: the total work is fixed), every rank
-runs the (tiny) encoder redundantly, the slabs are gathered to rank 0 over RCCL, rank 0 extracts the meshes.
-Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle - test infrastructure, the
+N > 1, default `--mode replicas` (BASELINE configs[4], weak scaling): one subject per GPU (image seeds 1..N), every rank
+runs the whole reconstruction, no data-path collective - subjects are independent, which is how a batch of inputs
+is served; `value` = N x 512^3 queries per max-over-ranks step time.
+`--mode slab` (BASELINE configs[3], strong scaling of ONE subject): the grid is split into contiguous x-slabs, one per
+rank, every rank runs the (small) encoder redundantly, the occupancy slabs are gathered to rank 0 over RCCL (the one real
+exchange step of the path), rank 0 extracts the meshes.  Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle - test infrastructure, the
 checker, never the thing measured - on a bounded sample of the same grid.
 """
 import argparse
@@ -38,6 +41,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--resolution", type=int, default=RES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "slab"],
+                    help="N>1 only: one subject per GPU (weak) or one subject split into x-slabs + RCCL gather (strong)")
     ap.add_argument("--image", default="noise", choices=["smooth", "noise"],
                     help="synthetic input: white noise x mask (SURVEY 8d, default) or band-limited; with random-init weights both give a noise-like field")
     args = ap.parse_args()
@@ -65,8 +70,9 @@ def main():
     net = model.SuRSNet(opt).to(device=dev)
     net.load_state_dict(sd)
     net.eval()
+    slab = world > 1 and args.mode == "slab"
     make_image = weights.smooth_image if args.image == "smooth" else weights.synthetic_image
-    image = torch.from_numpy(make_image(IMG, seed=1)).to(dev)
+    image = torch.from_numpy(make_image(IMG, seed=1 if slab else 1 + rank)).to(dev)
     calib = train_util.gen_calib().to(dev)
     b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
     lib = _lib.lib()
@@ -81,13 +87,13 @@ def main():
         net.filter_hr(f_hr)
         net.filter_lr(f_lr)
         ev[1].record()
-        i0, i1 = sdist.slab_range(R, rank, world)
+        i0, i1 = sdist.slab_range(R, rank, world) if slab else (0, R)
         vh, vl, mat = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max, None, i0, i1)
         ev[2].record()
-        full_hr = sdist.gather_slabs(vh, R, 0)
-        full_lr = sdist.gather_slabs(vl, R, 0)
+        full_hr = sdist.gather_slabs(vh, R, 0) if slab else vh
+        full_lr = sdist.gather_slabs(vl, R, 0) if slab else vl
         ev[3].record()
-        if rank == 0:
+        if rank == 0 or not slab:
             # gen_mesh keeps vertices and faces only (lib/train_util.py:72)
             mh = mesh_util.mesh_from_volume(net, full_hr, mat, want_normals=False)
             ml = mesh_util.mesh_from_volume(net, full_lr, mat, want_normals=False)
@@ -121,7 +127,7 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        queries = float(R) ** 3
+        queries = float(R) ** 3 * (1 if (slab or world == 1) else world)   # replicas: one full grid per rank
         ms_per_step = dt / args.steps * 1e3
         value = queries * args.steps / dt
         # dominant kernel: grid_mlp_kernel on this rank, HIP events around every launch
@@ -139,15 +145,17 @@ def main():
         out = {
             "metric": "occupancy queries/sec (dense %d^3 reconstruction: encoder + query sweep + 2x marching cubes)" % R,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: one 512x512 synthetic image, %d^3 grid, bf16 MFMA classifier cores, "
-                                   "HIP marching cubes x2%s" % (2 if world == 1 else 3, R,
-                                                                 "" if world == 1 else ", x-slab per rank + RCCL gather"),
+            "config": {"workload": "BASELINE configs[%d]: %s 512x512 synthetic image%s, %d^3 grid each, bf16 MFMA classifier cores, "
+                                   "HIP marching cubes x2%s" % (2 if world == 1 else (3 if slab else 4),
+                                                                 "one" if (slab or world == 1) else str(world),
+                                                                 "" if (slab or world == 1) else "s (one subject per GPU, replicas)", R,
+                                                                 ", x-slab per rank + RCCL gather" if slab else ""),
                        "resolution": R, "image": IMG, "image_kind": args.image, "queries_per_step": int(queries),
                        "reconstruction_s": ms_per_step / 1e3,
                        "stage_ms_rank0": {k: v / args.steps for k, v in stage_ms.items()},
-                       "mesh": dict(last), "parallelism": "slab%d" % world},
+                       "mesh": dict(last), "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world)},
             "roofline": {"kernel": "grid_mlp_kernel_v2<%s>" % args.precision, "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts_per_launch,
