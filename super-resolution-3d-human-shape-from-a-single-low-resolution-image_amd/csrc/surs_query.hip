@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
 }
 
 #include "surs_grid_v2.inc"
+#include "surs_grid_v3.inc"
 
 }  // namespace surs
 
@@ -742,7 +743,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
     static int kver = -1;
     if (kver < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
-        kver = (e && e[0] == '1') ? 1 : 2;
+        kver = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 2;
     }
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[dtype]) {
@@ -750,6 +751,10 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_F16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_BF16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_F16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
         if (dtype == SURS_BF16)
             SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
@@ -791,7 +796,12 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             SURS_HIP_CHECK(hipEventCreate(&e1));
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
-        if (kver == 2) {
+        if (kver == 3) {
+            if (dtype == SURS_BF16)
+                hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
+        } else if (kver == 2) {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v2<SURS_BF16>, dim3(grid), dim3(256), GRID2_LDS_BYTES, st, a);
             else
