@@ -156,7 +156,7 @@ def main():
                        "reconstruction_s": ms_per_step / 1e3,
                        "stage_ms_rank0": {k: v / args.steps for k, v in stage_ms.items()},
                        "mesh": dict(last), "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world)},
-            "roofline": {"kernel": "grid_mlp_kernel_v2<%s>" % args.precision, "bound": "mfma", "achieved": achieved, "peak": peak,
+            "roofline": {"kernel": "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "3")[:1], args.precision), "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts_per_launch,
                          "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": 2752512},

@@ -739,11 +739,14 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    // SURS_GRID_KERNEL=1 selects the simple (non-pipelined) kernel: kept as the bitwise regression reference
+    // SURS_GRID_KERNEL selects the column kernel: 3 (default) = waves split the output channels, weights straight
+    // from L2 into registers; 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple
+    // one-barrier-per-slab form of 2.  1 and 2 are bit-identical and kept as the regression reference of 3, which
+    // differs from them only in the summation order of the final 128-term dot product.
     static int kver = -1;
     if (kver < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
-        kver = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 2;
+        kver = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 3;
     }
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[dtype]) {

@@ -1,0 +1,62 @@
+"""Reduces the rocprofv3 --pmc CSVs that tools/profile_round.sh collected (gpurun_out/prof/) to profiles/pmc_summary.json
+and copies the per-kernel rows of the column kernel next to it.  HBM bytes per launch of the column kernel =
+2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md: the counter reports half the bytes of wide coalesced reads)
++ WRITE_SIZE, both in KiB, each from its own pass, averaged over the launches of that kernel."""
+import csv, glob, json, os, sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def rows(sub, counter):
+    out = []
+    for f in glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "grid_mlp_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                out.append(r)
+    return out
+
+
+def mean(rs):
+    v = [float(r["Counter_Value"]) for r in rs]
+    return sum(v) / len(v) if v else None
+
+
+def dur_ms(rs):
+    v = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in rs]
+    return sum(v) / len(v) if v else None
+
+
+def keep(sub, counter, name):
+    rs = rows(sub, counter)
+    if rs:
+        with open(os.path.join(ROOT, "profiles", name), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rs[0].keys()))
+            w.writeheader()
+            w.writerows(rs)
+    return rs
+
+
+fetch = keep("pmc_fetch", "FETCH_SIZE", "%s_pmc_fetch_size.csv" % TAG)
+write = keep("pmc_write", "WRITE_SIZE", "%s_pmc_write_size.csv" % TAG)
+hit, miss = rows("pmc_l2", "TCC_HIT_sum"), rows("pmc_l2", "TCC_MISS_sum")
+gui = rows("pmc_clk", "GRBM_GUI_ACTIVE")
+f_kb, w_kb = mean(fetch), mean(write)
+s = {
+    "kernel": fetch[0]["Kernel_Name"] if fetch else None,
+    "launch": "16384 columns x 512 voxels = 8388608 queries (bf16, R=512), tools/gpu_grid_once.py 512 bf16",
+    "fetch_size_kb_raw_per_launch": f_kb,
+    "write_size_kb_per_launch": w_kb,
+    "grid_mlp_kernel_hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0 if f_kb is not None and w_kb is not None else None,
+    "l2_hit_rate": (mean(hit) / (mean(hit) + mean(miss))) if hit and miss else None,
+    "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
+    "effective_clock_ghz": (mean(gui) / 8.0 / (dur_ms(gui) * 1e-3) * 1e-9) if gui else None,
+    "avg_launch_ms_under_pmc": dur_ms(fetch),
+    # algorithmic bytes of one launch: the per-column constants (CC_PAD floats per column), the column masks, the two
+    # output fields (2 x 4 B per voxel) and the packed weight stream once (2 x 42 slabs x 32 KiB)
+    "algorithmic_bytes_per_launch": 16384 * 2944 * 4 + 16384 * 4 + 8388608 * 8 + 2 * 42 * 32768,
+    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); separate --pmc passes; GRBM_GUI_ACTIVE is summed over the 8 XCDs",
+}
+json.dump(s, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(s, indent=1))
