@@ -28,6 +28,11 @@ constexpr int ZV_W0Z_LR = 0, ZV_W0Z_HR = 1024, ZV_W0P_HR = 2048, ZV_B1_LR = 3072
 //   per MLP: L1 (512x1024): 32 slabs of [2 k-steps][16 row tiles][64 lanes][8]
 //            L2 core (256x512): 8 slabs of [4 k-steps][8 row tiles][64][8]
 //            L3 core (128x256): 2 slabs of [8 k-steps][4 row tiles][64][8]
+// The second image (core16) holds the same matrices as 1 KiB fragments [64 lanes][8] of the 16x16x32 shape, lane =
+// (row n = lane & 15, k block q = lane >> 4):
+//   per MLP: L1: [32 k-steps][32 row tiles]  element j = W1[16T + n][32s + 8q + j]
+//            L2: [16 k-steps][16 row tiles]  element j = W2[16T + n][32s + 16(j>>2) + 4q + (j&3)]   (k order of a result
+//            L3: [ 8 k-steps][ 8 row tiles]  likewise with W3                                          tile pair reused as B)
 constexpr int SLAB_BYTES = 32768, SLABS_L1 = 32, SLABS_L2 = 8, SLABS_L3 = 2, SLABS_PER_MLP = 42, SLABS_TOTAL = 84;
 
 struct MlpBlobHeader {
@@ -42,9 +47,10 @@ struct MlpBlobHeader {
     uint32_t wc;    // fp32 k-major [320][CC_PAD]
     uint32_t bc;    // fp32 [CC_PAD]
     uint32_t zvec;  // fp32 [ZV_N]
-    uint32_t core;  // SLABS_TOTAL * SLAB_BYTES
+    uint32_t core;  // SLABS_TOTAL * SLAB_BYTES: A fragments of the 32x32x16 MFMA shape (column kernels v1-v3)
     uint32_t total_bytes;
-    uint32_t pad[5];
+    uint32_t core16;  // the same cores as A fragments of the 16x16x32 shape (column kernel v4), same size
+    uint32_t pad[4];
 };
 static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 constexpr uint32_t MLP_MAGIC = 0x53525553u;
@@ -74,6 +80,7 @@ inline MlpBlobHeader blob_layout(uint32_t dtype) {
     h.bc = take((size_t)CC_PAD * 4);
     h.zvec = take((size_t)ZV_N * 4);
     h.core = take((size_t)SLABS_TOTAL * SLAB_BYTES);
+    h.core16 = take((size_t)SLABS_TOTAL * SLAB_BYTES);
     h.total_bytes = (uint32_t)off;
     return h;
 }

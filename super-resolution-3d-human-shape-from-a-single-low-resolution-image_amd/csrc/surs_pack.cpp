@@ -145,6 +145,28 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
                         }
         }
     }
+    // ---- the same cores as A fragments of the 16x16x32 MFMA shape
+    {
+        uint16_t *core = (uint16_t *)(base + h.core16);
+        auto cvt = [&](float f) { return dtype == SURS_F16 ? f32_to_f16(f) : f32_to_bf16(f); };
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = kDims[m][0];
+            uint16_t *p = core + (size_t)m * SLABS_PER_MLP * (SLAB_BYTES / 2);
+            const int rows[3] = {D2, D3, D4}, kin[3] = {D1, D2, D3}, ld[3] = {D1, D2 + c0, D3 + c0};
+            for (int l = 0; l < 3; ++l) {
+                const int nT = rows[l] / 16, nS = kin[l] / 32;
+                for (int s = 0; s < nS; ++s)
+                    for (int T = 0; T < nT; ++T)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int n = lane & 15, q = lane >> 4;
+                                const int k = l == 0 ? 32 * s + 8 * q + j : 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+                                p[(((size_t)s * nT + T) * 64 + lane) * 8 + j] = cvt(W[m][l + 1][(size_t)(16 * T + n) * ld[l] + k]);
+                            }
+                p += (size_t)nS * nT * 512;
+            }
+        }
+    }
     return off;
 }
 

@@ -351,6 +351,7 @@ struct GridArgs {
     const float *colmask;  // [ncols]
     const float *zvec;     // [ZV_N]
     const char *core;      // SLABS_TOTAL slabs
+    const char *core16;    // the same cores in 16x16x32 fragment order (kernel v4)
     float *vol_hr, *vol_lr;  // [ncols][rz]
     int ncols, rz;
     double z0, dz;  // world z of voxel k = (float)(dz*k + z0)
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
 
 #include "surs_grid_v2.inc"
 #include "surs_grid_v3.inc"
+#include "surs_grid_v4.inc"
 
 }  // namespace surs
 
@@ -740,13 +742,14 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
     // SURS_GRID_KERNEL selects the column kernel: 3 (default) = waves split the output channels, weights straight
-    // from L2 into registers; 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple
-    // one-barrier-per-slab form of 2.  1 and 2 are bit-identical and kept as the regression reference of 3, which
-    // differs from them only in the summation order of the final 128-term dot product.
+    // from L2 into registers; 4 = the same on the 16x16x32 MFMA shape (experimental: higher clock, more cycles, +1 %);
+    // 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.
+    // 1 and 2 are bit-identical and kept as the regression reference of 3, which differs from them only in the
+    // summation order of the final 128-term dot product.
     static int kver = -1;
     if (kver < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
-        kver = (e && e[0] >= '1' && e[0] <= '3') ? (e[0] - '0') : 3;
+        kver = (e && e[0] >= '1' && e[0] <= '4') ? (e[0] - '0') : 3;
     }
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[dtype]) {
@@ -757,6 +760,10 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_BF16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_F16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_BF16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_F16>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
         if (dtype == SURS_BF16)
             SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>,
@@ -782,6 +789,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.colmask = cmask;
         a.zvec = (const float *)(blob + h.zvec);
         a.core = blob + h.core;
+        a.core16 = blob + h.core16;
         a.vol_hr = vol_hr + (size_t)c0 * rz;
         a.vol_lr = vol_lr + (size_t)c0 * rz;
         a.ncols = (int)nc;
@@ -799,7 +807,12 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             SURS_HIP_CHECK(hipEventCreate(&e1));
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
-        if (kver == 3) {
+        if (kver == 4) {
+            if (dtype == SURS_BF16)
+                hipLaunchKernelGGL(grid_mlp_kernel_v4<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(grid_mlp_kernel_v4<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
+        } else if (kver == 3) {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
             else
@@ -815,7 +828,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         SURS_LAUNCH_CHECK();
 #ifdef SURS_V3_TRACE
-        if (kver == 3 && c0 == 0 && getenv("SURS_V3_TRACE")) {
+        if (kver >= 3 && c0 == 0 && getenv("SURS_V3_TRACE")) {
             unsigned long long t[64];
             SURS_HIP_CHECK(hipStreamSynchronize(st));
             SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
