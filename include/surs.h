@@ -116,6 +116,20 @@ int surs_query_points(const float *points, int n, const float *calib, float zmul
                       size_t workspace_bytes, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr,
                       void *stream);
 
+/* The same for num_views > 1 and / or the perspective projection (SurfaceClassifier.forward's view mean after layer 2,
+ * lib/model/SurfaceClassifier.py:70-76; reshape_sample_tensor, lib/train_util.py:40-51; perspective,
+ * lib/geometry.py:34-48).  One subject (batch 1), V views:
+ *   points  [V][3][n] (the caller repeats the samples per view as reshape_sample_tensor does), calibs HOST [V][12],
+ *   projection 0 = orthogonal, 1 = perspective (x, y divided by the projected z),
+ *   feat_lr NHWC [V][hl][wl][256], feat_hr NHWC [V][hh][wh][64],
+ *   pred_hr / pred_lr [V][n]: the one prediction of the view-mean network under each view's in-image mask
+ *   (`in_img[:, None].float() * mlp(...)`, SuRSNet.py:156,183), logit_* [n] nullable. */
+int surs_query_points_views(const float *points, int n, int num_views, int projection, const float *calibs, float zmul,
+                            float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                            const void *mlp_blob, void *workspace, size_t workspace_bytes, float *pred_hr, float *pred_lr,
+                            float *logit_hr, float *logit_lr, void *stream);
+size_t surs_query_views_workspace_bytes(int max_points, int num_views);
+
 /* Dense grid sweep: voxel (i,j,k), i in [i0,i1), j in [0,ry), k in [0,rz) has world position
  * p = float32( mat[:,0]*i + mat[:,1]*j + mat[:,2]*k + mat[:,3] )  (mat HOST [12] doubles = create_grid's
  * coords_matrix rows 0..2, evaluated in double like np.matmul on the float64 grid, then cast as eval_func does).

@@ -261,6 +261,74 @@ def query(sd, points, calib, feat_lr, feat_hr, load_size=1024, z_size=200.0, wan
     return tuple(outs) if want_logits else (outs[0], outs[1])
 
 
+def _bilinear_np(feat, u, v):
+    """grid_sample(feat[C,H,W], (u,v), bilinear, zeros padding, align_corners=True) for N points -> [C,N] (geometry.py:4-12)."""
+    f32 = np.float32
+    C_, H, W = feat.shape
+    ix = ((u + f32(1.0)) / f32(2.0)) * f32(W - 1)
+    iy = ((v + f32(1.0)) / f32(2.0)) * f32(H - 1)
+    fx, fy = np.floor(ix), np.floor(iy)
+    x0, y0 = fx.astype(np.int64), fy.astype(np.int64)
+    x1, y1 = x0 + 1, y0 + 1
+    fx1, fy1 = (fx + f32(1.0)), (fy + f32(1.0))
+    w = {(0, 0): (fx1 - ix) * (fy1 - iy), (0, 1): (ix - fx) * (fy1 - iy), (1, 0): (fx1 - ix) * (iy - fy), (1, 1): (ix - fx) * (iy - fy)}
+    out = np.zeros((C_, u.shape[0]), f32)
+    for (dy, dx), wt in w.items():
+        xs, ys = (x1 if dx else x0), (y1 if dy else y0)
+        ok = (xs >= 0) & (xs < W) & (ys >= 0) & (ys < H)
+        xs_c, ys_c = np.clip(xs, 0, W - 1), np.clip(ys, 0, H - 1)
+        out += np.where(ok, wt, f32(0.0)).astype(f32)[None, :] * feat[:, ys_c, xs_c]
+    return out
+
+
+def query_views(sd, points, calibs, feat_lr, feat_hr, projection="orthogonal", load_size=1024, z_size=200.0):
+    """query_mr + query_sr + get_preds for ONE subject seen from V views (num_views = V >= 1), numpy restatement of
+    SuRSNet.py:131-187 with SurfaceClassifier.forward's view mean (SurfaceClassifier.py:53-81: after layer
+    len(filters)//2 = 2 both the activations and the input features are averaged over the views), the sample layout of
+    reshape_sample_tensor (train_util.py:40-51) and both projections (geometry.py:15-48).
+    points [V,3,N], calibs [V,4,4], feat_lr [V,256,h,w], feat_hr [V,64,H,W].
+    Returns pred_hr [V,N], pred_lr [V,N], logit_hr [N], logit_lr [N] (fp32)."""
+    f32 = np.float32
+    pts, cal = _f32(points), _f32(calibs)
+    V, _, n = pts.shape
+    feats, masks = [], []
+    for v in range(V):
+        rot, trans = cal[v, :3, :3], cal[v, :3, 3:4]
+        xyz = (trans + rot @ pts[v]).astype(f32)                 # baddbmm
+        if projection == "perspective":
+            xy = (xyz[:2] / xyz[2:3]).astype(f32)
+        else:
+            xy = xyz[:2]
+        z = xyz[2:3]
+        masks.append(((xy[0] >= -1.0) & (xy[0] <= 1.0) & (xy[1] >= -1.0) & (xy[1] <= 1.0)).astype(f32))
+        zf = (z * f32(load_size // 2) / f32(z_size)).astype(f32)   # DepthNormalizer.py:18
+        feats.append(np.concatenate([_bilinear_np(_f32(feat_lr[v]), xy[0], xy[1]), _bilinear_np(_f32(feat_hr[v]), xy[0], xy[1]), zf], 0))
+
+    def mlp(prefix, x_views):
+        W = [_f32(sd[prefix + "conv%d.weight" % l]).reshape(sd[prefix + "conv%d.weight" % l].shape[0], -1) for l in range(5)]
+        B = [_f32(sd[prefix + "conv%d.bias" % l])[:, None] for l in range(5)]
+        lrelu = lambda a: np.where(a > 0, a, f32(0.01) * a).astype(f32)
+        ys = []
+        for x in x_views:                                        # layers 0..2 per view (layer 2 takes cat([y, feature]))
+            y = lrelu(W[0] @ x + B[0])
+            y = lrelu(W[1] @ y + B[1])
+            ys.append(lrelu(W[2] @ np.concatenate([y, x], 0) + B[2]))
+        inv = f32(1.0) / f32(len(x_views))
+        y, xm = ys[0].copy(), x_views[0].copy()
+        for v in range(1, len(x_views)):
+            y, xm = y + ys[v], xm + x_views[v]
+        y, xm = (y * inv).astype(f32), (xm * inv).astype(f32)    # .mean(dim=1): sum in view order, times 1/V
+        y = lrelu(W[3] @ np.concatenate([y, xm], 0) + B[3])
+        return (W[4] @ np.concatenate([y, xm], 0) + B[4])[0].astype(f32)
+
+    sig = lambda a: (f32(1.0) / (f32(1.0) + np.exp(-a))).astype(f32)
+    logit_lr = mlp("mlp_lr.", feats)
+    pred_lr = np.stack([m * sig(logit_lr) for m in masks])       # in_img[:, None].float() * mlp(...)   SuRSNet.py:156
+    logit_hr = mlp("mlp_hr.", [np.concatenate([feats[v], pred_lr[v:v + 1]], 0) for v in range(V)])
+    pred_hr = np.stack([m * sig(logit_hr) for m in masks])
+    return pred_hr, pred_lr, logit_hr, logit_lr
+
+
 def grid_points(res, b_min, b_max, i0=0, i1=None):
     """Flat grid coordinates [3, i1-i0] as float32 (create_grid + eval_func cast: sdf.py:4-29, mesh_util.py:24)."""
     rx, ry, rz = (res, res, res) if np.isscalar(res) else res

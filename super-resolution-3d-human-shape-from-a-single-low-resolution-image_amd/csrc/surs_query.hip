@@ -48,6 +48,7 @@ struct PointSource {
     double mat[12];  // create_grid's coords_matrix rows 0..2
     float calib[12];
     float zmul, zdiv;
+    int persp;  // 1: perspective projection (lib/geometry.py:34-48): x, y divided by the projected z
 };
 
 __device__ __forceinline__ void make_point(const PointSource &s, long long t, float &px, float &py, float &pz) {
@@ -98,6 +99,10 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
             X = c[3] + ((c[0] * px + c[1] * py) + c[2] * pz);
             Y = c[7] + ((c[4] * px + c[5] * py) + c[6] * pz);
             const float Z = c[11] + ((c[8] * px + c[9] * py) + c[10] * pz);
+            if (src.persp) {
+                X = X / Z;
+                Y = Y / Z;
+            }
             const float in = (X >= -1.0f && X <= 1.0f && Y >= -1.0f && Y <= 1.0f) ? 1.0f : 0.0f;
             mask[t] = in;
             if (zproj) zproj[t] = Z;
@@ -262,6 +267,38 @@ __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__
     pred[t] = p;
     if (logit) logit[t] = acc;
     if (p_slot) p_slot[t] = p;
+}
+
+// multi-view (num_views > 1, SurfaceClassifier.py:70-76): out[r][t] = (sum_v in[v][r][t]) * (1/V), views summed in order
+__global__ __launch_bounds__(256) void mean_views_kernel(const float *__restrict__ in, long long view_stride, int nviews,
+                                                         long long count, float inv, float *__restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    float acc = in[t];
+    for (int v = 1; v < nviews; ++v) acc += in[(long long)v * view_stride + t];
+    out[t] = acc * inv;
+}
+
+// multi-view last layer: one logit per point from the view means; every view gets it under its own in-image mask
+// (SuRSNet.py:156,183: `in_img[:, None].float() * mlp(...)` broadcasts the [1,1,N] prediction over the V masks)
+__global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__restrict__ w4, const float *__restrict__ Y3,
+                                                             const float *__restrict__ Fm, long long ld, long long n,
+                                                             int nviews, const float *__restrict__ mask /*[V][ld]*/,
+                                                             float *__restrict__ pred /*[V][n]*/, float *__restrict__ logit,
+                                                             float *__restrict__ p_slot /*row 321 of view 0's F*/,
+                                                             long long f_view_stride) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float acc = w4[D4 + C0PAD];
+    for (int k = 0; k < D4; ++k) acc = fmaf(w4[k], Y3[(long long)k * ld + t], acc);
+    for (int k = 0; k < C_G + 2; ++k) acc = fmaf(w4[D4 + k], Fm[(long long)k * ld + t], acc);
+    const float y = 1.0f / (1.0f + expf(-acc));
+    if (logit) logit[t] = acc;
+    for (int v = 0; v < nviews; ++v) {
+        const float p = mask[(long long)v * ld + t] * y;
+        pred[(long long)v * n + t] = p;
+        if (p_slot) p_slot[(long long)v * f_view_stride + t] = p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,6 +672,89 @@ extern "C" int surs_query_points(const float *points, int n, const float *calib,
     if (rc) return rc;
     return run_points_fp32(st, src, n, feat_lr, hl, wl, feat_hr, hh, wh, (const char *)mlp_blob, h, w, pred_hr, pred_lr,
                            logit_hr, logit_lr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-view / perspective queries: SurfaceClassifier.py:70-76, train_util.py:40-51, geometry.py:34-48
+// ------------------------------------------------------------------------------------------------
+static size_t views_ws_bytes(long long np, int nviews) {
+    // per view: F (C0PAD rows), Y2 (D3 rows), mask; shared: Y0, Y1, Y3, mean F, mean Y2
+    return ((size_t)nviews * (C0PAD + D3 + 1) + (D1 + D2 + D4 + C0PAD + D3)) * (size_t)np * sizeof(float) + 4096;
+}
+
+extern "C" size_t surs_query_views_workspace_bytes(int max_points, int num_views) {
+    return views_ws_bytes((long long)ceil_div(max_points, 128) * 128, num_views < 1 ? 1 : num_views);
+}
+
+extern "C" int surs_query_points_views(const float *points, int n, int num_views, int projection, const float *calibs,
+                                       float zmul, float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr,
+                                       int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,
+                                       float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr, void *stream) {
+    SURS_REQUIRE(n >= 0, "negative point count");
+    SURS_REQUIRE(num_views >= 1 && num_views <= 64, "num_views must be in [1, 64]");
+    SURS_REQUIRE(projection == 0 || projection == 1, "projection: 0 = orthogonal, 1 = perspective");
+    if (n == 0) return 0;
+    SURS_REQUIRE(points && calibs && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
+    SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
+    hipStream_t st = as_stream(stream);
+    const long long np = (long long)ceil_div(n, 128) * 128;
+    SURS_REQUIRE(workspace_bytes >= views_ws_bytes(np, num_views), "workspace too small: need %zu bytes",
+                 views_ws_bytes(np, num_views));
+    const MlpBlobHeader h = blob_layout(SURS_BF16);
+    const char *blob = (const char *)mlp_blob;
+    const int V = num_views;
+    float *p = (float *)workspace;
+    float *F = p;      p += (size_t)V * C0PAD * np;  // [V][C0PAD][np]
+    float *Y2 = p;     p += (size_t)V * D3 * np;     // [V][D3][np]
+    float *mask = p;   p += (size_t)V * np;          // [V][np]
+    float *Y0 = p;     p += (size_t)D1 * np;
+    float *Y1 = p;     p += (size_t)D2 * np;
+    float *Y3 = p;     p += (size_t)D4 * np;
+    float *Fm = p;     p += (size_t)C0PAD * np;
+    float *Y2m = p;
+    const long long fstride = (long long)C0PAD * np;
+    // gather every view with its own calibration and feature maps; zero the padding rows of every F
+    for (int v = 0; v < V; ++v) {
+        float *Fv = F + (size_t)v * fstride;
+        SURS_HIP_CHECK(hipMemsetAsync(Fv + (size_t)(C_G + 2) * np, 0, (size_t)(C0PAD - C_G - 2) * np * sizeof(float), st));
+        PointSource src;
+        memset(&src, 0, sizeof(src));
+        src.mode = 0;
+        src.pts = points + (size_t)v * 3 * n;
+        src.ld = n;
+        src.persp = projection;
+        fill_calib(src, calibs + 12 * v, zmul, zdiv);
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
+                           feat_lr + (size_t)v * hl * wl * C_LR, hl, wl, feat_hr + (size_t)v * hh * wh * C_HR, hh, wh, Fv, np,
+                           mask + (size_t)v * np, (float *)nullptr);
+        SURS_LAUNCH_CHECK();
+    }
+    for (int m = 0; m < 2; ++m) {
+        auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
+        auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
+        int rc;
+        for (int v = 0; v < V; ++v) {
+            const float *Fv = F + (size_t)v * fstride;
+            if ((rc = launch_gemm(st, false, WT(0), D1, Fv, C0PAD, np, nullptr, 0, 0, BI(0), 1, Y0, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(1), D2, Y0, D1, np, nullptr, 0, 0, BI(1), 1, Y1, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(2), D3, Y1, D2, np, Fv, C0PAD, np, BI(2), 1, Y2 + (size_t)v * D3 * np, np, np)))
+                return rc;
+        }
+        // the view mean after layer 2 (index len(filters) // 2) of both the activations and the input features
+        const float inv = 1.0f / (float)V;
+        hipLaunchKernelGGL(mean_views_kernel, dim3((unsigned)ceil_div((long long)D3 * np, 256)), dim3(256), 0, st, Y2,
+                           (long long)D3 * np, V, (long long)D3 * np, inv, Y2m);
+        SURS_LAUNCH_CHECK();
+        hipLaunchKernelGGL(mean_views_kernel, dim3((unsigned)ceil_div(fstride, 256)), dim3(256), 0, st, F, fstride, V, fstride,
+                           inv, Fm);
+        SURS_LAUNCH_CHECK();
+        if ((rc = launch_gemm(st, false, WT(3), D4, Y2m, D3, np, Fm, C0PAD, np, BI(3), 1, Y3, np, np))) return rc;
+        hipLaunchKernelGGL(mlp_last_views_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                           (const float *)(blob + h.w4[m]), Y3, Fm, np, (long long)n, V, mask, m == 0 ? pred_lr : pred_hr,
+                           m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride);
+        SURS_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

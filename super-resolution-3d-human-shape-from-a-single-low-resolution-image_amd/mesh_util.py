@@ -40,6 +40,31 @@ def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=Non
     return vh, vl, mat
 
 
+def eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, num_samples=1 << 18):
+    """Dense sweep for num_views > 1 or the perspective projection: eval_grid's batch loop (lib/sdf.py:32-52) over
+    eval_func (lib/mesh_util.py:20-28) - every batch of grid points repeated per view, query_mr + query_sr, view 0's
+    prediction kept (`net.get_preds()[0][0]`).  Grid coordinates in float64, cast to float32, like create_grid."""
+    _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
+    dev = net._device()
+    R = int(resolution)
+    total = R * R * R
+    M = torch.from_numpy(np.asarray(mat, np.float64)).to(dev)
+    vh = torch.empty(total, dtype=torch.float32, device=dev)
+    vl = torch.empty_like(vh)
+    calib = calib_tensor.to(dev)
+    for s in range(0, total, num_samples):
+        f = torch.arange(s, min(total, s + num_samples), device=dev, dtype=torch.int64)
+        i, j, k = (f // (R * R)).double(), ((f // R) % R).double(), (f % R).double()
+        pts = torch.stack([(((M[r, 0] * i + M[r, 1] * j) + M[r, 2] * k) + M[r, 3]) for r in range(3)]).float()
+        samples = pts.unsqueeze(0).repeat(net.num_views, 1, 1)
+        net.query_mr(samples, calib)
+        net.query_sr(samples, calib)
+        phr, plr = net.get_preds()
+        vh[s:s + f.numel()] = phr[0, 0]
+        vl[s:s + f.numel()] = plr[0, 0]
+    return vh.view(R, R, R), vl.view(R, R, R), mat
+
+
 def eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, init_resolution=64):
     """eval_grid_octree: float64 device volumes (sdf_hr, sdf_lr) and the grid matrix."""
     _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
@@ -65,7 +90,10 @@ def mesh_from_volume(net, vol, mat, level=0.5, want_normals=True):
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
                    transform=None, want_normals=True):
     """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy)."""
-    if use_octree:
+    if net.num_views > 1 or getattr(net, "projection_mode", "orthogonal") != "orthogonal":
+        # multi-view / perspective: always the dense sweep (the octree walk is only wired to the single-view kernels)
+        vh, vl, mat = eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+    elif use_octree:
         vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     else:
         vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)

@@ -38,9 +38,9 @@ def _as_img(t):
 
 class SuRSNet:
     def __init__(self, opt, projection_mode="orthogonal", error_term=None):
-        if projection_mode != "orthogonal":
-            raise NotImplementedError("only the orthogonal projection is on the reference's eval path "
-                                      "(EvalDataset_LR_v2.py:136)")
+        if projection_mode not in ("orthogonal", "perspective"):
+            raise ValueError("projection_mode must be 'orthogonal' or 'perspective' (BaseSuRSNet.py:26)")
+        self.projection_mode = projection_mode
         self.name = "base"
         self.opt = opt
         self.num_views = opt.num_views
@@ -169,15 +169,32 @@ class SuRSNet:
     def _query(self, points, calibs, transforms):
         if transforms is not None:
             raise NotImplementedError("image-space `transforms` are never passed on the eval path (lib/geometry.py:27-30)")
-        if points.shape[0] != 1 or self.num_views != 1:
-            raise NotImplementedError("multi-view queries (num_views > 1) are not built yet (SURVEY.md 8f-4)")
         dev = self._device()
-        pts = points[0].to(dev, torch.float32).contiguous()
-        calib = calibs[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
-        fl, fh = self.features()
         zmul, zdiv = self._zscale()
-        phr, plr = native.query_points(pts, calib, zmul, zdiv, fl, fh, self._mlp_blob(), self._workspace())
-        return phr.view(1, 1, -1), plr.view(1, 1, -1)
+        V = self.num_views
+        if V == 1 and self.projection_mode == "orthogonal":
+            if points.shape[0] != 1:
+                raise NotImplementedError("one subject per call: points must be [1,3,N] (gen_mesh never batches subjects)")
+            pts = points[0].to(dev, torch.float32).contiguous()
+            calib = calibs[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
+            fl, fh = self.features()
+            phr, plr = native.query_points(pts, calib, zmul, zdiv, fl, fh, self._mlp_blob(), self._workspace())
+            return phr.view(1, 1, -1), plr.view(1, 1, -1)
+        # multi-view and / or perspective: the view mean of SurfaceClassifier.py:70-76 needs every view of the one subject
+        # in the call: points [V,3,N] as reshape_sample_tensor (train_util.py:40-51) lays them out, calibs [V,4,4]
+        if points.shape[0] != V or calibs.shape[0] != V:
+            raise NotImplementedError("one subject per call: points must be [num_views,3,N] and calibs [num_views,4,4]")
+        if not self.im_feat_list_lr or not self.im_feat_list_hr:
+            raise RuntimeError("filter_lr / filter_hr must run before a query")
+        fl = self.im_feat_list_lr[-1].to(dev).permute(0, 2, 3, 1).contiguous()
+        fh = self.im_feat_list_hr[0].to(dev).permute(0, 2, 3, 1).contiguous()
+        if fl.shape[0] != V or fh.shape[0] != V:
+            raise RuntimeError("the encoder ran on %d views, num_views is %d" % (fl.shape[0], V))
+        pts = points.to(dev, torch.float32).contiguous()
+        cal = calibs.detach().to("cpu", torch.float32).numpy().reshape(V, -1)[:, :12]
+        phr, plr = native.query_points_views(pts, cal, self.projection_mode, zmul, zdiv, fl, fh, self._mlp_blob(),
+                                             self._workspace())
+        return phr.view(V, 1, -1), plr.view(V, 1, -1)
 
     def query_mr(self, points, calibs, transforms=None, labels=None):
         """Evaluates both classifiers in one fused pass; preds_hr is kept for the following query_sr."""

@@ -226,6 +226,28 @@ def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_log
     return tuple(outs)
 
 
+def query_points_views(points, calibs, projection, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_logits=False):
+    """Multi-view / perspective query.  points [V,3,N] f32 device tensor; calibs [V,12] (host); feat_lr [V,hl,wl,256] and
+    feat_hr [V,hh,wh,64] contiguous NHWC device tensors; projection 'orthogonal' | 'perspective'.
+    Returns pred_hr [V,N], pred_lr [V,N][, logit_hr [N], logit_lr [N]]."""
+    points = _f32c(points)
+    V, _, n = points.shape
+    dev = points.device
+    feat_lr, feat_hr = _f32c(feat_lr), _f32c(feat_hr)
+    assert feat_lr.shape[0] == V and feat_hr.shape[0] == V and feat_lr.shape[3] == 256 and feat_hr.shape[3] == 64
+    phr = torch.empty((V, n), dtype=torch.float32, device=dev)
+    plr = torch.empty_like(phr)
+    lg = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(2)] if want_logits else [None, None]
+    cal = np.ascontiguousarray(np.asarray(calibs, np.float32).reshape(V, -1)[:, :12])
+    cbuf = (C.c_float * (12 * V))(*[float(v) for v in cal.reshape(-1)])
+    w = ws.get(lib().surs_query_views_workspace_bytes(n, V))
+    check(lib().surs_query_points_views(_ptr(points), n, V, {"orthogonal": 0, "perspective": 1}[projection], cbuf, float(zmul),
+                                        float(zdiv), _ptr(feat_lr), feat_lr.shape[1], feat_lr.shape[2], _ptr(feat_hr),
+                                        feat_hr.shape[1], feat_hr.shape[2], _ptr(blob), _ptr(w), w.numel(), _ptr(phr), _ptr(plr),
+                                        _ptr(lg[0]) if want_logits else None, _ptr(lg[1]) if want_logits else None, _stream()))
+    return (phr, plr, lg[0], lg[1]) if want_logits else (phr, plr)
+
+
 def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None):
     """Dense sweep of grid slab [i0, i1): returns (vol_hr, vol_lr) float32 device tensors [(i1-i0), ry, rz]."""
     dev = blob.device

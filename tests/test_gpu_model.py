@@ -143,3 +143,43 @@ def test_eval_driver_end_to_end(tmp_path):
             path = out / "exp" / ("synthetic_0000_%s.obj" % tag)
             lines = open(path).read().splitlines()
             assert lines[0].startswith("v ") and lines[-1].startswith("f ") and len(lines) > 100
+
+
+def test_multiview_facade_and_reconstruction(golden_dir):
+    """num_views = 2 through the drop-in boundary: query_mr / query_sr / get_preds on [V,3,N] samples against the
+    reference's own multi-view outputs, and reconstruction() (eval_func repeats the grid points per view and keeps view
+    0's prediction, lib/mesh_util.py:20-28) against the oracle's field + marching cubes at R = 12."""
+    import oracle
+    from surs_amd import mesh_util, model, options
+    V = 2
+    opt = options.BaseOptions().parse(common.FLAGS + ["--num_views", str(V)])
+    net = model.SuRSNet(opt, "orthogonal").to(device=torch.device("cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    g = np.load(os.path.join(golden_dir, "query_views.npz"))
+    fl = np.stack([common.synth_features(seed=10 + v)[0] for v in range(V)])
+    fh = np.stack([common.synth_features(seed=10 + v)[1] for v in range(V)])
+    net.im_feat_list_lr = [torch.from_numpy(fl).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(fh).to("cuda:0")]
+    pts = weights.synthetic_points(3001, seed=20 + V)
+    samples = torch.from_numpy(np.repeat(pts[None], V, 0).copy())
+    calibs = torch.from_numpy(g["o2_calibs"].copy())
+    net.query_mr(samples, calibs)
+    net.query_sr(samples, calibs)
+    phr, plr = net.get_preds()
+    assert tuple(phr.shape) == (V, 1, 3001)
+    assert np.abs(phr[:, 0].cpu().numpy() - g["o2_pred_hr"]).max() < 1e-4
+    assert np.abs(plr[:, 0].cpu().numpy() - g["o2_pred_lr"]).max() < 1e-4
+    # reconstruction: dense, fp32, view 0 kept
+    R, b_min, b_max = 12, np.array([-0.5] * 3), np.array([0.5] * 3)
+    out = mesh_util.reconstruction(opt, net, torch.device("cuda:0"), calibs, R, b_min, b_max, use_octree=True)
+    gp = oracle.grid_points(R, b_min, b_max)
+    o_hr, o_lr, _, _ = oracle.query_views(common.state_dict(), np.repeat(gp[None], V, 0), g["o2_calibs"], fl, fh)
+    vh, vl, _ = mesh_util.eval_volumes_views(opt, net, calibs, R, b_min, b_max)
+    assert np.abs(vh.cpu().numpy().reshape(-1) - o_hr[0]).max() < 1e-4
+    assert np.abs(vl.cpu().numpy().reshape(-1) - o_lr[0]).max() < 1e-4
+    mat = oracle.coords_matrix(R, b_min, b_max)
+    for field, (v_got, f_got) in ((vh, (out[0], out[1])), (vl, (out[4], out[5]))):
+        v, f, _, _ = oracle.marching_cubes_lewiner(field.cpu().numpy().astype(np.float64), 0.5)
+        assert np.array_equal(f, f_got)
+        assert np.allclose((np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T, v_got, atol=1e-6)

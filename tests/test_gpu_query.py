@@ -134,3 +134,39 @@ def test_channel_split_kernels_match_point_split_kernel(tmp_path):
         assert len(diffs) == 8, lines
         for k, d in diffs.items():
             assert d <= (1e-6 if (k.endswith("_lr") and ver == "3") else 2e-3), (ver, k, d)
+
+
+def test_multiview_and_perspective_vs_reference(setup, golden_dir):
+    """num_views = 2 (orthogonal) and 3 (perspective) through surs_query_points_views against the outputs of the
+    reference's own multi-view path (tests/golden/query_views.npz): 1e-4 on occupancies and logits."""
+    from surs_amd import weights
+    nat, gg = setup["native"], setup["g"]
+    g = np.load(os.path.join(golden_dir, "query_views.npz"))
+    for tag, V, proj, n in (("o2", 2, "orthogonal", 3001), ("p3", 3, "perspective", 2050)):
+        fl = np.stack([common.synth_features(seed=10 + v)[0] for v in range(V)])
+        fh = np.stack([common.synth_features(seed=10 + v)[1] for v in range(V)])
+        Fl = torch.from_numpy(np.ascontiguousarray(fl.transpose(0, 2, 3, 1))).to(gg.dev())
+        Fh = torch.from_numpy(np.ascontiguousarray(fh.transpose(0, 2, 3, 1))).to(gg.dev())
+        pts = weights.synthetic_points(n, seed=20 + V)
+        P = torch.from_numpy(np.ascontiguousarray(np.repeat(pts[None], V, 0))).to(gg.dev())
+        outs = nat.query_points_views(P, g[tag + "_calibs"].reshape(V, -1)[:, :12], proj, ZMUL, ZDIV, Fl, Fh, gg.blob("bf16"),
+                                      setup["ws"], want_logits=True)
+        for name, o in zip(("pred_hr", "pred_lr", "logit_hr", "logit_lr"), outs):
+            o = o.cpu().numpy()
+            assert o.shape == g[tag + "_" + name].shape, (tag, name)
+            assert np.abs(o - g[tag + "_" + name]).max() < 1e-4, (tag, name, np.abs(o - g[tag + "_" + name]).max())
+
+
+def test_multiview_single_view_equals_plain_query(setup):
+    """V = 1, orthogonal through the multi-view entry point: the same kernels in the same order as surs_query_points."""
+    from surs_amd import weights
+    nat, gg = setup["native"], setup["g"]
+    pts = weights.synthetic_points(4099, seed=5)
+    a = _q(setup, pts, common.CALIB)
+    Fl = torch.from_numpy(np.ascontiguousarray(setup["fl"].transpose(1, 2, 0)[None])).to(gg.dev())
+    Fh = torch.from_numpy(np.ascontiguousarray(setup["fh"].transpose(1, 2, 0)[None])).to(gg.dev())
+    P = torch.from_numpy(np.ascontiguousarray(pts[None])).to(gg.dev())
+    b = nat.query_points_views(P, common.CALIB.reshape(1, -1)[:, :12], "orthogonal", ZMUL, ZDIV, Fl, Fh, gg.blob("bf16"),
+                               setup["ws"], want_logits=True)
+    for x, y in zip(a, (b[0][0], b[1][0], b[2], b[3])):
+        assert np.array_equal(x, y.cpu().numpy())

@@ -82,3 +82,30 @@ def test_reconstruction_dense(R, golden_dir):
         vw = (np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T
         assert np.array_equal(f, g["faces_" + tag])
         assert np.array_equal(vw, g["verts_" + tag])
+
+
+def test_multiview_oracle_matches_reference_goldens(golden_dir):
+    """num_views = 2 (orthogonal) and 3 (perspective): the numpy restatement of the view-mean network against the
+    outputs of the reference itself (tests/golden/query_views.npz, tools/gen_golden.py views)."""
+    g = np.load(os.path.join(golden_dir, "query_views.npz"))
+    sd = common.state_dict()
+    for tag, V, proj, n in (("o2", 2, "orthogonal", 3001), ("p3", 3, "perspective", 2050)):
+        fl = np.stack([common.synth_features(seed=10 + v)[0] for v in range(V)])
+        fh = np.stack([common.synth_features(seed=10 + v)[1] for v in range(V)])
+        pts = weights.synthetic_points(n, seed=20 + V)
+        out = oracle.query_views(sd, np.repeat(pts[None], V, 0), g[tag + "_calibs"], fl, fh, proj)
+        for name, o in zip(("pred_hr", "pred_lr", "logit_hr", "logit_lr"), out):
+            assert o.shape == g[tag + "_" + name].shape
+            assert np.abs(o - g[tag + "_" + name]).max() < 1e-5, (tag, name)
+        # the masks differ between the views, the prediction under them does not
+        assert (out[0] == 0).mean(1).std() > 0 or V == 1
+
+
+def test_multiview_oracle_reduces_to_single_view():
+    sd = common.state_dict()
+    fl, fh = common.synth_features()
+    pts = weights.synthetic_points(1500, seed=2)
+    a = oracle.query(sd, pts, common.CALIB, fl, fh, want_logits=True)
+    b = oracle.query_views(sd, pts[None], common.CALIB[None], fl[None], fh[None])
+    for x, y in zip(a, (b[0][0], b[1][0], b[2], b[3])):
+        assert np.abs(x - y).max() < 1e-5

@@ -6,7 +6,7 @@ tests/golden/.  Inputs (weights, images, points, synthetic features) come from
 the counter-based PRNG in surs_amd.prng, so the fixtures hold only the
 reference's OUTPUTS plus the seeds/flags that produced them.
 
-    python tools/gen_golden.py [query] [encoder] [recon] [keys] [octree]
+    python tools/gen_golden.py [query] [views] [encoder] [recon] [keys] [octree]
 """
 import json
 import os
@@ -94,6 +94,49 @@ def gen_query():
     out.update(c_points=pts_c, c_pred_hr=phr, c_pred_lr=plr, c_logit_hr=lhr, c_logit_lr=llr)
     np.savez_compressed(os.path.join(GOLD, "query.npz"), **out)
     print("query done")
+
+
+def gen_views():
+    """num_views = 2 (orthogonal) and num_views = 3 (perspective): the reference's own multi-view path
+    (SurfaceClassifier.py:70-76, train_util.py:40-51, geometry.py:34-48), one subject, per-view features and calibs."""
+    ns = rh.load_reference()
+    out = {}
+    for tag, V, proj, n in (("o2", 2, "orthogonal", 3001), ("p3", 3, "perspective", 2050)):
+        opt_ref = rh.parse_opt(FLAGS + ["--num_views", str(V)])
+        with rh.quiet():
+            net = ns.SuRSNet(opt_ref, proj).to(torch.device("cpu"))
+        net.eval()
+        sd = weights.synthetic_state_dict(options.BaseOptions().parse(FLAGS), seed=0)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+        fl = np.stack([synth_features(seed=10 + v)[0] for v in range(V)])
+        fh = np.stack([synth_features(seed=10 + v)[1] for v in range(V)])
+        net.im_feat_list_lr = [torch.from_numpy(fl.copy())]
+        net.im_feat_list_hr = [torch.from_numpy(fh.copy())]
+        pts = weights.synthetic_points(n, seed=20 + V)
+        if proj == "orthogonal":
+            calibs = np.stack([np.array([[2.0 * np.cos(a), 0, 2.0 * np.sin(a), 0.02 * v], [0, -2.0, 0, -0.01 * v],
+                                         [-2.0 * np.sin(a), 0, 2.0 * np.cos(a), 0], [0, 0, 0, 1]], np.float32)
+                               for v, a in enumerate(np.linspace(0.0, 0.6, V))])
+        else:   # projected z in about [1.5, 2.6]: x, y divided by it
+            calibs = np.stack([np.array([[3.6 * np.cos(a), 0, 3.6 * np.sin(a), 0.03 * v], [0, -3.6, 0.2, 0.0],
+                                         [0.15 * v, 0.1, 0.5, 2.0 + 0.05 * v], [0, 0, 0, 1]], np.float32)
+                               for v, a in enumerate(np.linspace(0.0, 0.5, V))])
+        cap = {}
+        h1 = net.mlp_lr.conv4.register_forward_hook(lambda m, i, o: cap.__setitem__("lr", o.detach().clone()))
+        h2 = net.mlp_hr.conv4.register_forward_hook(lambda m, i, o: cap.__setitem__("hr", o.detach().clone()))
+        samples = ns.train_util.reshape_sample_tensor(torch.from_numpy(pts[None].copy()), V)   # [V,3,N]
+        c = torch.from_numpy(calibs.copy())
+        with torch.no_grad(), rh.quiet():
+            net.query_mr(samples, c)
+            net.query_sr(samples, c)
+            phr, plr = net.get_preds()
+        h1.remove(); h2.remove()
+        assert tuple(phr.shape) == (V, 1, n) and tuple(cap["lr"].shape) == (1, 1, n)
+        out.update({tag + "_calibs": calibs, tag + "_pred_hr": phr[:, 0].numpy(), tag + "_pred_lr": plr[:, 0].numpy(),
+                    tag + "_logit_hr": cap["hr"][0, 0].numpy(), tag + "_logit_lr": cap["lr"][0, 0].numpy()})
+        print("views", tag, "pred_hr range", float(phr.min()), float(phr.max()), "outside frac per view",
+              [float((phr[v] == 0).float().mean()) for v in range(V)])
+    np.savez_compressed(os.path.join(GOLD, "query_views.npz"), **out)
 
 
 def _sub(a, step):
