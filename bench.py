@@ -95,9 +95,8 @@ def main():
         ev[3].record()
         if rank == 0 or not slab:
             # gen_mesh keeps vertices and faces only (lib/train_util.py:72)
-            mh = mesh_util.mesh_from_volume(net, full_hr, mat, want_normals=False)
-            ml = mesh_util.mesh_from_volume(net, full_lr, mat, want_normals=False)
-            last["verts_hr"], last["faces_hr"], last["verts_lr"], last["faces_lr"] = len(mh[0]), len(mh[1]), len(ml[0]), len(ml[1])
+            m = mesh_util.meshes_from_volumes(net, [full_hr, full_lr], mat, want_normals=False)   # as reconstruction() does
+            last["verts_hr"], last["faces_hr"], last["verts_lr"], last["faces_lr"] = len(m[0]), len(m[1]), len(m[4]), len(m[5])
         ev[4].record()
         if timed:
             torch.cuda.synchronize()

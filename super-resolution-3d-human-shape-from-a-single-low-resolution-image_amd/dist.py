@@ -50,4 +50,4 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
         return None
     if not want_mesh:
         return full_hr, full_lr, mat
-    return mesh_util.mesh_from_volume(net, full_hr, mat) + mesh_util.mesh_from_volume(net, full_lr, mat)
+    return mesh_util.meshes_from_volumes(net, [full_hr, full_lr], mat)

@@ -87,6 +87,23 @@ def mesh_from_volume(net, vol, mat, level=0.5, want_normals=True):
     return tuple(ws.to_host([vw, f, n, val]))
 
 
+def meshes_from_volumes(net, vols, mat, level=0.5, want_normals=True):
+    """mesh_from_volume for several fields: the device -> host copy of one mesh runs (on the workspace's copy stream)
+    while the next field's marching cubes executes.  Returns the concatenated tuples, in order."""
+    ws = net._workspace()
+    pending = []
+    for vol in vols:
+        if vol.dtype == torch.float64:
+            vol = native.f64_to_f32(vol)
+        v, f, n, val = native.marching_cubes_lewiner(vol, level, ws, want_normals=want_normals)
+        vw = native.transform_points(v, mat[:3].reshape(-1))
+        pending.append(ws.to_host_async([vw, f, n, val]))
+    out = ()
+    for p in pending:
+        out += tuple(p.result())
+    return out
+
+
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
                    transform=None, want_normals=True):
     """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy)."""
@@ -97,7 +114,7 @@ def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_o
         vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     else:
         vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
-    return mesh_from_volume(net, vh, mat, want_normals=want_normals) + mesh_from_volume(net, vl, mat, want_normals=want_normals)
+    return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
 
 
 def _obj_text(verts, faces):

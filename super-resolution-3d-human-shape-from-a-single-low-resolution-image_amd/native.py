@@ -208,6 +208,46 @@ class Workspace:
         torch.cuda.current_stream().synchronize()
         return [o.numpy() if o is not None else None for o in outs]
 
+    def to_host_async(self, tensors):
+        """Same copies on a side stream, ordered after the work enqueued so far; returns a HostCopy."""
+        return _to_host_async(self, tensors)
+
+
+class HostCopy:
+    """Device -> pinned host copies in flight on the workspace's copy stream (Workspace.to_host_async); result() waits
+    for them and returns the numpy arrays.  Lets the copy of one mesh run under the marching cubes of the next."""
+
+    def __init__(self, hosts, done, keep):
+        self._hosts, self._done, self._keep = hosts, done, keep
+
+    def result(self):
+        self._done.synchronize()
+        self._keep = None
+        return [h.numpy() if h is not None else None for h in self._hosts]
+
+
+def _to_host_async(ws, tensors):
+    cur = torch.cuda.current_stream()
+    if getattr(ws, "_copy_stream", None) is None:
+        ws._copy_stream = torch.cuda.Stream(device=ws.device)
+    side = ws._copy_stream
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    side.wait_event(ready)
+    hosts = []
+    with torch.cuda.stream(side):
+        for t in tensors:
+            if t is None:
+                hosts.append(None)
+                continue
+            t.record_stream(side)   # the caching allocator must not hand the block out again before the copy ran
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            hosts.append(h)
+        done = torch.cuda.Event()
+        done.record(side)
+    return HostCopy(hosts, done, list(tensors))
+
 
 def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_logits=False):
     """points [3,N] f32 device tensor; calib: 12 floats (host); feat_*: Img with ld == c.  Returns pred_hr, pred_lr[, logits]."""
