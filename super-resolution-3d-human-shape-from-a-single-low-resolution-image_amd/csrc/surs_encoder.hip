@@ -25,7 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CK = 16;    // input channels per chunk
 constexpr int PS = 17;    // LDS pixel stride in floats (odd: conflict-free ds_read_b32 across 32 pixels)
-constexpr int NT = 64;    // output channels per workgroup
+// (output channels per workgroup: template parameter NT = 64, or 32 for maps too small to fill 256 CUs otherwise)
 constexpr int TC = 32;    // tile columns (pixels) = one MFMA tile
 
 struct ConvArgs {
@@ -38,8 +38,9 @@ struct ConvArgs {
     const float *res; int res_ld;
 };
 
-template <int KS, int STRIDE, int TR>
+template <int KS, int STRIDE, int TR, int NT>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
+    constexpr int NJ = NT / 32;  // MFMA column tiles (32 output channels each) per wave
     constexpr int PAD = KS / 2;
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;  // patch rows / cols
     constexpr int RPW = TR / 4;                                             // rows per wave
@@ -50,11 +51,11 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     const int ox0 = blockIdx.x * TC, oy0 = blockIdx.y * TR, n0 = blockIdx.z * NT;
     const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD;
 
-    f32x16 acc[RPW][2];
+    f32x16 acc[RPW][NJ];
 #pragma unroll
     for (int r = 0; r < RPW; ++r)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[r][j][q] = 0.0f;
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         }
         // ---- stage the weights: [tap][16][64]
         for (int item = tid; item < KS * KS * CK * (NT / 4); item += 256) {
-            const int co4 = (item & 15) * 4, row = item >> 4;  // row = tap*CK + c
+            const int co4 = (item % (NT / 4)) * 4, row = item / (NT / 4);  // row = tap*CK + c
             const int tap = row / CK, c = row - tap * CK;
             const f32x4 t = *reinterpret_cast<const f32x4 *>(a.wp + ((size_t)tap * a.cin_pad + c0 + c) * a.cout_pad + n0 + co4);
             *reinterpret_cast<f32x4 *>(ws + row * NT + co4) = t;
@@ -104,18 +105,18 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
                 const float *wt = ws + (ky * KS + kx) * CK * NT;
 #pragma unroll
                 for (int s = 0; s < CK / 2; ++s) {
-                    float av[RPW], bv[2];
+                    float av[RPW], bv[NJ];
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
                         const int prow = (wave * RPW + r) * STRIDE + ky, pcol = li * STRIDE + kx;
                         av[r] = xs[(prow * PC + pcol) * PS + 2 * s + kh];
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[j] = wt[(2 * s + kh) * NT + j * 32 + li];
+                    for (int j = 0; j < NJ; ++j) bv[j] = wt[(2 * s + kh) * NT + j * 32 + li];
 #pragma unroll
                     for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[r][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[j], acc[r][j], 0, 0, 0);
                 }
             }
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
         const int oy = oy0 + wave * RPW + r;
         if (oy >= a.ho) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int co = n0 + j * 32 + li;
             if (co >= a.cout) continue;
             const float b = a.bias ? a.bias[co] : 0.f;
@@ -146,19 +147,35 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a) {
     }
 }
 
-template <int KS, int STRIDE, int TR>
-static int launch_conv(const ConvArgs &a, hipStream_t st) {
+template <int KS, int STRIDE, int TR, int NT>
+static int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
     const size_t lds = (size_t)(PR * PC * PS + KS * KS * CK * NT) * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<KS, STRIDE, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<KS, STRIDE, TR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), a.cout_pad / NT);
-    hipLaunchKernelGGL((conv_kernel<KS, STRIDE, TR>), grid, dim3(256), lds, st, a);
+    dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), ceil_div(a.cout_pad, NT));
+    hipLaunchKernelGGL((conv_kernel<KS, STRIDE, TR, NT>), grid, dim3(256), lds, st, a);
     SURS_LAUNCH_CHECK();
     return 0;
+}
+
+// Tile choice: TR rows x 32 columns x NT channels per workgroup.  The big tile (TR_BIG x 64) re-uses a staged patch most;
+// maps that would give fewer workgroups than the chip has CUs (the hourglass's 128^2 / 64^2 levels: 32-128 workgroups)
+// take 4 rows and, if still short, 32 channels.  Every output element is the same sum in the same order in all of them.
+template <int KS, int STRIDE, int TR_BIG>
+static int launch_conv(const ConvArgs &a, hipStream_t st) {
+    const long long cols = ceil_div(a.wo, TC);
+    const long long wg_big = cols * ceil_div(a.ho, TR_BIG) * (a.cout_pad / 64);
+    const long long wg_r4 = cols * ceil_div(a.ho, 4) * (a.cout_pad / 64);
+    if (wg_big >= 256 || TR_BIG == 4) {
+        if (TR_BIG == 4 && wg_big < 256) return launch_conv_cfg<KS, STRIDE, 4, 32>(a, st);
+        return launch_conv_cfg<KS, STRIDE, TR_BIG, 64>(a, st);
+    }
+    if (wg_r4 >= 256) return launch_conv_cfg<KS, STRIDE, 4, 64>(a, st);
+    return launch_conv_cfg<KS, STRIDE, 4, 32>(a, st);
 }
 
 // ---------------------------------------------------------------- GroupNorm coefficients
