@@ -163,18 +163,20 @@ static int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
 }
 
 // Tile choice: TR rows x 32 columns x NT channels per workgroup.  The big tile (TR_BIG x 64) re-uses a staged patch most;
-// maps that would give fewer workgroups than the chip has CUs (the hourglass's 128^2 / 64^2 levels: 32-128 workgroups)
+// maps that would give fewer than two workgroups per CU (the hourglass's 128^2 / 64^2 levels: 32-128 workgroups)
 // take 4 rows and, if still short, 32 channels.  Every output element is the same sum in the same order in all of them.
 template <int KS, int STRIDE, int TR_BIG>
 static int launch_conv(const ConvArgs &a, hipStream_t st) {
     const long long cols = ceil_div(a.wo, TC);
     const long long wg_big = cols * ceil_div(a.ho, TR_BIG) * (a.cout_pad / 64);
     const long long wg_r4 = cols * ceil_div(a.ho, 4) * (a.cout_pad / 64);
-    if (wg_big >= 256 || TR_BIG == 4) {
-        if (TR_BIG == 4 && wg_big < 256) return launch_conv_cfg<KS, STRIDE, 4, 32>(a, st);
+    // two workgroups per CU (LDS: 60 KB each) let one stage while the other multiplies: ask for >= 512 workgroups
+    constexpr long long WANT = 512;
+    if (wg_big >= WANT || TR_BIG == 4) {
+        if (TR_BIG == 4 && wg_big < WANT) return launch_conv_cfg<KS, STRIDE, 4, 32>(a, st);
         return launch_conv_cfg<KS, STRIDE, TR_BIG, 64>(a, st);
     }
-    if (wg_r4 >= 256) return launch_conv_cfg<KS, STRIDE, 4, 64>(a, st);
+    if (wg_r4 >= WANT) return launch_conv_cfg<KS, STRIDE, 4, 64>(a, st);
     return launch_conv_cfg<KS, STRIDE, 4, 32>(a, st);
 }
 
