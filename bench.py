@@ -79,6 +79,7 @@ def main():
 
     stage_ms = {"encoder": 0.0, "query": 0.0, "gather": 0.0, "mesh": 0.0}
     last = {}
+    streamed = [False]
 
     def step(timed):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -87,20 +88,33 @@ def main():
         net.filter_hr(f_hr)
         net.filter_lr(f_lr)
         ev[1].record()
-        i0, i1 = sdist.slab_range(R, rank, world) if slab else (0, R)
-        vh, vl, mat = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max, None, i0, i1)
-        ev[2].record()
-        full_hr = sdist.gather_slabs(vh, R, 0) if slab else vh
-        full_lr = sdist.gather_slabs(vl, R, 0) if slab else vl
-        ev[3].record()
-        if rank == 0 or not slab:
-            # gen_mesh keeps vertices and faces only (lib/train_util.py:72)
-            m = mesh_util.meshes_from_volumes(net, [full_hr, full_lr], mat, want_normals=False)   # as reconstruction() does
+        m = None
+        if not slab:
+            # the product path of reconstruction(): marching cubes and the mesh copies pipelined into the sweep (from the
+            # second reconstruction on: the first one sizes the mesh buffers); ev[2] = end of the sweep's last launch
+            m = mesh_util.reconstruction_streamed(opt, net, calib, R, b_min, b_max, None, want_normals=False, timing=ev[2])
+            streamed[0] = m is not None
+            if m is not None:
+                ev[3].record()
+        if m is None:
+            i0, i1 = sdist.slab_range(R, rank, world) if slab else (0, R)
+            vh, vl, mat = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max, None, i0, i1)
+            ev[2].record()
+            full_hr = sdist.gather_slabs(vh, R, 0) if slab else vh
+            full_lr = sdist.gather_slabs(vl, R, 0) if slab else vl
+            ev[3].record()
+            if rank == 0 or not slab:
+                # gen_mesh keeps vertices and faces only (lib/train_util.py:72)
+                m = mesh_util.meshes_from_volumes(net, [full_hr, full_lr], mat, want_normals=False)
+        if m is not None:
             last["verts_hr"], last["faces_hr"], last["verts_lr"], last["faces_lr"] = len(m[0]), len(m[1]), len(m[4]), len(m[5])
         ev[4].record()
         if timed:
             torch.cuda.synchronize()
-            for k, (a, b) in zip(("encoder", "query", "gather", "mesh"), zip(ev[:-1], ev[1:])):
+            # streamed path: "query" = the sweep with the marching cubes of finished layers between its launches,
+            # "mesh" = what is left after the last launch (last layers, last copies); the slab path also has "gather"
+            names = ("encoder", "query", "mesh", "gather") if streamed[0] else ("encoder", "query", "gather", "mesh")
+            for k, (a, b) in zip(names, zip(ev[:-1], ev[1:])):
                 stage_ms[k] += a.elapsed_time(b)
 
     def barrier():
@@ -147,7 +161,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[%d]: %s 512x512 synthetic image%s, %d^3 grid each, bf16 MFMA classifier cores, "
-                                   "HIP marching cubes x2%s" % (2 if world == 1 else (3 if slab else 4),
+                                   "HIP marching cubes x2 pipelined into the sweep%s" % (2 if world == 1 else (3 if slab else 4),
                                                                  "one" if (slab or world == 1) else str(world),
                                                                  "" if (slab or world == 1) else "s (one subject per GPU, replicas)", R,
                                                                  ", x-slab per rank + RCCL gather" if slab else ""),

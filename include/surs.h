@@ -194,6 +194,20 @@ int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void
                     float *verts, float *normals, float *values, int cap_verts, int32_t *faces, int cap_faces,
                     surs_mc_counts *counts, void *stream);
 
+/* The same extraction, incrementally, for a volume that is produced slab by slab along axis 0 (the dense sweep writes
+ * whole axis-0 planes in order): processes the cell layers [layer_begin, layer_end) - they read the voxel planes
+ * layer_begin .. layer_end, which must be final - and appends their vertices / faces at run->n_verts / run->n_faces
+ * (HOST struct, in/out; initialise to {0, 0, +FLT_MAX, -FLT_MAX}).  Called with contiguous increasing ranges that end
+ * at n0 - 1, the outputs are identical to one surs_mc_lewiner call: Lewiner's sweep has axis 0 outermost, so vertex and
+ * face numbering of a layer depend only on the layers before it.  Normals / values of a vertex keep accumulating from
+ * later layers: read them after the last range and surs_mc_normalize.  The level-range / no-surface checks are the
+ * caller's, from run->vmin / vmax / n_verts after the last range.  Synchronises the stream once per call.
+ * SURS_E_CAPACITY leaves run advanced to the sizes needed so far. */
+int surs_mc_lewiner_range(const float *vol, int n0, int n1, int n2, int layer_begin, int layer_end, double level,
+                          void *workspace, size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
+                          int32_t *faces, int cap_faces, surs_mc_counts *run, void *stream);
+int surs_mc_normalize(float *normals, int n_verts, void *stream);
+
 /* out[i] = mat[:3,:3] @ verts[i] + mat[:3,3] in float64 (mat HOST [12] doubles, rows 0..2 of the 4x4 index->world
  * matrix): the vertex transform of lib/mesh_util.py:42-43,47-48.  verts fp32 [n][3], out fp64 [n][3]. */
 int surs_transform_points(const float *verts, int n, const double *mat, double *out, void *stream);

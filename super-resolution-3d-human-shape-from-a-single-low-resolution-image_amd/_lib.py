@@ -66,6 +66,9 @@ _SIGS = {
     "surs_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "surs_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "surs_transform_points": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
+    "surs_mc_lewiner_range": (C.c_int, [_vp, _i, _i, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i,
+                                        C.POINTER(McCounts), _vp]),
+    "surs_mc_normalize": (C.c_int, [_vp, _i, _vp]),
     "surs_mc_lewiner": (C.c_int, [_vp, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(McCounts), _vp]),
 }
 EXPORTS = sorted(_SIGS)

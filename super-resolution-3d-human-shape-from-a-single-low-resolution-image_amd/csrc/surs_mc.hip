@@ -47,6 +47,8 @@ struct Dims {
     int nz, ny, nx;     // volume dims (axis 0, 1, 2)
     int cz, cy, cx;     // cells per axis
     long long ncells;
+    long long cell_begin, cell_end;   // the flat (sweep-order) cell range this call processes
+    int base_verts, base_faces;      // vertices / triangles produced by earlier ranges
 };
 
 struct Tiling {
@@ -348,12 +350,12 @@ __global__ __launch_bounds__(THREADS) void mc_classify_kernel(const float *__res
                                                               float2 *__restrict__ block_minmax) {
     __shared__ int red[3][4];
     __shared__ float redf[2][4];
-    const long long c0 = (long long)blockIdx.x * CELLS_PER_BLOCK;
+    const long long c0 = d.cell_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
     int nt_sum = 0, nv_sum = 0, na_sum = 0;
     float lo = FLT_MAX, hi = -FLT_MAX;
     for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
         const long long c = c0 + r * THREADS + threadIdx.x;
-        if (c >= d.ncells) break;
+        if (c >= d.cell_end) break;
         int x, y, z;
         cell_xyz(d, c, x, y, z);
         Cell cell;
@@ -464,13 +466,13 @@ __global__ __launch_bounds__(THREADS) void mc_compact_kernel(const unsigned *__r
                                                              ActiveCell *__restrict__ alist) {
     __shared__ int wsum[3][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long c0 = (long long)blockIdx.x * CELLS_PER_BLOCK;
+    const long long c0 = d.cell_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
     const BlockSums bo = block_offsets[blockIdx.x];
-    int run_v = bo.nv, run_t = bo.nt, run_a = bo.na;
+    int run_v = d.base_verts + bo.nv, run_t = d.base_faces + bo.nt, run_a = bo.na;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
         const long long c = c0 + r * THREADS + threadIdx.x;
-        const unsigned code = (c < d.ncells) ? codes[c] : 0u;
+        const unsigned code = (c < d.cell_end) ? codes[c] : 0u;
         const bool active = code != 0u;
         const unsigned long long am = __ballot(active);
         const int nt = code_nt(code), nv = code_nv(code);
@@ -715,20 +717,25 @@ extern "C" size_t surs_mc_workspace_bytes(int n0, int n1, int n2) {
     return mc_ws_layout(n0, n1, n2, off) + align_up((size_t)ncells * sizeof(ActiveCell), 256);
 }
 
-extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void *workspace,
-                               size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
-                               int32_t *faces, int cap_faces, surs_mc_counts *counts, void *stream) {
-    SURS_REQUIRE(vol && workspace && counts, "null argument");
-    SURS_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
-    SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
-    SURS_REQUIRE((long long)n0 * n1 * n2 < (1ll << 31) * 4, "volume too large");
-    hipStream_t st = as_stream(stream);
+// One contiguous range of cells in sweep order, [cell_begin, cell_end): classify, scan, and - unless count_only -
+// compact, vertices, faces; vertex / face ids continue from run->n_verts / run->n_faces, which are advanced (also on
+// SURS_E_CAPACITY, so that the caller knows the sizes), run->vmin / vmax are widened.  Synchronises once (the host
+// needs the counts to size the launches that follow).
+static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_begin, long long cell_end, double level,
+                    void *workspace, size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
+                    int32_t *faces, int cap_faces, bool count_only, surs_mc_counts *run, hipStream_t st) {
     Dims d;
     d.nz = n0; d.ny = n1; d.nx = n2;
     d.cz = n0 - 1; d.cy = n1 - 1; d.cx = n2 - 1;
     d.ncells = (long long)d.cz * d.cy * d.cx;
     SURS_REQUIRE(d.ncells < (1ll << 32), "volume too large");
-    const int nb = mc_nblocks(d.ncells);
+    SURS_REQUIRE(cell_begin >= 0 && cell_begin <= cell_end && cell_end <= d.ncells, "bad cell range");
+    if (cell_begin == cell_end) return 0;
+    d.cell_begin = cell_begin;
+    d.cell_end = cell_end;
+    d.base_verts = run->n_verts;
+    d.base_faces = run->n_faces;
+    const int nb = mc_nblocks(cell_end - cell_begin);
     size_t off[5];
     const size_t fixed = mc_ws_layout(n0, n1, n2, off);
     char *ws = (char *)workspace;
@@ -740,7 +747,6 @@ extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double 
     unsigned *codes = (unsigned *)(ws + off[3]);
     int *evid = (int *)(ws + off[4]);
     ActiveCell *alist = (ActiveCell *)(ws + fixed);
-    const bool count_only = !verts || !faces;
 
     hipLaunchKernelGGL(mc_classify_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, count_only ? (unsigned *)nullptr : codes,
                        bcounts, bminmax);
@@ -750,17 +756,14 @@ extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double 
     struct { float mm[2]; unsigned pad[2]; int tot[3]; } host;
     SURS_HIP_CHECK(hipMemcpyAsync(&host, minmax, sizeof(host), hipMemcpyDeviceToHost, st));
     SURS_HIP_CHECK(hipStreamSynchronize(st));
-    counts->vmin = host.mm[0];
-    counts->vmax = host.mm[1];
-    counts->n_verts = host.tot[0];
-    counts->n_faces = host.tot[1];
+    run->vmin = fminf(run->vmin, host.mm[0]);
+    run->vmax = fmaxf(run->vmax, host.mm[1]);
     const int nactive = host.tot[2];
-    if (level < (double)counts->vmin || level > (double)counts->vmax)
-        return fail(SURS_E_LEVEL_RANGE, "Surface level must be within volume data range.");
-    if (counts->n_verts == 0) return fail(SURS_E_NO_SURFACE, "No surface found at the given iso value.");
-    if (count_only) return 0;
-    if (counts->n_verts > cap_verts || counts->n_faces > cap_faces)
-        return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", counts->n_verts, counts->n_faces);
+    run->n_verts = d.base_verts + host.tot[0];
+    run->n_faces = d.base_faces + host.tot[1];
+    if (count_only || nactive == 0) return 0;
+    if (run->n_verts > cap_verts || run->n_faces > cap_faces)
+        return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
     hipLaunchKernelGGL(mc_compact_kernel, dim3(nb), dim3(THREADS), 0, st, codes, d, boffs, alist);
     SURS_LAUNCH_CHECK();
     const int ab = ceil_div(nactive, THREADS);
@@ -770,11 +773,59 @@ extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double 
     hipLaunchKernelGGL(mc_face_kernel, dim3(ab), dim3(THREADS), 0, st, vol, d, level, alist, nactive, evid, faces, normals, values,
                        cap_verts, cap_faces);
     SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void *workspace,
+                               size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
+                               int32_t *faces, int cap_faces, surs_mc_counts *counts, void *stream) {
+    SURS_REQUIRE(vol && workspace && counts, "null argument");
+    SURS_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
+    SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
+    SURS_REQUIRE((long long)n0 * n1 * n2 < (1ll << 31) * 4, "volume too large");
+    hipStream_t st = as_stream(stream);
+    const long long ncells = (long long)(n0 - 1) * (n1 - 1) * (n2 - 1);
+    const bool count_only = !verts || !faces;
+    counts->n_verts = 0;
+    counts->n_faces = 0;
+    counts->vmin = FLT_MAX;
+    counts->vmax = -FLT_MAX;
+    // the level-range and no-surface errors come before the capacity error, as in one pass over the whole volume
+    surs_mc_counts probe = *counts;
+    int rc = mc_range(vol, n0, n1, n2, 0, ncells, level, workspace, workspace_bytes, verts, normals, values, cap_verts, faces,
+                      cap_faces, count_only, &probe, st);
+    *counts = probe;
+    if (rc && rc != SURS_E_CAPACITY) return rc;
+    if (level < (double)counts->vmin || level > (double)counts->vmax)
+        return fail(SURS_E_LEVEL_RANGE, "Surface level must be within volume data range.");
+    if (counts->n_verts == 0) return fail(SURS_E_NO_SURFACE, "No surface found at the given iso value.");
+    if (rc) return rc;
+    if (count_only) return 0;
     if (normals) {
         hipLaunchKernelGGL(mc_normalize_kernel, dim3(ceil_div(counts->n_verts, 256)), dim3(256), 0, st, normals, counts->n_verts);
         SURS_LAUNCH_CHECK();
     }
     SURS_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int surs_mc_lewiner_range(const float *vol, int n0, int n1, int n2, int layer_begin, int layer_end, double level,
+                                     void *workspace, size_t workspace_bytes, float *verts, float *normals, float *values,
+                                     int cap_verts, int32_t *faces, int cap_faces, surs_mc_counts *run, void *stream) {
+    SURS_REQUIRE(vol && workspace && run && verts && faces, "null argument");
+    SURS_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
+    SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
+    SURS_REQUIRE(layer_begin >= 0 && layer_begin <= layer_end && layer_end <= n0 - 1, "bad layer range");
+    const long long per_layer = (long long)(n1 - 1) * (n2 - 1);
+    return mc_range(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
+                    normals, values, cap_verts, faces, cap_faces, false, run, as_stream(stream));
+}
+
+extern "C" int surs_mc_normalize(float *normals, int n_verts, void *stream) {
+    if (n_verts <= 0) return 0;
+    SURS_REQUIRE(normals, "null argument");
+    hipLaunchKernelGGL(mc_normalize_kernel, dim3(ceil_div(n_verts, 256)), dim3(256), 0, as_stream(stream), normals, n_verts);
+    SURS_LAUNCH_CHECK();
     return 0;
 }
 

@@ -92,16 +92,62 @@ def meshes_from_volumes(net, vols, mat, level=0.5, want_normals=True):
     while the next field's marching cubes executes.  Returns the concatenated tuples, in order."""
     ws = net._workspace()
     pending = []
-    for vol in vols:
+    for k, vol in enumerate(vols):
         if vol.dtype == torch.float64:
             vol = native.f64_to_f32(vol)
-        v, f, n, val = native.marching_cubes_lewiner(vol, level, ws, want_normals=want_normals)
+        v, f, n, val = native.marching_cubes_lewiner(vol, level, ws, want_normals=want_normals, key=k)
         vw = native.transform_points(v, mat[:3].reshape(-1))
         pending.append(ws.to_host_async([vw, f, n, val]))
     out = ()
     for p in pending:
         out += tuple(p.result())
     return out
+
+
+def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, want_normals=True, timing=None,
+                            planes=None):
+    """Dense reconstruction with the mesh extraction pipelined into the sweep: the sweep writes the volumes 16 384 columns
+    (whole axis-0 planes) per launch; after every launch the cell layers that have become final are extracted
+    (surs_mc_lewiner_range: Lewiner's sweep has axis 0 outermost, so their vertex / face numbers are final too) and their
+    vertices and faces travel to the host under the next launches.  Same outputs as eval_volumes + meshes_from_volumes.
+    Returns None if it cannot run (first extraction of this workspace: no buffer sizes yet; multi-view; octree)."""
+    ws = net._workspace()
+    if ws.mc_capacity.get(0) is None or ws.mc_capacity.get(1) is None or net.num_views != 1:
+        return None
+    R = int(resolution)
+    _, mat = create_grid(R, R, R, b_min, b_max, transform=transform)
+    calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
+    fl, fh = net.features()
+    zmul, zdiv = net._zscale()
+    prec = getattr(opt, "precision", "fp32")
+    blob = net._mlp_blob()
+    if prec != "fp32" and native.DTYPES[prec] != net._core_dtype:
+        raise ValueError("network was packed for %s, reconstruction asked for %s: set opt.precision before loading" %
+                         (net.precision, prec))
+    dev = blob.device
+    vh = torch.empty((R, R, R), dtype=torch.float32, device=dev)
+    vl = torch.empty_like(vh)
+    streams = [native.MeshStream(ws, 0, vh, mat[:3].reshape(-1), 0.5, want_normals),
+               native.MeshStream(ws, 1, vl, mat[:3].reshape(-1), 0.5, want_normals)]
+    planes = planes or max(1, 16384 // R)   # default: one launch of the column kernel per slab
+    for i0 in range(0, R, planes):
+        i1 = min(R, i0 + planes)
+        try:
+            native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1])
+        except native._lib.SursError as e:
+            if e.code != -3:
+                raise
+            prec = "fp32"   # general calibration / grid transform: the column kernel does not apply
+            native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1])
+        # queued behind that launch: the layers the PREVIOUS launches completed (a cell layer needs the plane above it)
+        for s in streams:
+            s.advance(i0 - 1)
+    if timing is not None:
+        timing.record()
+    outs = [s.finish() for s in streams]
+    if any(o is None for o in outs):   # a buffer was too small: extract the finished volumes in one piece
+        return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
+    return outs[0] + outs[1]
 
 
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
@@ -113,6 +159,9 @@ def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_o
     elif use_octree:
         vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     else:
+        out = reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform, want_normals)
+        if out is not None:
+            return out
         vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
 

@@ -185,7 +185,8 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.buf = None
-        self.mc_capacity = None   # (verts, faces) of the last extraction: sizes the next one without a counting pass
+        self.mc_capacity = {}     # key -> (verts, faces) of that field's last extraction: sizes the next one without a counting pass
+        self.mesh_ws = {}         # key -> private marching-cubes workspace of an incremental extraction (MeshStream)
 
     def get(self, nbytes):
         if self.buf is None or self.buf.numel() < nbytes:
@@ -307,7 +308,7 @@ def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, d
 
 # ------------------------------------------------------------------ marching cubes
 
-def marching_cubes_lewiner(vol, level, ws, want_normals=True):
+def marching_cubes_lewiner(vol, level, ws, want_normals=True, key=None):
     """vol: float32 device tensor [n0,n1,n2].  Returns device tensors (verts [V,3] f32, faces [F,3] i32, normals, values).
     Raises ValueError / RuntimeError like skimage.measure.marching_cubes_lewiner."""
     if vol.dim() != 3:
@@ -329,21 +330,103 @@ def marching_cubes_lewiner(vol, level, ws, want_normals=True):
                                    _ptr(values), cap_v, _ptr(faces), cap_f, C.byref(counts), _stream())
         return rc, verts, faces, normals, values
 
-    if ws.mc_capacity is None:
+    if ws.mc_capacity.get(key) is None:
         # first extraction with this workspace: counting pass (no outputs) to size the buffers
         check(lib().surs_mc_lewiner(_ptr(vol), n0, n1, n2, float(level), _ptr(w), w.numel(), None, None, None, 0, None, 0,
                                     C.byref(counts), _stream()))
         cap = (counts.n_verts, counts.n_faces)
     else:
-        cap = ws.mc_capacity
+        cap = ws.mc_capacity[key]
     rc, verts, faces, normals, values = run(*cap)
     if rc == -6:   # SURS_E_CAPACITY: the counts are filled in, retry with exact sizes
         rc, verts, faces, normals, values = run(counts.n_verts, counts.n_faces)
     check(rc)
     nv, nf = counts.n_verts, counts.n_faces
-    ws.mc_capacity = (int(nv * 1.125) + 1024, int(nf * 1.125) + 2048)
+    ws.mc_capacity[key] = (int(nv * 1.125) + 1024, int(nf * 1.125) + 2048)
     return (verts[:nv], faces[:nf], normals[:nv] if normals is not None else None,
             values[:nv] if values is not None else None)
+
+
+class MeshStream:
+    """Incremental Lewiner extraction of ONE field while the dense sweep is still writing it (surs_mc_lewiner_range): after
+    every advance() the new vertices are transformed to world space and they and the new faces start their way to
+    pinned host memory on the workspace's copy stream, under the sweep launches that follow.  Buffers are sized from the
+    field's previous extraction (ws.mc_capacity[key]); `overflow` is set if that turns out too small - the caller then
+    extracts the finished volume in one piece."""
+
+    def __init__(self, ws, key, vol, mat, level=0.5, want_normals=True):
+        self.ws, self.key, self.vol, self.level, self.want = ws, key, vol, float(level), want_normals
+        self.n0, self.n1, self.n2 = vol.shape
+        dev = vol.device
+        self.cap_v, self.cap_f = ws.mc_capacity[key]
+        need = lib().surs_mc_workspace_bytes(self.n0, self.n1, self.n2)
+        w = ws.mesh_ws.get(key)
+        if w is None or w.numel() < need:
+            w = ws.mesh_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=dev)   # holds the edge tables between calls
+        self.w = w
+        self.verts = torch.empty((self.cap_v, 3), dtype=torch.float32, device=dev)
+        self.world = torch.empty((self.cap_v, 3), dtype=torch.float64, device=dev)
+        self.faces = torch.empty((self.cap_f, 3), dtype=torch.int32, device=dev)
+        self.normals = torch.empty((self.cap_v, 3), dtype=torch.float32, device=dev) if want_normals else None
+        self.values = torch.empty((self.cap_v,), dtype=torch.float32, device=dev) if want_normals else None
+        self.h_world = torch.empty((self.cap_v, 3), dtype=torch.float64, pin_memory=True)
+        self.h_faces = torch.empty((self.cap_f, 3), dtype=torch.int32, pin_memory=True)
+        self.mat = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+        self.run = _lib.McCounts(0, 0, 3.4028234663852886e38, -3.4028234663852886e38)
+        self.layers = 0          # cell layers (axis 0) extracted so far
+        self.sent_v = self.sent_f = 0
+        self.overflow = False
+        if getattr(ws, "_copy_stream", None) is None:
+            ws._copy_stream = torch.cuda.Stream(device=dev)
+        self.side = ws._copy_stream
+        for t in (self.world, self.faces):
+            t.record_stream(self.side)
+
+    def advance(self, layer_end):
+        """Extract the cell layers [self.layers, layer_end): the voxel planes up to layer_end must be final."""
+        layer_end = min(int(layer_end), self.n0 - 1)
+        if self.overflow or layer_end <= self.layers:
+            return
+        rc = lib().surs_mc_lewiner_range(_ptr(self.vol), self.n0, self.n1, self.n2, self.layers, layer_end, self.level,
+                                         _ptr(self.w), self.w.numel(), _ptr(self.verts), _ptr(self.normals), _ptr(self.values),
+                                         self.cap_v, _ptr(self.faces), self.cap_f, C.byref(self.run), _stream())
+        if rc == -6:
+            self.overflow = True
+            return
+        check(rc)
+        self.layers = layer_end
+        nv, nf = self.run.n_verts, self.run.n_faces
+        if nv > self.sent_v:
+            check(lib().surs_transform_points(self.verts[self.sent_v:].data_ptr(), nv - self.sent_v, self.mat,
+                                              self.world[self.sent_v:].data_ptr(), _stream()))
+        if nv > self.sent_v or nf > self.sent_f:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                if nv > self.sent_v:
+                    self.h_world[self.sent_v:nv].copy_(self.world[self.sent_v:nv], non_blocking=True)
+                if nf > self.sent_f:
+                    self.h_faces[self.sent_f:nf].copy_(self.faces[self.sent_f:nf], non_blocking=True)
+            self.sent_v, self.sent_f = nv, nf
+
+    def finish(self):
+        """Last layers, the checks of marching_cubes_lewiner, normals; -> (verts_world, faces, normals, values) numpy."""
+        self.advance(self.n0 - 1)
+        if self.overflow:
+            return None
+        if self.level < self.run.vmin or self.level > self.run.vmax:
+            raise ValueError("Surface level must be within volume data range.")
+        nv, nf = self.run.n_verts, self.run.n_faces
+        if nv == 0:
+            raise RuntimeError("No surface found at the given iso value.")
+        self.ws.mc_capacity[self.key] = (int(nv * 1.125) + 1024, int(nf * 1.125) + 2048)
+        extra = [None, None]
+        if self.want:
+            check(lib().surs_mc_normalize(_ptr(self.normals), nv, _stream()))
+            extra = self.ws.to_host([self.normals[:nv], self.values[:nv]])
+        self.side.synchronize()
+        return self.h_world[:nv].numpy(), self.h_faces[:nf].numpy(), extra[0], extra[1]
 
 
 def transform_points(verts, mat):

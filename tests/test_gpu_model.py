@@ -183,3 +183,35 @@ def test_multiview_facade_and_reconstruction(golden_dir):
         v, f, _, _ = oracle.marching_cubes_lewiner(field.cpu().numpy().astype(np.float64), 0.5)
         assert np.array_equal(f, f_got)
         assert np.allclose((np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T, v_got, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_streamed_reconstruction_equals_one_piece(precision):
+    """reconstruction_streamed (marching cubes pipelined into the sweep, slab by slab, copies under the next launches)
+    must return exactly what eval_volumes + meshes_from_volumes return: same vertices, faces, normals, values."""
+    from surs_amd import mesh_util, model, options
+    opt = options.BaseOptions().parse(common.FLAGS + ["--precision", precision])
+    net = model.SuRSNet(opt).to(device=torch.device("cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    fl, fh = common.synth_features()
+    net.im_feat_list_lr = [torch.from_numpy(fl[None]).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None]).to("cuda:0")]
+    calib = torch.from_numpy(common.CALIB[None].copy())
+    R, b_min, b_max = 40, np.array([-0.5] * 3), np.array([0.5] * 3)
+    assert mesh_util.reconstruction_streamed(opt, net, calib, R, b_min, b_max) is None      # no buffer sizes yet
+    vh, vl, mat = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max)
+    ref = mesh_util.meshes_from_volumes(net, [vh, vl], mat)
+    for planes in (5, 7, 40):          # ragged last slab, several layers per step, a single slab
+        got = mesh_util.reconstruction_streamed(opt, net, calib, R, b_min, b_max, planes=planes)
+        assert got is not None and len(got) == 8
+        for a, b in zip(got, ref):
+            assert a.dtype == b.dtype and a.shape == b.shape
+            if a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 3 and a is not got[0] and a is not got[4]:
+                assert np.allclose(a, b, atol=1e-5)     # normals: float atomics, order-dependent in the last bits
+            else:
+                assert np.array_equal(a, b)
+    # too-small buffers fall back to the one-piece extraction
+    net._workspace().mc_capacity[0] = (16, 16)
+    got = mesh_util.reconstruction_streamed(opt, net, calib, R, b_min, b_max, planes=5)
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
