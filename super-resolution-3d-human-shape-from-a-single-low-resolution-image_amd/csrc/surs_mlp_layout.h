@@ -35,6 +35,12 @@ constexpr int ZV_W0Z_LR = 0, ZV_W0Z_HR = 1024, ZV_W0P_HR = 2048, ZV_B1_LR = 3072
 //            L3: [ 8 k-steps][ 8 row tiles]  likewise with W3                                          tile pair reused as B)
 constexpr int SLAB_BYTES = 32768, SLABS_L1 = 32, SLABS_L2 = 8, SLABS_L3 = 2, SLABS_PER_MLP = 42, SLABS_TOTAL = 84;
 
+// Layer-1 bias through the matrix pipe (column kernel v3): the accumulators start as A_bias x B_ones instead of 256
+// v_accvgpr_write per lane (8 cycles each).  The bias is split into three 16-bit parts in k-slots 0..2 (hi + mid + lo
+// = the fp32 value exactly in bf16; every partial sum is exact, so the accumulator starts bit-identical to the fp32 bias),
+// B_ones holds 1 / B1FRAG_SCALE there.  f16 has too little range for the low parts: they are scaled by 2^12 (exact).
+constexpr float B1FRAG_SCALE_BF16 = 1.0f, B1FRAG_SCALE_F16 = 4096.0f;
+
 struct MlpBlobHeader {
     uint32_t magic;  // 'SURS'
     uint32_t dtype;  // SURS_BF16 / SURS_F16 of the core slabs
@@ -50,7 +56,8 @@ struct MlpBlobHeader {
     uint32_t core;  // SLABS_TOTAL * SLAB_BYTES: A fragments of the 32x32x16 MFMA shape (column kernels v1-v3)
     uint32_t total_bytes;
     uint32_t core16;  // the same cores as A fragments of the 16x16x32 shape (column kernel v4), same size
-    uint32_t pad[4];
+    uint32_t b1frag;  // layer-1 biases as 32x32x16 A fragments [2 MLPs][16 row tiles][64 lanes][8] (see B1FRAG_SCALE)
+    uint32_t pad[3];
 };
 static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 constexpr uint32_t MLP_MAGIC = 0x53525553u;
@@ -81,6 +88,7 @@ inline MlpBlobHeader blob_layout(uint32_t dtype) {
     h.zvec = take((size_t)ZV_N * 4);
     h.core = take((size_t)SLABS_TOTAL * SLAB_BYTES);
     h.core16 = take((size_t)SLABS_TOTAL * SLAB_BYTES);
+    h.b1frag = take((size_t)2 * (D2 / 32) * 1024);
     h.total_bytes = (uint32_t)off;
     return h;
 }

@@ -25,6 +25,19 @@ static uint16_t f32_to_f16(float f) {
     return u;
 }
 
+static float bf16_to_f32(uint16_t u) {
+    const uint32_t v = (uint32_t)u << 16;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+static float f16_to_f32(uint16_t u) {
+    _Float16 h;
+    memcpy(&h, &u, 2);
+    return (float)h;
+}
+
 static const int kDims[2][6] = {{321, D1, D2, D3, D4, 1}, {322, D1, D2, D3, D4, 1}};
 
 }  // namespace surs
@@ -166,6 +179,24 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
                 p += (size_t)nS * nT * 512;
             }
         }
+    }
+    // ---- layer-1 biases as A fragments (three exact 16-bit parts in k-slots 0..2 of lanes 0..31)
+    {
+        uint16_t *bf = (uint16_t *)(base + h.b1frag);
+        memset(bf, 0, (size_t)2 * (D2 / 32) * 1024);
+        const float scale = dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16;
+        auto cvt = [&](float f) { return dtype == SURS_F16 ? f32_to_f16(f) : f32_to_bf16(f); };
+        auto back = [&](uint16_t u) { return dtype == SURS_F16 ? f16_to_f32(u) : bf16_to_f32(u); };
+        for (int m = 0; m < 2; ++m)
+            for (int T = 0; T < D2 / 32; ++T)
+                for (int r = 0; r < 32; ++r) {
+                    float rest = B[m][1][32 * T + r] * scale;
+                    for (int part = 0; part < 3; ++part) {
+                        const uint16_t u = cvt(rest);
+                        bf[(((size_t)m * (D2 / 32) + T) * 64 + r) * 8 + part] = u;
+                        rest -= back(u);
+                    }
+                }
     }
     return off;
 }

@@ -389,6 +389,8 @@ struct GridArgs {
     const float *zvec;     // [ZV_N]
     const char *core;      // SLABS_TOTAL slabs
     const char *core16;    // the same cores in 16x16x32 fragment order (kernel v4)
+    const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
+    float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
     int ncols, rz;
     double z0, dz;  // world z of voxel k = (float)(dz*k + z0)
@@ -910,6 +912,8 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.zvec = (const float *)(blob + h.zvec);
         a.core = blob + h.core;
         a.core16 = blob + h.core16;
+        a.b1frag = blob + h.b1frag;
+        a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
         a.vol_hr = vol_hr + (size_t)c0 * rz;
         a.vol_lr = vol_lr + (size_t)c0 * rz;
         a.ncols = (int)nc;
