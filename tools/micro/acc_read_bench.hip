@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc,
     __syncthreads();
     unsigned long long t0 = __builtin_readcyclecounter();
     float sum = 0;
-    for (int r = 0; r < reps; ++r) {
+    for (int r = 0; r < (MODE == 3 ? 0 : reps); ++r) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -38,6 +38,39 @@ __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc,
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
+    if (MODE == 3) {
+        // bounce: ds_write_b128 straight from the AGPRs, ds_read_b128 back into VGPRs two fragments later
+        char *bounce = smem + 65536 + threadIdx.x * 16;   // [slot][256 lanes][16 B]
+        t0 = __builtin_readcyclecounter();
+        for (int r = 0; r < reps; ++r) {
+            auto put = [&](int f) {   // fragment f = (i, u): 8 registers = two 16-byte pieces
+                const int i = f >> 1, u = f & 1;
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 lo = {acc[i][8 * u], acc[i][8 * u + 1], acc[i][8 * u + 2], acc[i][8 * u + 3]};
+                f32x4 hi = {acc[i][8 * u + 4], acc[i][8 * u + 5], acc[i][8 * u + 6], acc[i][8 * u + 7]};
+                char *p = bounce + (f & 3) * 8192;
+                const unsigned lds_addr = 65536u + threadIdx.x * 16u + (f & 3) * 8192u;   // dynamic LDS starts at 0 here
+                (void)p;
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:4096" : : "v"(lds_addr), "a"(lo), "a"(hi) : "memory");
+            };
+            put(0); put(1);
+#pragma unroll
+            for (int f = 0; f < 32; ++f) {
+                if (f + 2 < 32) put(f + 2);
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                char *p = bounce + (f & 3) * 8192;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(p), hi = *reinterpret_cast<const f32x4 *>(p + 4096);
+                vec8 b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    b[j] = (__bf16)fmaxf(lo[j], 0.01f * lo[j]);
+                    b[4 + j] = (__bf16)fmaxf(hi[j], 0.01f * hi[j]);
+                }
+                *reinterpret_cast<vec8 *>(smem + (f * 256 + threadIdx.x) * 16) = b;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
     unsigned long long t1 = __builtin_readcyclecounter();
     __syncthreads();
     sum = *reinterpret_cast<float *>(smem + threadIdx.x * 16);
@@ -48,10 +81,11 @@ int main() {
     float *out; unsigned long long *cyc, h;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
     const int reps = 4;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         for (int it = 0; it < 2; ++it) {
             if (mode == 0) { hipFuncSetAttribute((const void *)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 131072, 0, out, cyc, reps); }
             if (mode == 1) { hipFuncSetAttribute((const void *)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 131072, 0, out, cyc, reps); }
+            if (mode == 3) { hipFuncSetAttribute((const void *)k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(k<3>, dim3(256), dim3(256), 131072, 0, out, cyc, reps); }
             if (mode == 2) { hipFuncSetAttribute((const void *)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 131072, 0, out, cyc, reps); }
             hipDeviceSynchronize();
         }
