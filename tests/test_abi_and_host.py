@@ -148,3 +148,78 @@ def test_eval_dataset_contract(tmp_path):
     assert np.abs(it["img_LR"][0].numpy() - want).max() < 1e-6
     assert np.array_equal(it["calib"][0].numpy(), np.diag([2.0, -2.0, 2.0, 1.0]).astype(np.float32))
     assert np.array_equal(it["b_max"], [0.5, 0.5, 0.5])
+
+
+def _pack_blob(dtype_code):
+    import ctypes as C
+    from surs_amd import _lib
+    sd = common.state_dict()
+    keep = []
+
+    def arrs(prefix):
+        ws, bs = (C.c_void_p * 5)(), (C.c_void_p * 5)()
+        for l in range(5):
+            w = np.ascontiguousarray(sd[prefix + "conv%d.weight" % l].reshape(sd[prefix + "conv%d.weight" % l].shape[0], -1))
+            b = np.ascontiguousarray(sd[prefix + "conv%d.bias" % l])
+            keep.extend([w, b])
+            ws[l], bs[l] = w.ctypes.data, b.ctypes.data
+        return ws, bs
+
+    wl, bl = arrs("mlp_lr.")
+    wh, bh = arrs("mlp_hr.")
+    n = _lib.lib().surs_mlp_pack(wl, bl, wh, bh, dtype_code, None)
+    blob = np.zeros(n, np.uint8)
+    assert _lib.lib().surs_mlp_pack(wl, bl, wh, bh, dtype_code, blob.ctypes.data_as(C.c_void_p)) == n
+    return blob, sd
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_mlp_blob_fragment_images_and_bias_split():
+    """surs_mlp_pack is host code: unpack what it wrote.  Header offsets (csrc/surs_mlp_layout.h: 14 uint32 before
+    `core`), the 32x32x16 A-fragment image (v1-v3), the 16x16x32 image with the permuted k order of layers 2/3 (v4), and
+    the three-part bias fragments whose parts must sum to the fp32 bias exactly in bf16."""
+    blob, sd = _pack_blob(1)   # SURS_BF16
+    hdr = blob[:256].view(np.uint32)
+    assert hdr[0] == 0x53525553 and hdr[1] == 1
+    # header: magic, dtype, wt[2][4], bias[2][4], w4[2], reserved[2], wc, bc, zvec, core, total, core16, b1frag
+    core, total, core16, b1frag = int(hdr[25]), int(hdr[26]), int(hdr[27]), int(hdr[28])
+    assert total == blob.size and core < core16 < b1frag < total
+    per_mlp = 42 * 32768
+    w1 = sd["mlp_hr.conv1.weight"].reshape(512, 1024)
+    w2 = sd["mlp_hr.conv2.weight"].reshape(256, -1)
+    rnd = lambda a: _bf16_to_f32(((a.view(np.uint32) + 0x7fff + ((a.view(np.uint32) >> 16) & 1)) >> 16).astype(np.uint16))
+    # --- 32x32x16 image, hr MLP: layer 1 fragment (k-step s, row tile T): lane (r, h) element j = W1[32T + r][16s + 8h + j]
+    img = blob[core + per_mlp: core + 2 * per_mlp].view(np.uint16)
+    s_, T = 5, 3
+    frag = _bf16_to_f32(img[(s_ * 16 + T) * 512:(s_ * 16 + T + 1) * 512]).reshape(64, 8)
+    lane = np.arange(64)
+    want = w1[32 * T + (lane & 31)][:, None, ...] if False else np.stack([w1[32 * T + (l & 31), 16 * s_ + 8 * (l >> 5): 16 * s_ + 8 * (l >> 5) + 8] for l in lane])
+    assert np.array_equal(frag, rnd(np.ascontiguousarray(want)))
+    # layer 2 (after 64*16 fragments): element j = W2[32T + r][16s + 8(j>>2) + 4h + (j&3)]
+    s_, T = 7, 2
+    base = (64 * 16 + s_ * 8 + T) * 512
+    frag = _bf16_to_f32(img[base:base + 512]).reshape(64, 8)
+    want = np.stack([[w2[32 * T + (l & 31), 16 * s_ + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3)] for j in range(8)] for l in lane]).astype(np.float32)
+    assert np.array_equal(frag, rnd(want))
+    # --- 16x16x32 image: layer 1 fragment (s, T of 32): lane (n, q) element j = W1[16T + n][32s + 8q + j];
+    #     layer 2 (after 32*32 fragments, 16 row tiles): W2[16T + n][32s + 16(j>>2) + 4q + (j&3)]
+    img16 = blob[core16 + per_mlp: core16 + 2 * per_mlp].view(np.uint16)
+    s_, T = 9, 17
+    frag = _bf16_to_f32(img16[(s_ * 32 + T) * 512:(s_ * 32 + T + 1) * 512]).reshape(64, 8)
+    want = np.stack([w1[16 * T + (l & 15), 32 * s_ + 8 * (l >> 4): 32 * s_ + 8 * (l >> 4) + 8] for l in lane])
+    assert np.array_equal(frag, rnd(np.ascontiguousarray(want)))
+    s_, T = 4, 11
+    base = (32 * 32 + s_ * 16 + T) * 512
+    frag = _bf16_to_f32(img16[base:base + 512]).reshape(64, 8)
+    want = np.stack([[w2[16 * T + (l & 15), 32 * s_ + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3)] for j in range(8)] for l in lane]).astype(np.float32)
+    assert np.array_equal(frag, rnd(want))
+    # --- bias fragments [2][16][64][8]: lanes 0..31, elements 0..2 = three parts that sum to the bias exactly
+    bf = _bf16_to_f32(blob[b1frag:b1frag + 2 * 16 * 1024].view(np.uint16)).reshape(2, 16, 64, 8)
+    for m, key in enumerate(("mlp_lr.conv1.bias", "mlp_hr.conv1.bias")):
+        b1 = sd[key]
+        parts = bf[m, :, :32, :3].reshape(512, 3)
+        assert np.array_equal((parts[:, 0] + parts[:, 1]) + parts[:, 2], b1)
+        assert np.all(bf[m, :, 32:, :] == 0) and np.all(bf[m, :, :, 3:] == 0)
