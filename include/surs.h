@@ -70,6 +70,14 @@ int surs_device_info(int *cu_count, char *arch_out);
 int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld, const float *wpacked, const float *bias, float *y,
                      int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
                      float slope, const float *residual, int res_ld, void *stream);
+/* The same 3x3 / stride-1 convolution on the bf16 matrix pipe with fp32 accuracy: every operand is split into three bf16
+ * parts (exactly) and the six significant partial products are accumulated in fp32 - 2.7x the fp32 MFMA rate.
+ * wsplit: surs_conv_pack_weights_x3 layout (device). */
+int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias, float *y,
+                        int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
+                        float slope, const float *residual, int res_ld, void *stream);
+/* HOST helper for it: [3 parts][k*k][cin_pad/16][cout_pad][16] uint16 (bf16).  Returns bytes (query with out == NULL). */
+size_t surs_conv_pack_weights_x3(const float *w, int cout, int cin, int ksize, void *out);
 /* HOST helper: repack a PyTorch [cout][cin][k][k] weight into the kernel layout [k*k][cin_pad][cout_pad] (floats).
  * Returns the number of floats written (query with out == NULL). */
 size_t surs_conv_pack_weights(const float *w, int cout, int cin, int ksize, float *out);

@@ -15,6 +15,9 @@
 // after it) and the K*K x 16 x 64 weight slice in LDS.  Pixel stride 17 floats keeps the A reads conflict-free.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "surs_common.h"
 
 namespace surs {
@@ -178,6 +181,282 @@ static int launch_conv(const ConvArgs &a, hipStream_t st) {
     }
     if (wg_r4 >= WANT) return launch_conv_cfg<KS, STRIDE, 4, 64>(a, st);
     return launch_conv_cfg<KS, STRIDE, 4, 32>(a, st);
+}
+
+// ---------------------------------------------------------------- 3x3 convolution on the bf16 matrix pipe, fp32-exact
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate.  Every fp32 operand is instead split into three
+// bf16 parts, x = x1 + x2 + x3 exactly (8 + 8 + 8 significant bits), and the product is accumulated from the six
+// partial products that matter, x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x2 w2 + x3 w1): each is exact in the fp32
+// accumulator's input, what is dropped is below 2^-24 of the product - fp32 accuracy (measured 3e-7 of the output range
+// on a 2304-term convolution against 5e-7 for the fp32 MFMA) at 6 bf16 MFMAs of 8 passes for 16 channels against
+// 8 fp32 MFMAs of 16 passes: 2.7x.  Weights are split by the packer (surs_conv_pack_weights_x3), activations while they
+// are staged (after the fused GroupNorm-apply + ReLU).  Tile: TR rows x 32 columns x NT3 output channels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+constexpr int XS = 24;    // LDS row pitch in halfwords (48 B): conflict-free ds_read_b128 across consecutive pixels / channels
+
+__device__ __forceinline__ void split3(float x, unsigned short &a, unsigned short &b, unsigned short &c) {
+    const __bf16 ha = (__bf16)x;
+    const float r1 = x - (float)ha;
+    const __bf16 hb = (__bf16)r1;
+    const float r2 = r1 - (float)hb;
+    const __bf16 hc = (__bf16)r2;
+    a = __builtin_bit_cast(unsigned short, ha);
+    b = __builtin_bit_cast(unsigned short, hb);
+    c = __builtin_bit_cast(unsigned short, hc);
+}
+
+#ifdef SURS_CONV_TRACE
+__device__ unsigned long long g_conv_trace[8];
+#define CSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); g_conv_trace[i] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+template <int KS, int STRIDE, int TR, int NT3>
+__global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
+    constexpr int NJ = NT3 / 32;   // 32-channel MFMA column tiles per wave
+    constexpr int PAD = KS / 2, T = KS * KS;
+    constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
+    constexpr int RPW = TR / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+    unsigned short *xs = lds16;                         // [3][PR*PC][XS]
+    unsigned short *wsm = lds16 + 3 * PR * PC * XS;     // [3][T][NT3][XS]
+    float *gn = reinterpret_cast<float *>(wsm + 3 * T * NT3 * XS);   // [2][cin_pad]: GroupNorm scale, shift (if any)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ox0 = blockIdx.x * TC, oy0 = blockIdx.y * TR, n0 = blockIdx.z * NT3;
+    const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD;
+    const int nch = a.cin_pad / CK;
+    const size_t per_part = (size_t)T * nch * a.cout_pad * 16;
+
+    // A dependent MFMA (same accumulator as the one before it) waits for that one's result, ~2x its issue interval:
+    // consecutive MFMAs always go to different accumulators.  The big tile has 4 (rows x channel tiles); the small tile
+    // has one, so its six partial products are spread over three accumulators that are added at the end.
+    constexpr int NA = (RPW * NJ >= 4) ? 1 : 3;
+    f32x16 acc[NA][RPW][NJ];
+#pragma unroll
+    for (int s_ = 0; s_ < NA; ++s_)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[s_][r][j][q] = 0.0f;
+
+    const bool vec_ok = (a.x_ld % 4 == 0) && ((reinterpret_cast<size_t>(a.x) & 15) == 0);
+    if (a.in_scale) {   // once per workgroup: read per element from global memory they stall every chunk's staging
+        for (int c = tid; c < a.cin_pad; c += 256) {
+            gn[c] = c < a.cin ? a.in_scale[c] : 0.f;
+            gn[a.cin_pad + c] = c < a.cin ? a.in_shift[c] : 0.f;
+        }
+        __syncthreads();
+    }
+    // A chunk's MFMAs take ~1.7 k cycles, less than a global-memory round trip: the next chunk's patch and weight
+    // slices are fetched into registers while the current chunk multiplies, and split / stored to LDS afterwards.
+    constexpr int NPI = (PR * PC * (CK / 4) + 255) / 256;   // patch items per thread (4 channels of one pixel each)
+    constexpr int NWI = (3 * T * NT3 * 2 + 255) / 256;      // weight items per thread (16 bytes each)
+    f32x4 pre_x[NPI], pre_w[NWI];
+    // per-thread item descriptors, computed once (the index arithmetic would otherwise cost more than the MFMAs)
+    long long px_src[NPI];   // element offset of the item's 4 channels in x for chunk 0, or -1: outside the image / no item
+    int px_dst[NPI];         // halfword offset in one part's LDS image, or -1: no item
+    long long w_src[NWI];    // halfword offset in wsplit for chunk 0, or -1
+    int w_dst[NWI];
+#pragma unroll
+    for (int k = 0; k < NPI; ++k) {
+        const int item = tid + k * 256;
+        px_src[k] = -1;
+        px_dst[k] = -1;
+        if (item < PR * PC * (CK / 4)) {
+            const int pix = item >> 2, cq = (item & 3) * 4;
+            const int pr = pix / PC, pc = pix - pr * PC;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            px_dst[k] = pix * XS + cq;
+            if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) px_src[k] = ((long long)iy * a.w + ix) * a.x_ld + cq;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NWI; ++k) {
+        const int item = tid + k * 256;
+        w_src[k] = -1;
+        w_dst[k] = -1;
+        if (item < 3 * T * NT3 * 2) {
+            const int half = item & 1, row = item >> 1;            // row = (part*T + tap)*NT3 + n
+            const int n = row % NT3, pt = row / NT3;               // pt = part*T + tap
+            const int part = pt / T, tap = pt - part * T;
+            w_src[k] = (long long)(part * per_part) + ((long long)tap * nch * a.cout_pad + n0 + n) * 16 + half * 8;
+            w_dst[k] = row * XS + half * 8;
+        }
+    }
+    const long long w_step = (long long)a.cout_pad * 16;   // halfwords per chunk in wsplit
+    auto fetch = [&](int ch) {
+        const int c0 = ch * CK;
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (px_src[k] >= 0) {
+                const float *src = a.x + px_src[k] + c0;
+                const int cq = (tid & 3) * 4;    // the same for every item of a thread (256 is a multiple of 4)
+                if (vec_ok && c0 + cq + 4 <= a.cin) {
+                    v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + cq + q < a.cin) v[q] = src[q];
+                }
+            }
+            pre_x[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w_src[k] >= 0) v = *reinterpret_cast<const f32x4 *>(wsplit + w_src[k] + ch * w_step);
+            pre_w[k] = v;
+        }
+    };
+    auto stage = [&](int ch) {
+        const int c0 = ch * CK;
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            if (px_dst[k] < 0) continue;
+            const int cq = (tid & 3) * 4;
+            float v[4] = {pre_x[k][0], pre_x[k][1], pre_x[k][2], pre_x[k][3]};
+            if (a.in_scale && px_src[k] >= 0) {   // zero padding stays zero: it is applied after the norm
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + cq + q < a.cin) {
+                        const float t = v[q] * gn[c0 + cq + q] + gn[a.cin_pad + c0 + cq + q];
+                        v[q] = t > 0.f ? t : 0.f;
+                    }
+            }
+            u16x4 p0, p1, p2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned short x0, x1, x2;
+                split3(v[q], x0, x1, x2);
+                p0[q] = x0; p1[q] = x1; p2[q] = x2;
+            }
+            *reinterpret_cast<u16x4 *>(xs + 0 * PR * PC * XS + px_dst[k]) = p0;
+            *reinterpret_cast<u16x4 *>(xs + 1 * PR * PC * XS + px_dst[k]) = p1;
+            *reinterpret_cast<u16x4 *>(xs + 2 * PR * PC * XS + px_dst[k]) = p2;
+        }
+#pragma unroll
+        for (int k = 0; k < NWI; ++k) {
+            if (w_dst[k] < 0) continue;
+            *reinterpret_cast<f32x4 *>(wsm + w_dst[k]) = pre_w[k];
+        }
+    };
+    fetch(0);
+#ifdef SURS_CONV_TRACE
+    unsigned long long tprev = __builtin_readcyclecounter();
+    if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) for (int i = 0; i < 8; ++i) g_conv_trace[i] = 0;
+#endif
+    for (int ch = 0; ch < nch; ++ch) {
+        CSTAMP(4);
+        stage(ch);
+        CSTAMP(0);
+        __syncthreads();
+        CSTAMP(1);
+        if (ch + 1 < nch) fetch(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);   // the loads are issued HERE, not sunk to their use behind the MFMAs
+        CSTAMP(2);
+        const int kh = lane >> 5, li = lane & 31;
+        // operands of tap t + 1 are read from LDS while tap t multiplies (register double buffer): without it every tap
+        // starts with an exposed LDS round trip
+        bf16x8 bw[2][NJ][3], ax[2][RPW][3];
+        auto ldtap = [&](int tap, int buf) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bw[buf][j][p] = *reinterpret_cast<const bf16x8 *>(wsm + ((size_t)(p * T + tap) * NT3 + j * 32 + li) * XS + 8 * kh);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int prow = (wave * RPW + r) * STRIDE + ky, pcol = li * STRIDE + kx;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    ax[buf][r][p] = *reinterpret_cast<const bf16x8 *>(xs + ((size_t)p * PR * PC + prow * PC + pcol) * XS + 8 * kh);
+            }
+        };
+        ldtap(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            const int cur = tap & 1;
+            if (tap + 1 < T) ldtap(tap + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);   // the next tap's reads are in flight before this tap's MFMAs start
+            // the six partial products, smallest first: (x part, w part)
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[t % NA][r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[cur][r][PA[t]], bw[cur][j][PB[t]], acc[t % NA][r][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        CSTAMP(3);
+        __syncthreads();
+    }
+    // ---- epilogue: register q of a tile is pixel column (q&3) + 8*(q>>2) + 4*(lane>>5), lane&31 is the channel
+    const int kh = lane >> 5, li = lane & 31;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int oy = oy0 + wave * RPW + r;
+        if (oy >= a.ho) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int co = n0 + j * 32 + li;
+            if (co >= a.cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                if (ox >= a.wo) continue;
+                float t = acc[0][r][j][q];
+                if (NA == 3) t = (acc[0][r][j][q] + acc[1][r][j][q]) + acc[2][r][j][q];
+                t += b;
+                if (a.act == 1) t = t > 0.f ? t : a.slope * t;
+                const size_t pix = (size_t)oy * a.wo + ox;
+                if (a.res) t += a.res[pix * a.res_ld + co];
+                a.y[pix * a.y_ld + co] = t;
+            }
+        }
+    }
+}
+
+template <int KS, int STRIDE, int TR, int NT3>
+static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
+    constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
+    SURS_REQUIRE(a.cin_pad <= 1024, "split-bf16 convolution: at most 1024 input channels");
+    const size_t lds = (size_t)(3 * PR * PC * XS + 3 * KS * KS * NT3 * XS) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), ceil_div(a.cout_pad, NT3));
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3>), grid, dim3(256), lds, st, a, wsplit);
+    SURS_LAUNCH_CHECK();
+#ifdef SURS_CONV_TRACE
+    if (getenv("SURS_CONV_TRACE") && a.cin == 256 && a.cout == 128) {
+        unsigned long long t[8];
+        SURS_HIP_CHECK(hipStreamSynchronize(st));
+        SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_conv_trace), sizeof(t)));
+        fprintf(stderr, "conv_x3 <%d,%d> %dx%d cin %d cout %d: per workgroup cycles: stage %llu, barrier %llu, fetch issue %llu, mfma %llu, barrier2 %llu\n",
+                TR, NT3, a.h, a.w, a.cin, a.cout, t[0], t[1], t[2], t[3], t[4]);
+    }
+#endif
+    return 0;
+}
+
+// 8 rows x 64 channels (140 KB of LDS, one workgroup per CU, 216 MFMAs per wave and chunk: long enough to cover the
+// prefetch, and the input is re-read least) where that still gives every CU two workgroups' worth of tiles; 4 rows x 32
+// channels (79 KB, two workgroups per CU) for the small maps.
+template <int KS, int STRIDE>
+static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
+    const long long wg_big = (long long)ceil_div(a.wo, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64);
+    if (wg_big >= 512) return launch_conv_x3_cfg<KS, STRIDE, 8, 64>(a, wsplit, st);
+    return launch_conv_x3_cfg<KS, STRIDE, 4, 32>(a, wsplit, st);
 }
 
 // ---------------------------------------------------------------- GroupNorm coefficients
@@ -374,6 +653,25 @@ extern "C" int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld,
     if (ksize == 1) return launch_conv<1, 1, 8>(a, st);
     if (stride == 1) return launch_conv<3, 1, 8>(a, st);
     return launch_conv<3, 2, 4>(a, st);
+}
+
+extern "C" int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                                   float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
+                                   const float *in_shift, int act, float slope, const float *residual, int res_ld,
+                                   void *stream) {
+    SURS_REQUIRE(x && wsplit && y, "null argument");
+    SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
+    SURS_REQUIRE(ksize == 3 && stride == 1, "the split-bf16 kernel is built for 3x3, stride 1");
+    SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
+    ConvArgs a;
+    a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
+    a.wp = nullptr; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
+    a.bias = bias;
+    a.y = y; a.ho = h; a.wo = w; a.cout = cout; a.y_ld = y_ld;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    a.act = act; a.slope = slope;
+    a.res = residual; a.res_ld = res_ld;
+    return launch_conv_x3<3, 1>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
 extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,

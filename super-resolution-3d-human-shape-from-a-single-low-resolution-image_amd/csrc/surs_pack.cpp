@@ -213,3 +213,27 @@ extern "C" size_t surs_conv_pack_weights(const float *w, int cout, int cin, int 
                 out[((size_t)t * cin_pad + c) * cout_pad + o] = w[((size_t)o * cin + c) * taps + t];
     return n;
 }
+
+// Split-bf16 layout of a conv weight for surs_conv2d_nhwc_x3: every weight as three bf16 parts (hi + mid + lo = the fp32
+// value exactly), [3 parts][k*k taps][cin_pad / 16 chunks][cout_pad][16 channels of the chunk] uint16 - the order the
+// kernel's B fragments are read in (a lane reads 8 consecutive channels of one output channel).
+extern "C" size_t surs_conv_pack_weights_x3(const float *w, int cout, int cin, int ksize, void *out) {
+    const int cin_pad = (cin + 15) / 16 * 16, cout_pad = (cout + 63) / 64 * 64, taps = ksize * ksize, nch = cin_pad / 16;
+    const size_t per_part = (size_t)taps * nch * cout_pad * 16;
+    const size_t bytes = 3 * per_part * sizeof(uint16_t);
+    if (!out) return bytes;
+    uint16_t *o = (uint16_t *)out;
+    memset(o, 0, bytes);
+    for (int oc = 0; oc < cout; ++oc)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < taps; ++t) {
+                float rest = w[((size_t)oc * cin + c) * taps + t];
+                const size_t idx = (((size_t)t * nch + c / 16) * cout_pad + oc) * 16 + (c & 15);
+                for (int part = 0; part < 3; ++part) {
+                    const uint16_t u = f32_to_bf16(rest);
+                    o[part * per_part + idx] = u;
+                    rest -= bf16_to_f32(u);
+                }
+            }
+    return bytes;
+}

@@ -5,6 +5,7 @@ device pointers to libsurs_hip.so.  Tensors must live on the current CUDA (HIP)
 device.  Nothing here computes on the CPU and nothing falls back.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -87,6 +88,12 @@ class ConvWeights:
                                      packed.ctypes.data_as(C.c_void_p))
         self.w = torch.from_numpy(packed).to(device)
         self.b = torch.from_numpy(np.ascontiguousarray(b, np.float32)).to(device) if b is not None else None
+        self.w3 = None    # split-bf16 image for the 3x3 / stride-1 kernel (surs_conv2d_nhwc_x3)
+        if self.k == 3 and os.environ.get("SURS_CONV_X3", "1") != "0":
+            nb = lib().surs_conv_pack_weights_x3(None, self.cout, self.cin, self.k, None)
+            buf = np.empty(nb, np.uint8)
+            lib().surs_conv_pack_weights_x3(w.ctypes.data_as(C.c_void_p), self.cout, self.cin, self.k, buf.ctypes.data_as(C.c_void_p))
+            self.w3 = torch.from_numpy(buf).to(device)
 
 
 def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope=0.0, residual=None):
@@ -96,10 +103,11 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
     if out is None:
         out = Img(ho, wo, cw.cout, device=x.buf.device)
     assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
-    check(lib().surs_conv2d_nhwc(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(cw.w), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
-                                 stride, _ptr(in_scale), _ptr(in_shift), act, slope,
-                                 residual.ptr() if residual is not None else None,
-                                 residual.ld if residual is not None else 0, _stream()))
+    fn, wt = (lib().surs_conv2d_nhwc_x3, cw.w3) if (cw.w3 is not None and stride == 1) else (lib().surs_conv2d_nhwc, cw.w)
+    check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
+             stride, _ptr(in_scale), _ptr(in_shift), act, slope,
+             residual.ptr() if residual is not None else None,
+             residual.ld if residual is not None else 0, _stream()))
     return out
 
 
