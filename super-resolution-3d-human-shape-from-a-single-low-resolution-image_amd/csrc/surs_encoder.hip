@@ -242,7 +242,6 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[s_][r][j][q] = 0.0f;
 
-    const bool vec_ok = (a.x_ld % 4 == 0) && ((reinterpret_cast<size_t>(a.x) & 15) == 0);
     if (a.in_scale) {   // once per workgroup: read per element from global memory they stall every chunk's staging
         for (int c = tid; c < a.cin_pad; c += 256) {
             gn[c] = c < a.cin ? a.in_scale[c] : 0.f;
@@ -254,84 +253,74 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     // slices are fetched into registers while the current chunk multiplies, and split / stored to LDS afterwards.
     constexpr int NPI = (PR * PC * (CK / 4) + 255) / 256;   // patch items per thread (4 channels of one pixel each)
     constexpr int NWI = (3 * T * NT3 * 2 + 255) / 256;      // weight items per thread (16 bytes each)
-    f32x4 pre_x[NPI], pre_w[NWI];
-    // per-thread item descriptors, computed once (the index arithmetic would otherwise cost more than the MFMAs)
-    long long px_src[NPI];   // element offset of the item's 4 channels in x for chunk 0, or -1: outside the image / no item
-    int px_dst[NPI];         // halfword offset in one part's LDS image, or -1: no item
-    long long w_src[NWI];    // halfword offset in wsplit for chunk 0, or -1
-    int w_dst[NWI];
+    // chunks in flight: the small tile's MFMAs (1.7 k cycles) are shorter than a memory round trip -> two; the big tile's
+    // (7 k cycles) cover it, and a second buffer (80 more registers) would spill
+    constexpr int PD = (RPW * NJ >= 4) ? 1 : 2;
+    f32x4 pre_x[PD][NPI], pre_w[PD][NWI];
+    // per-thread item descriptors, computed once (the index arithmetic would otherwise cost more than the MFMAs).
+    // Loads are unconditional - items outside the image or beyond the item count read element 0 and are masked /
+    // dropped afterwards - so that the compiler emits them back to back instead of one branch per item.
+    unsigned px_src[NPI];    // element offset of the item's 4 channels in x for chunk 0
+    bool px_ok[NPI];         // inside the image
+    int px_dst[NPI];         // halfword offset in one part's LDS image, or -1: no such item
+    unsigned w_src[NWI];     // halfword offset in wsplit for chunk 0
+    int w_dst[NWI];          // halfword offset in the LDS weight image, or -1
+    const int cq = (tid & 3) * 4;   // the same for every patch item of a thread (256 is a multiple of 4)
 #pragma unroll
     for (int k = 0; k < NPI; ++k) {
         const int item = tid + k * 256;
-        px_src[k] = -1;
+        px_src[k] = 0;
+        px_ok[k] = false;
         px_dst[k] = -1;
         if (item < PR * PC * (CK / 4)) {
-            const int pix = item >> 2, cq = (item & 3) * 4;
+            const int pix = item >> 2;
             const int pr = pix / PC, pc = pix - pr * PC;
             const int iy = iy0 + pr, ix = ix0 + pc;
             px_dst[k] = pix * XS + cq;
-            if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) px_src[k] = ((long long)iy * a.w + ix) * a.x_ld + cq;
+            if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w) {
+                px_ok[k] = true;
+                px_src[k] = (unsigned)((iy * a.w + ix) * a.x_ld + cq);
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < NWI; ++k) {
         const int item = tid + k * 256;
-        w_src[k] = -1;
+        w_src[k] = 0;
         w_dst[k] = -1;
         if (item < 3 * T * NT3 * 2) {
             const int half = item & 1, row = item >> 1;            // row = (part*T + tap)*NT3 + n
             const int n = row % NT3, pt = row / NT3;               // pt = part*T + tap
             const int part = pt / T, tap = pt - part * T;
-            w_src[k] = (long long)(part * per_part) + ((long long)tap * nch * a.cout_pad + n0 + n) * 16 + half * 8;
+            w_src[k] = (unsigned)(part * per_part + ((size_t)tap * nch * a.cout_pad + n0 + n) * 16 + half * 8);
             w_dst[k] = row * XS + half * 8;
         }
     }
-    const long long w_step = (long long)a.cout_pad * 16;   // halfwords per chunk in wsplit
-    auto fetch = [&](int ch) {
-        const int c0 = ch * CK;
+    const unsigned w_step = (unsigned)a.cout_pad * 16;   // halfwords per chunk in wsplit
+    auto fetch = [&](int ch, int pb) {
 #pragma unroll
-        for (int k = 0; k < NPI; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (px_src[k] >= 0) {
-                const float *src = a.x + px_src[k] + c0;
-                const int cq = (tid & 3) * 4;    // the same for every item of a thread (256 is a multiple of 4)
-                if (vec_ok && c0 + cq + 4 <= a.cin) {
-                    v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
+        for (int k = 0; k < NPI; ++k) pre_x[pb][k] = *reinterpret_cast<const f32x4 *>(a.x + (px_src[k] + (unsigned)(ch * CK)));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c0 + cq + q < a.cin) v[q] = src[q];
-                }
-            }
-            pre_x[k] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NWI; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (w_src[k] >= 0) v = *reinterpret_cast<const f32x4 *>(wsplit + w_src[k] + ch * w_step);
-            pre_w[k] = v;
-        }
+        for (int k = 0; k < NWI; ++k) pre_w[pb][k] = *reinterpret_cast<const f32x4 *>(wsplit + (w_src[k] + (unsigned)ch * w_step));
     };
-    auto stage = [&](int ch) {
+    auto stage = [&](int ch, int pb) {
         const int c0 = ch * CK;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.in_scale) {
+            sc = *reinterpret_cast<const f32x4 *>(gn + c0 + cq);
+            sh = *reinterpret_cast<const f32x4 *>(gn + a.cin_pad + c0 + cq);
+        }
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
             if (px_dst[k] < 0) continue;
-            const int cq = (tid & 3) * 4;
-            float v[4] = {pre_x[k][0], pre_x[k][1], pre_x[k][2], pre_x[k][3]};
-            if (a.in_scale && px_src[k] >= 0) {   // zero padding stays zero: it is applied after the norm
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (c0 + cq + q < a.cin) {
-                        const float t = v[q] * gn[c0 + cq + q] + gn[a.cin_pad + c0 + cq + q];
-                        v[q] = t > 0.f ? t : 0.f;
-                    }
-            }
             u16x4 p0, p1, p2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                float v = pre_x[pb][k][q];
+                if (a.in_scale) v = fmaxf(v * sc[q] + sh[q], 0.f);
+                v = px_ok[k] ? v : 0.f;   // zero padding is applied after the norm
                 unsigned short x0, x1, x2;
-                split3(v[q], x0, x1, x2);
+                split3(v, x0, x1, x2);
                 p0[q] = x0; p1[q] = x1; p2[q] = x2;
             }
             *reinterpret_cast<u16x4 *>(xs + 0 * PR * PC * XS + px_dst[k]) = p0;
@@ -341,21 +330,22 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
             if (w_dst[k] < 0) continue;
-            *reinterpret_cast<f32x4 *>(wsm + w_dst[k]) = pre_w[k];
+            *reinterpret_cast<f32x4 *>(wsm + w_dst[k]) = pre_w[pb][k];
         }
     };
-    fetch(0);
+    fetch(0, 0);
+    if (PD == 2 && nch > 1) fetch(1, 1);
 #ifdef SURS_CONV_TRACE
     unsigned long long tprev = __builtin_readcyclecounter();
     if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) for (int i = 0; i < 8; ++i) g_conv_trace[i] = 0;
 #endif
-    for (int ch = 0; ch < nch; ++ch) {
+    auto chunk = [&](int ch, int pb) {
         CSTAMP(4);
-        stage(ch);
+        stage(ch, pb);
         CSTAMP(0);
         __syncthreads();
         CSTAMP(1);
-        if (ch + 1 < nch) fetch(ch + 1);
+        if (ch + PD < nch) fetch(ch + PD, pb);   // into the buffer this chunk has just been staged from
         __builtin_amdgcn_sched_barrier(0);   // the loads are issued HERE, not sunk to their use behind the MFMAs
         CSTAMP(2);
         const int kh = lane >> 5, li = lane & 31;
@@ -396,6 +386,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         }
         CSTAMP(3);
         __syncthreads();
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        chunk(ch, 0);
+        if (ch + 1 < nch) chunk(ch + 1, PD - 1);
     }
     // ---- epilogue: register q of a tile is pixel column (q&3) + 8*(q>>2) + 4*(lane>>5), lane&31 is the channel
     const int kh = lane >> 5, li = lane & 31;
@@ -662,6 +656,9 @@ extern "C" int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_
     SURS_REQUIRE(x && wsplit && y, "null argument");
     SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
     SURS_REQUIRE(ksize == 3 && stride == 1, "the split-bf16 kernel is built for 3x3, stride 1");
+    SURS_REQUIRE(cin % 16 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0,
+                 "the split-bf16 kernel needs cin %% 16 == 0 and 16-byte aligned pixels");
+    SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
     SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
     ConvArgs a;
     a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;

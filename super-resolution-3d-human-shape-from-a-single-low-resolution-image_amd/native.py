@@ -103,7 +103,8 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
     if out is None:
         out = Img(ho, wo, cw.cout, device=x.buf.device)
     assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
-    fn, wt = (lib().surs_conv2d_nhwc_x3, cw.w3) if (cw.w3 is not None and stride == 1) else (lib().surs_conv2d_nhwc, cw.w)
+    x3 = cw.w3 is not None and stride == 1 and x.c % 16 == 0 and x.ld % 4 == 0 and (x.buf.data_ptr() + 4 * x.off) % 16 == 0
+    fn, wt = (lib().surs_conv2d_nhwc_x3, cw.w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
     check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
              residual.ptr() if residual is not None else None,
