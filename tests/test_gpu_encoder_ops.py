@@ -34,6 +34,7 @@ def _chw(img):
     (64, 64, 40, 24, 1, 1, True),     # 1x1
     (512, 512, 8, 8, 3, 1, True),     # bott2 at the smallest size
     (32, 3, 20, 20, 3, 1, True),      # last: cout 3
+    (32, 128, 256, 256, 3, 1, True),  # 512 workgroups of 8 rows x 64 channels: the big tile of the split-bf16 kernel
 ])
 def test_conv(env, cin, cout, h, w, k, stride, bias):
     nat, orc = env["native"], env["oracle"]
@@ -87,3 +88,26 @@ def test_pool_bicubic_shuffle_add(env):
     assert np.array_equal(_chw(nat.add3(X, _img(env, y))), x + y)
     t = torch.from_numpy(x[None]).to(env["dev"])
     assert np.array_equal(_chw(nat.Img.from_nchw(t)), x)
+
+
+def test_split_bf16_conv_equals_fp32_mfma_conv(env):
+    """surs_conv2d_nhwc_x3 (three bf16 parts per operand, six partial products) against surs_conv2d_nhwc (fp32 MFMA) on
+    the same input, fused GroupNorm prologue and LeakyReLU + residual epilogue included: both within fp32 round-off of
+    each other."""
+    import ctypes as C
+    nat = env["native"]
+    cin, cout, h, w = 128, 96, 50, 70
+    x = prng.uniform("sx", 1, (cin, h, w), -2, 2)
+    wt = prng.uniform("sw", 2, (cout, cin, 3, 3), -0.1, 0.1)
+    b = prng.uniform("sb", 3, (cout,), -0.5, 0.5)
+    sc = torch.from_numpy(prng.uniform("ss", 4, (cin,), 0.5, 1.5)).to(env["dev"])
+    sh = torch.from_numpy(prng.uniform("sh", 5, (cin,), -0.3, 0.3)).to(env["dev"])
+    res = _img(env, prng.uniform("sr", 6, (cout, h, w), -1, 1))
+    X = _img(env, x)
+    cw = nat.ConvWeights(wt, b, env["dev"])
+    assert cw.w3 is not None
+    y3 = _chw(nat.conv2d(X, cw, in_scale=sc, in_shift=sh, act=1, slope=0.2, residual=res))
+    w3, cw.w3 = cw.w3, None
+    y1 = _chw(nat.conv2d(X, cw, in_scale=sc, in_shift=sh, act=1, slope=0.2, residual=res))
+    cw.w3 = w3
+    assert common.rel_err(y3, y1) < 2e-6
