@@ -215,3 +215,27 @@ def test_streamed_reconstruction_equals_one_piece(precision):
     net._workspace().mc_capacity[0] = (16, 16)
     got = mesh_util.reconstruction_streamed(opt, net, calib, R, b_min, b_max, planes=5)
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[0], ref[0])
+
+
+def test_bench_contract_small():
+    """bench.py prints ONE JSON line with the driver's keys (reduced resolution here; the roofline / cpu_baseline objects
+    are part of the line) and the streamed reconstruction is what the timed steps run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--resolution", "64", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "queries/s" and d["dtype"] == "bf16"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert abs(d["value"] - 64 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "mfma"
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and d["config"]["stage_ms_rank0"]["mesh"] < d["config"]["stage_ms_rank0"]["query"]
