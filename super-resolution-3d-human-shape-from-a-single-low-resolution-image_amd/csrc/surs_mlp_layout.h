@@ -57,7 +57,11 @@ struct MlpBlobHeader {
     uint32_t total_bytes;
     uint32_t core16;  // the same cores as A fragments of the 16x16x32 shape (column kernel v4), same size
     uint32_t b1frag;  // layer-1 biases as 32x32x16 A fragments [2 MLPs][16 row tiles][64 lanes][8] (see B1FRAG_SCALE)
-    uint32_t pad[3];
+    // fp32 path on the bf16 matrix pipe (gemm_x3_kernel): the k-major matrices wt[m][l] and wc again, every element as
+    // three bf16 parts (hi + mid + lo = the fp32 value exactly), [3 parts][Kpad / 16][M][16] uint16
+    uint32_t wt3[2][4];
+    uint32_t wc3;
+    uint32_t pad[2];
 };
 static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 constexpr uint32_t MLP_MAGIC = 0x53525553u;
@@ -89,6 +93,9 @@ inline MlpBlobHeader blob_layout(uint32_t dtype) {
     h.core = take((size_t)SLABS_TOTAL * SLAB_BYTES);
     h.core16 = take((size_t)SLABS_TOTAL * SLAB_BYTES);
     h.b1frag = take((size_t)2 * (D2 / 32) * 1024);
+    for (int m = 0; m < 2; ++m)
+        for (int l = 0; l < 4; ++l) h.wt3[m][l] = take((size_t)kpad[l] * mout[l] * 6);
+    h.wc3 = take((size_t)C_G * CC_PAD * 6);
     h.total_bytes = (uint32_t)off;
     return h;
 }

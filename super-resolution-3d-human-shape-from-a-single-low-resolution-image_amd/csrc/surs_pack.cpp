@@ -180,6 +180,28 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
             }
         }
     }
+    // ---- the k-major fp32 matrices again as three bf16 parts: [3][Kpad / 16][M][16]
+    {
+        auto split_kmajor = [&](const float *wt, int kpad, int M, uint16_t *out) {
+            const size_t per_part = (size_t)kpad * M;
+            for (int k = 0; k < kpad; ++k)
+                for (int o = 0; o < M; ++o) {
+                    float rest = wt[(size_t)k * M + o];
+                    const size_t idx = ((size_t)(k / 16) * M + o) * 16 + (k & 15);
+                    for (int part = 0; part < 3; ++part) {
+                        const uint16_t u = f32_to_bf16(rest);
+                        out[part * per_part + idx] = u;
+                        rest -= bf16_to_f32(u);
+                    }
+                }
+        };
+        const int mout[4] = {D1, D2, D3, D4};
+        const int kpad[4] = {C0PAD, D1, D2 + C0PAD, D3 + C0PAD};
+        for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < 4; ++l)
+                split_kmajor((const float *)(base + h.wt[m][l]), kpad[l], mout[l], (uint16_t *)(base + h.wt3[m][l]));
+        split_kmajor((const float *)(base + h.wc), C_G, CC_PAD, (uint16_t *)(base + h.wc3));
+    }
     // ---- layer-1 biases as A fragments (three exact 16-bit parts in k-slots 0..2 of lanes 0..31)
     {
         uint16_t *bf = (uint16_t *)(base + h.b1frag);

@@ -251,6 +251,138 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix pipe with fp32 accuracy (see conv_x3_kernel in surs_encoder.hip): every operand as
+// three exact bf16 parts, the six significant partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -
+// 2.7x the rate of v_mfma_f32_32x32x2_f32.  W3: the packer's split image of Wt, [3][K/16][M][16] (a row's 16 k values
+// contiguous: the MFMA operand order).  X stays fp32 k-major in global memory; a thread loads 8 consecutive k of one
+// column (8 coalesced dword loads), splits them and stores three 16-byte fragments pieces, i.e. the transposition
+// happens in registers.  LDS rows have a 48-byte pitch (conflict-free ds_read_b128 across 32 rows).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_bf16(float x, unsigned short &a, unsigned short &b, unsigned short &c) {
+    const __bf16 ha = (__bf16)x;
+    const float r1 = x - (float)ha;
+    const __bf16 hb = (__bf16)r1;
+    const float r2 = r1 - (float)hb;
+    const __bf16 hc = (__bf16)r2;
+    a = __builtin_bit_cast(unsigned short, ha);
+    b = __builtin_bit_cast(unsigned short, hb);
+    c = __builtin_bit_cast(unsigned short, hc);
+}
+
+template <bool TRANSPOSED_OUT>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__restrict__ W3, int M, int Ktot,
+                                                      const float *__restrict__ X1, int K1, long long ld1,
+                                                      const float *__restrict__ X2, int K2, long long ld2,
+                                                      const float *__restrict__ bias, int act,
+                                                      float *__restrict__ Y, long long ldy) {
+    constexpr int PITCH = 24;   // halfwords per row (48 B)
+    __shared__ __attribute__((aligned(16))) unsigned short At[2][3][128][PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][3][128][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long n0 = (long long)blockIdx.x * 128;
+    const int m0 = blockIdx.y * 128;
+    const int ktiles = (K1 + K2) / 16;
+    const size_t per_part = (size_t)Ktot * M;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // staging roles: A: thread t copies 16 bytes (half a row) of each part; X: thread (n = t & 127, h = t >> 7) owns
+    // k = 8h..8h+7 of column n
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const int xn = tid & 127, xh = tid >> 7;
+    f32x4 ra[3];
+    float rx[8];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * 16;
+        const float *X;
+        long long ld;
+        int kx;
+        if (k0 < K1) { X = X1; ld = ld1; kx = k0; } else { X = X2; ld = ld2; kx = k0 - K1; }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            ra[p] = *reinterpret_cast<const f32x4 *>(W3 + p * per_part + ((size_t)kt * M + m0 + arow) * 16 + ahalf * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[j] = X[(long long)(kx + 8 * xh + j) * ld + n0 + xn];
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4 *>(&At[buf][p][arow][ahalf * 8]) = ra[p];
+        u16x8_t q0, q1, q2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned short a, b, c;
+            split3_bf16(rx[j], a, b, c);
+            q0[j] = a; q1[j] = b; q2[j] = c;
+        }
+        *reinterpret_cast<u16x8_t *>(&Xt[buf][0][xn][xh * 8]) = q0;
+        *reinterpret_cast<u16x8_t *>(&Xt[buf][1][xn][xh * 8]) = q1;
+        *reinterpret_cast<u16x8_t *>(&Xt[buf][2][xn][xh * 8]) = q2;
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int kh = lane >> 5, li = lane & 31;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) load_tile(kt + 1);
+        bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = *reinterpret_cast<const bf16x8_t *>(&At[buf][p][wm * 64 + i * 32 + li][kh * 8]);
+                b[i][p] = *reinterpret_cast<const bf16x8_t *>(&Xt[buf][p][wn * 64 + i * 32 + li][kh * 8]);
+            }
+        // the six partial products, smallest first (weight part, activation part); consecutive MFMAs on different tiles
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+        if (kt + 1 < ktiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: acc[i][j][r] is row m = (r&3) + 8*(r>>2) + 4*(lane>>5), column n = lane&31 of its 32x32 tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m = m0 + wm * 64 + i * 32 + 8 * g + 4 * kh;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][4 * g + r] + (bias ? bias[m + r] : 0.0f);
+                    if (act == 1) t = t > 0.0f ? t : 0.01f * t;
+                    v[r] = t;
+                }
+                if (TRANSPOSED_OUT) {
+                    *reinterpret_cast<f32x4 *>(Y + n * ldy + m) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Y[(long long)(m + r) * ldy + n] = v[r];
+                }
+            }
+        }
+}
+
 // last layer (Cout = 1) + sigmoid * mask.  One thread per point, coalesced over points.
 //   logit = b4 + w4[0:128].Y3[:,n] + w4[128:128+336].F[:,n];  pred = mask * sigmoid(logit)
 __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__ w4,
@@ -324,11 +456,27 @@ static Fp32Workspace carve_fp32(void *ws, long long np) {
     return w;
 }
 
-static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, int M, const float *X1, int K1, long long ld1,
-                       const float *X2, int K2, long long ld2, const float *bias, int act, float *Y, long long ldy,
-                       long long np) {
+// SURS_GEMM_X3=0 in the environment keeps the fp32 MFMA kernel (A/B comparisons)
+static bool gemm_use_x3() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SURS_GEMM_X3");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const void *W3, int M, const float *X1, int K1,
+                       long long ld1, const float *X2, int K2, long long ld2, const float *bias, int act, float *Y,
+                       long long ldy, long long np) {
     dim3 grid((unsigned)(np / 128), (unsigned)(M / 128));
-    if (transposed)
+    if (W3 && gemm_use_x3()) {
+        const unsigned short *w3 = (const unsigned short *)W3;
+        if (transposed)
+            hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+        else
+            hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(256), 0, st, w3, M, K1 + K2, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+    } else if (transposed)
         hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
     else
         hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
@@ -348,12 +496,13 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
     SURS_LAUNCH_CHECK();
     for (int m = 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
+        auto W3 = [&](int l) { return (const void *)(blob + h.wt3[m][l]); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
-        if ((rc = launch_gemm(st, false, WT(0), D1, w.F, C0PAD, np, nullptr, 0, 0, BI(0), 1, w.Y0, np, np))) return rc;
-        if ((rc = launch_gemm(st, false, WT(1), D2, w.Y0, D1, np, nullptr, 0, 0, BI(1), 1, w.Y1, np, np))) return rc;
-        if ((rc = launch_gemm(st, false, WT(2), D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
-        if ((rc = launch_gemm(st, false, WT(3), D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(0), W3(0), D1, w.F, C0PAD, np, nullptr, 0, 0, BI(0), 1, w.Y0, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(1), W3(1), D2, w.Y0, D1, np, nullptr, 0, 0, BI(1), 1, w.Y1, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(2), W3(2), D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(3), W3(3), D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
         hipLaunchKernelGGL(mlp_last_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                            (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
                            m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr);
@@ -733,13 +882,14 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
     }
     for (int m = 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
+        auto W3 = [&](int l) { return (const void *)(blob + h.wt3[m][l]); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
         for (int v = 0; v < V; ++v) {
             const float *Fv = F + (size_t)v * fstride;
-            if ((rc = launch_gemm(st, false, WT(0), D1, Fv, C0PAD, np, nullptr, 0, 0, BI(0), 1, Y0, np, np))) return rc;
-            if ((rc = launch_gemm(st, false, WT(1), D2, Y0, D1, np, nullptr, 0, 0, BI(1), 1, Y1, np, np))) return rc;
-            if ((rc = launch_gemm(st, false, WT(2), D3, Y1, D2, np, Fv, C0PAD, np, BI(2), 1, Y2 + (size_t)v * D3 * np, np, np)))
+            if ((rc = launch_gemm(st, false, WT(0), W3(0), D1, Fv, C0PAD, np, nullptr, 0, 0, BI(0), 1, Y0, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(1), W3(1), D2, Y0, D1, np, nullptr, 0, 0, BI(1), 1, Y1, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(2), W3(2), D3, Y1, D2, np, Fv, C0PAD, np, BI(2), 1, Y2 + (size_t)v * D3 * np, np, np)))
                 return rc;
         }
         // the view mean after layer 2 (index len(filters) // 2) of both the activations and the input features
@@ -750,7 +900,7 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
         hipLaunchKernelGGL(mean_views_kernel, dim3((unsigned)ceil_div(fstride, 256)), dim3(256), 0, st, F, fstride, V, fstride,
                            inv, Fm);
         SURS_LAUNCH_CHECK();
-        if ((rc = launch_gemm(st, false, WT(3), D4, Y2m, D3, np, Fm, C0PAD, np, BI(3), 1, Y3, np, np))) return rc;
+        if ((rc = launch_gemm(st, false, WT(3), W3(3), D4, Y2m, D3, np, Fm, C0PAD, np, BI(3), 1, Y3, np, np))) return rc;
         hipLaunchKernelGGL(mlp_last_views_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                            (const float *)(blob + h.w4[m]), Y3, Fm, np, (long long)n, V, mask, m == 0 ? pred_lr : pred_hr,
                            m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride);
@@ -903,7 +1053,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
                            feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr);
         SURS_LAUNCH_CHECK();
-        rc = launch_gemm(st, true, (const float *)(blob + h.wc), CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
+        rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
                          (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
         if (rc) return rc;
         GridArgs a;
