@@ -180,14 +180,16 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
             }
         }
     }
-    // ---- the k-major fp32 matrices again as three bf16 parts: [3][Kpad / 16][M][16]
+    // ---- the k-major fp32 matrices again as three bf16 parts in MFMA A-operand order: [3][Kpad / 16][M / 32][2][32][8]
+    //      (16 k x 32 rows = 1 KB, lane 32h + r of a wave holds k = 8h..8h+7 of row r: a wave-wide 16-byte load of the
+    //      block is contiguous AND already the v_mfma_f32_32x32x16_bf16 fragment)
     {
         auto split_kmajor = [&](const float *wt, int kpad, int M, uint16_t *out) {
             const size_t per_part = (size_t)kpad * M;
             for (int k = 0; k < kpad; ++k)
                 for (int o = 0; o < M; ++o) {
                     float rest = wt[(size_t)k * M + o];
-                    const size_t idx = ((size_t)(k / 16) * M + o) * 16 + (k & 15);
+                    const size_t idx = ((((size_t)(k / 16) * (M / 32) + o / 32) * 2 + ((k >> 3) & 1)) * 32 + (o & 31)) * 8 + (k & 7);
                     for (int part = 0; part < 3; ++part) {
                         const uint16_t u = f32_to_bf16(rest);
                         out[part * per_part + idx] = u;

@@ -31,6 +31,7 @@ namespace surs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
@@ -76,6 +77,26 @@ __device__ __forceinline__ void make_point(const PointSource &s, long long t, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// split-bf16 operands: x = a + b + c exactly (three bf16 parts of an fp32 value, 24 significant bits), so six bf16 MFMA
+// partial products reproduce the fp32 product sum at 2.7x the fp32 matrix rate (conv_x3_kernel in surs_encoder.hip).
+// A "split image" of a k-major fp32 matrix X[K][N] is [3 parts][K/16][N][16] bf16: the 16 k values of one column are
+// 32 contiguous bytes, which is the MFMA operand order of v_mfma_f32_32x32x16_bf16 (lane (n, h) takes k = 8h..8h+7).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_bf16(float x, unsigned short &a, unsigned short &b, unsigned short &c) {
+    const __bf16 ha = (__bf16)x;
+    const float r1 = x - (float)ha;
+    const __bf16 hb = (__bf16)r1;
+    const float r2 = r1 - (float)hb;
+    const __bf16 hc = (__bf16)r2;
+    a = __builtin_bit_cast(unsigned short, ha);
+    b = __builtin_bit_cast(unsigned short, hb);
+    c = __builtin_bit_cast(unsigned short, hc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // gather: F[c][n] for c < 320 (bilinear, zeros padding, align_corners=True), F[320][n] = z_feat,
 //         F[321][n] = 0 (p_lr slot), mask[n] = in_img, zproj[n] = projected Z (for the column kernel: Z at k = 0)
 // One workgroup = 64 points; wave w gathers points 16w..16w+15 with lanes = channels (coalesced 256 B per
@@ -84,7 +105,9 @@ __device__ __forceinline__ void make_point(const PointSource &s, long long t, fl
 __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long n, const float *__restrict__ feat_lr,
                                                      int hl, int wl, const float *__restrict__ feat_hr, int hh,
                                                      int wh, float *__restrict__ F, long long ldf,
-                                                     float *__restrict__ mask, float *__restrict__ zproj) {
+                                                     float *__restrict__ mask, float *__restrict__ zproj,
+                                                     unsigned short *__restrict__ Fs, long long fs_part) {
+    // Fs (optional): the split image of F for the split-bf16 layer kernels, [3][C0PAD/16][ldf][16], fs_part = part stride
     __shared__ float tile[64][65];
     __shared__ float sx[64], sy[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,6 +131,17 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
             if (zproj) zproj[t] = Z;
             F[(long long)C_G * ldf + t] = Z * src.zmul / src.zdiv;
             F[(long long)(C_G + 1) * ldf + t] = 0.0f;
+            if (Fs) {   // k-tile 20 = rows 320..335: z, the p_lr slot (mlp_last_kernel fills it), zero padding
+                unsigned short zp[3];
+                split3_bf16(Z * src.zmul / src.zdiv, zp[0], zp[1], zp[2]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    u16x8_t v = {zp[p], 0, 0, 0, 0, 0, 0, 0}, z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    u16x8_t *dst = reinterpret_cast<u16x8_t *>(Fs + p * fs_part + ((long long)(C_G / 16) * ldf + t) * 16);
+                    dst[0] = v;
+                    dst[1] = z;
+                }
+            }
         }
         sx[tid] = X;
         sy[tid] = Y;
@@ -144,8 +178,47 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
             const int ch = wave * 16 + q;
             if (n0 + lane < n) F[(long long)(cbase + ch) * ldf + n0 + lane] = tile[ch][lane];
         }
+        if (Fs) {   // 4 k-tiles x 64 points x 2 halves of 8 channels
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int item = tid + 256 * it, p = item & 63, half = (item >> 6) & 1, ktl = item >> 7;
+                u16x8_t q0, q1, q2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned short a, b, c;
+                    split3_bf16(tile[ktl * 16 + half * 8 + j][p], a, b, c);
+                    q0[j] = a; q1[j] = b; q2[j] = c;
+                }
+                if (n0 + p < n) {
+                    unsigned short *dst = Fs + ((long long)(cbase / 16 + ktl) * ldf + n0 + p) * 16 + half * 8;
+                    *reinterpret_cast<u16x8_t *>(dst) = q0;
+                    *reinterpret_cast<u16x8_t *>(dst + fs_part) = q1;
+                    *reinterpret_cast<u16x8_t *>(dst + 2 * fs_part) = q2;
+                }
+            }
+        }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workgroup -> output tile for the layer GEMMs.  The point tile (128 columns of X, up to 1360 x 128 values) is the big
+// operand and every row block of the layer re-reads it, so the row blocks of one point tile must run together and on
+// ONE XCD (its L2 then serves the re-reads; with the row index slow every layer read its input M/128 times from HBM).
+// Workgroup ids go round-robin over the 8 XCDs: XCD x takes the logical range [x*per, (x+1)*per), row block fastest.
+// The grid is 8*per workgroups, per = ceil(mblocks*nblocks / 8).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool gemm_block_tile(int mblocks, int nblocks, int &mb, int &nb) {
+    const unsigned total = (unsigned)mblocks * (unsigned)nblocks, per = gridDim.x >> 3;
+    const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    mb = (int)(logical % (unsigned)mblocks);
+    nb = (int)(logical / (unsigned)mblocks);
+    return logical < total;
+}
+
+static inline unsigned gemm_grid(int mblocks, long long nblocks) {
+    const long long total = (long long)mblocks * nblocks;
+    return (unsigned)(((total + 7) / 8) * 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,13 +232,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
                                                        const float *__restrict__ X1, int K1, long long ld1,
                                                        const float *__restrict__ X2, int K2, long long ld2,
                                                        const float *__restrict__ bias, int act,
-                                                       float *__restrict__ Y, long long ldy) {
+                                                       float *__restrict__ Y, long long ldy, int nblocks) {
     __shared__ __attribute__((aligned(16))) float As[2][16][128];
     __shared__ __attribute__((aligned(16))) float Bs[2][16][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long n0 = (long long)blockIdx.x * 128;
-    const int m0 = blockIdx.y * 128;
+    int mb, nb;
+    if (!gemm_block_tile(M / 128, nblocks, mb, nb)) return;
+    const long long n0 = (long long)nb * 128;
+    const int m0 = mb * 128;
     const int ktiles = (K1 + K2) / 16;
     const int lrow = tid >> 5, lcol = (tid & 31) * 4;
 
@@ -254,38 +329,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__
 // ------------------------------------------------------------------------------------------------
 // The same GEMM on the bf16 matrix pipe with fp32 accuracy (see conv_x3_kernel in surs_encoder.hip): every operand as
 // three exact bf16 parts, the six significant partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -
-// 2.7x the rate of v_mfma_f32_32x32x2_f32.  W3: the packer's split image of Wt, [3][K/16][M][16] (a row's 16 k values
-// contiguous: the MFMA operand order).  X stays fp32 k-major in global memory; a thread loads 8 consecutive k of one
+// 2.7x the rate of v_mfma_f32_32x32x2_f32.  W3: the packer's split image of Wt, [3][K/16][M/32][2][32][8] = MFMA A-fragment
+// order (surs_pack.cpp), so a 128-row tile of one k step is 4 KB contiguous and thread t stages its t-th 16 bytes.
 // column (8 coalesced dword loads), splits them and stores three 16-byte fragments pieces, i.e. the transposition
 // happens in registers.  LDS rows have a 48-byte pitch (conflict-free ds_read_b128 across 32 rows).
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3_bf16(float x, unsigned short &a, unsigned short &b, unsigned short &c) {
-    const __bf16 ha = (__bf16)x;
-    const float r1 = x - (float)ha;
-    const __bf16 hb = (__bf16)r1;
-    const float r2 = r1 - (float)hb;
-    const __bf16 hc = (__bf16)r2;
-    a = __builtin_bit_cast(unsigned short, ha);
-    b = __builtin_bit_cast(unsigned short, hb);
-    c = __builtin_bit_cast(unsigned short, hc);
-}
-
 template <bool TRANSPOSED_OUT>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__restrict__ W3, int M, int Ktot,
                                                       const float *__restrict__ X1, int K1, long long ld1,
                                                       const float *__restrict__ X2, int K2, long long ld2,
                                                       const float *__restrict__ bias, int act,
-                                                      float *__restrict__ Y, long long ldy) {
+                                                      float *__restrict__ Y, long long ldy, int nblocks) {
     constexpr int PITCH = 24;   // halfwords per row (48 B)
     __shared__ __attribute__((aligned(16))) unsigned short At[2][3][128][PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Xt[2][3][128][PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long n0 = (long long)blockIdx.x * 128;
-    const int m0 = blockIdx.y * 128;
+    int mb, nb;
+    if (!gemm_block_tile(M / 128, nblocks, mb, nb)) return;
+    const long long n0 = (long long)nb * 128;
+    const int m0 = mb * 128;
     const int ktiles = (K1 + K2) / 16;
     const size_t per_part = (size_t)Ktot * M;
 
@@ -299,7 +362,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__re
 
     // staging roles: A: thread t copies 16 bytes (half a row) of each part; X: thread (n = t & 127, h = t >> 7) owns
     // k = 8h..8h+7 of column n
-    const int arow = tid >> 1, ahalf = tid & 1;
+    const int arow = (tid >> 6) * 32 + (tid & 31), ahalf = (tid >> 5) & 1;
     const int xn = tid & 127, xh = tid >> 7;
     f32x4 ra[3];
     float rx[8];
@@ -310,8 +373,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__re
         int kx;
         if (k0 < K1) { X = X1; ld = ld1; kx = k0; } else { X = X2; ld = ld2; kx = k0 - K1; }
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            ra[p] = *reinterpret_cast<const f32x4 *>(W3 + p * per_part + ((size_t)kt * M + m0 + arow) * 16 + ahalf * 8);
+        for (int p = 0; p < 3; ++p)   // fragment-ordered image: thread t copies the t-th 16 bytes of the 4 KB tile
+            ra[p] = *reinterpret_cast<const f32x4 *>(W3 + p * per_part + ((size_t)kt * M + m0) * 16 + tid * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) rx[j] = X[(long long)(kx + 8 * xh + j) * ld + n0 + xn];
     };
@@ -337,6 +400,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__re
     for (int kt = 0; kt < ktiles; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ktiles) load_tile(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs
         bf16x8_t a[2][3], b[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -354,6 +418,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__re
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < ktiles) store_tile(buf ^ 1);
         __syncthreads();
     }
@@ -383,13 +448,349 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__re
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The layer kernel of the fp32 point path: both operands arrive as split images, the output leaves as one.
+//   Ys[m][n] = split(act(sum_k W[k][m] X[k][n] + bias[m]))   or   Y[m][n] fp32 (the layer in front of mlp_last_kernel)
+// Same 128x128 block / 2x2 waves / 2x2 MFMA tiles as above, but per 16-k step a thread issues only 16-byte moves:
+//   weights  6 global loads (3 parts x 2 row tiles) straight into the MFMA A registers - a wave's loads cover 1 KB
+//            contiguous, the 2 waves sharing the rows hit L1/L2 - prefetched one step ahead;
+//   points   3 global loads -> 3 LDS stores (the 128 x 16 x 3 activation tile, 48-byte pitch), 6 LDS fragment reads;
+// and 24 MFMAs.  No conversion work in the loop: the producer (gather_kernel, this kernel's epilogue) stores the parts.
+// The epilogue pairs the accumulator groups of lanes l and l+32 (v_permlane32_swap) so every lane owns 8 consecutive
+// output rows = one 16-byte piece of the next layer's operand per part.
+// ------------------------------------------------------------------------------------------------
+#ifdef SURS_GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[4 * 16];
+#define GEMM_STAMP(i)                                                                                          \
+    do {                                                                                                       \
+        if (kt >= 8 && kt < 24 && tid == 0 && blockIdx.x == (gridDim.x / 16) * 8 + 3)                            \
+            g_gemm_trace[4 * (kt - 8) + (i)] = __builtin_readcyclecounter();                                   \
+    } while (0)
+#else
+#define GEMM_STAMP(i) do { } while (0)
+#endif
+
+struct SplitSeg {
+    const unsigned short *base;   // [3][ktiles][np][16]
+    long long part;               // halfwords between parts
+    int ktiles;
+};
+
+template <bool SPLIT_OUT>
+__global__ __launch_bounds__(256) void gemm_x3s_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
+                                                       SplitSeg s2, long long np, const float *__restrict__ bias, int act,
+                                                       float *__restrict__ Y, long long ldy,
+                                                       unsigned short *__restrict__ Ys, long long ys_part, int nblocks) {
+    constexpr int PITCH = 24;
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][3][128][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = lane >> 5, li = lane & 31;
+    int mb, nb;
+    if (!gemm_block_tile(M / 128, nblocks, mb, nb)) return;
+    const long long n0 = (long long)nb * 128;
+    const int m0 = mb * 128;
+    const int ktiles = s1.ktiles + s2.ktiles;
+    const size_t per_part = (size_t)Ktot * M;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const unsigned short *wlane = W3 + ((size_t)(m0 + wm * 64)) * 16 + lane * 8;   // fragment-ordered image
+    const int xr = tid >> 1, xhalf = tid & 1;
+    auto load_w = [&](int kt, bf16x8_t (&a)[2][3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i][p] = *reinterpret_cast<const bf16x8_t *>(wlane + p * per_part + ((size_t)kt * M + i * 32) * 16);
+    };
+    auto load_x = [&](int kt, f32x4 (&rx)[3]) {
+        const bool first = kt < s1.ktiles;
+        const unsigned short *b = first ? s1.base : s2.base;
+        const long long part = first ? s1.part : s2.part;
+        const int k = first ? kt : kt - s1.ktiles;
+        const unsigned short *src = b + ((long long)k * np + n0 + xr) * 16 + xhalf * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) rx[p] = *reinterpret_cast<const f32x4 *>(src + p * part);
+    };
+    auto store_x = [&](int buf, const f32x4 (&rx)[3]) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4 *>(&Xt[buf][p][xr][xhalf * 8]) = rx[p];
+    };
+    // step kt: MFMAs on LDS buffer kt&1 and a; issues the weight loads of step kt+1 (-> an) and the point loads of step
+    // kt+2 (-> xn: HBM latency under load is about two steps); stores the point tile of step kt+1 (xs, loaded one step
+    // ago) into the other buffer.  Weights first: the counters retire in order and the weights are needed first.
+    auto step = [&](auto full, int kt, const bf16x8_t (&a)[2][3], bf16x8_t (&an)[2][3], const f32x4 (&xs)[3], f32x4 (&xn)[3]) {
+        const int buf = kt & 1;
+        GEMM_STAMP(0);
+        if (full.value || kt + 1 < ktiles) load_w(kt + 1, an);
+        if (full.value || kt + 2 < ktiles) load_x(kt + 2, xn);
+        // the scheduler otherwise sinks the prefetch below the MFMAs and exposes its whole latency
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP(1);
+        bf16x8_t b[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                b[j][p] = *reinterpret_cast<const bf16x8_t *>(&Xt[buf][p][wn * 64 + j * 32 + li][kh * 8]);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP(2);
+        if (full.value || kt + 1 < ktiles) store_x(buf ^ 1, xs);
+        GEMM_STAMP(3);
+        __syncthreads();
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+
+    bf16x8_t a0[2][3], a1[2][3];
+    f32x4 x0[3], x1[3];
+    load_w(0, a0);
+    load_x(0, x0);
+    if (ktiles > 1) load_x(1, x1);
+    store_x(0, x0);
+    __syncthreads();
+    // x1 holds the tile of step 1; step kt stores the set loaded in step kt-1 and loads into the other one
+    int kt = 0;
+    for (; kt + 3 < ktiles; kt += 2) {   // both steps prefetch unconditionally
+        step(Yes(), kt, a0, a1, x1, x0);
+        step(Yes(), kt + 1, a1, a0, x0, x1);
+    }
+    for (; kt + 1 < ktiles; kt += 2) {
+        step(No(), kt, a0, a1, x1, x0);
+        step(No(), kt + 1, a1, a0, x0, x1);
+    }
+    if (kt < ktiles) step(No(), kt, a0, a1, x1, x0);
+
+    // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's 64, column 32j + li
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wn * 64 + j * 32 + li;
+            const int mrow = m0 + wm * 64 + i * 32;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][4 * g + r] + (bias ? bias[mrow + 8 * g + 4 * kh + r] : 0.0f);
+                    if (act == 1) t = t > 0.0f ? t : 0.01f * t;
+                    v[4 * g + r] = t;
+                }
+            if (!SPLIT_OUT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Y[(long long)(mrow + 8 * g + 4 * kh + r) * ldy + n] = v[4 * g + r];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {   // 16 output rows = one k-tile of the next layer
+                    unsigned e[3][2], o[3][2];  // packed parts of groups g = 2q (rows 4kh..4kh+3) and 2q+1 (8+4kh..)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        unsigned short x0[3], x1[3], y0[3], y1[3];
+                        split3_bf16(v[8 * q + 2 * d], x0[0], x0[1], x0[2]);
+                        split3_bf16(v[8 * q + 2 * d + 1], x1[0], x1[1], x1[2]);
+                        split3_bf16(v[8 * q + 4 + 2 * d], y0[0], y0[1], y0[2]);
+                        split3_bf16(v[8 * q + 4 + 2 * d + 1], y1[0], y1[1], y1[2]);
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            e[p][d] = (unsigned)x0[p] | ((unsigned)x1[p] << 16);
+                            o[p][d] = (unsigned)y0[p] | ((unsigned)y1[p] << 16);
+                        }
+                    }
+                    unsigned short *dst = Ys + ((long long)((mrow >> 4) + q) * np + n) * 16 + kh * 8;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        // lanes < 32 keep their even group and receive the partner's even group (rows 0..7);
+                        // lanes >= 32 receive the partner's odd group and keep their own (rows 8..15)
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(e[p][0], o[p][0], false, false);
+                        const auto s1v = __builtin_amdgcn_permlane32_swap(e[p][1], o[p][1], false, false);
+                        u32x4 w = {s0[0], s1v[0], s0[1], s1v[1]};
+                        *reinterpret_cast<u32x4 *>(dst + p * ys_part) = w;
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The big-tile form of the layer kernel (M and np multiples of 256): measured on the 128x128 kernel above, the matrix pipe
+// idles because the operands cannot be fetched fast enough - 36 KB of L2 reads per 96 MFMAs is 48 B/clk/CU at full MFMA
+// rate (tools/gpu_gemm_trace.py: the 9 loads of a step take 2000 cycles to issue).  Here one workgroup of 8 waves owns a
+// 256 x 256 output tile, both operands go through LDS once per workgroup (48 KB per 384 MFMAs = 16 B/clk/CU), and the
+// staging is LDS-DMA (global_load_lds_dwordx4, no staging registers) into a 3-stage ring, two stages in flight:
+//   stage = [3 parts][8 pieces] weights + [3 parts][8 pieces] points, a piece = 32 rows x 16 k = 1 KB = one wave-wide DMA;
+//   the weight image is fragment-ordered (surs_pack.cpp) so a weight piece IS an MFMA A operand in lane order; a point
+//   piece is row-linear (lane l of the DMA = row l/2, half l&1) and is read as lane (r, h) -> 32 r + 16 h (2-way conflict).
+//   Wave w issues piece w of every part of both operands: 6 DMAs per stage.
+// Waves 2 (rows) x 4 (columns), wave tile 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers.
+// Synchronisation is by hand (cdna_hip_programming.md, "Pipelining across barriers"): fragment reads are asm ds_read_b128
+// with counted lgkmcnt waits, the step barrier is a raw s_barrier behind `s_waitcnt vmcnt(6)` = "my DMAs of this step
+// have landed, those of the next may still fly"; the compiler sees no LDS read and therefore adds no vmcnt(0) of its own.
+// ------------------------------------------------------------------------------------------------
+constexpr int G3_STAGE = 49152, G3_STAGES = 3, G3_LDS_BYTES = G3_STAGE * G3_STAGES;
+
+__global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
+                                                       SplitSeg s2, long long np, const float *__restrict__ bias,
+                                                       unsigned short *__restrict__ Ys, long long ys_part, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    typedef const __attribute__((address_space(1))) void gptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kh = lane >> 5, li = lane & 31;
+    int mb, nb;
+    {   // same XCD-aware order as gemm_block_tile, on 256-wide tiles
+        const unsigned mblocks = (unsigned)M / 256u, total = mblocks * (unsigned)nblocks, per = gridDim.x >> 3;
+        const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (logical >= total) return;
+        mb = (int)(logical % mblocks);
+        nb = (int)(logical / mblocks);
+    }
+    const long long n0 = (long long)nb * 256;
+    const int m0 = mb * 256;
+    const int ktiles = s1.ktiles + s2.ktiles;
+    const size_t per_part = (size_t)Ktot * M;
+    lds_u8 *smem = (lds_u8 *)g3_smem;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // DMA sources of this wave: piece `wave` (32 rows) of the weight tile and of the point tile, lane-linear
+    const unsigned short *wsrc = W3 + ((size_t)(m0 + 32 * wave)) * 16 + lane * 8;
+    auto issue = [&](int kt) {
+        const int stage = kt % G3_STAGES;
+        const bool first = kt < s1.ktiles;
+        const unsigned short *xb = first ? s1.base : s2.base;
+        const long long xpart = first ? s1.part : s2.part;
+        const int k = first ? kt : kt - s1.ktiles;
+        const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * wave) * 16 + lane * 8;
+        const unsigned short *wk = wsrc + (size_t)kt * M * 16;
+        lds_u8 *dst = smem + stage * G3_STAGE + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds((gptr_t *)(wk + p * per_part), (__attribute__((address_space(3))) void *)(dst + p * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(xsrc + p * xpart), (__attribute__((address_space(3))) void *)(dst + 24576 + p * 8192), 16, 0, 0);
+        }
+    };
+
+    issue(0);
+    if (ktiles > 1) issue(1);
+    // fragment addresses inside a stage: weights piece (4 wm + i) at lane * 16; points rows 64 wn + 32 j + r, half h
+    const unsigned a_off = lds0 + (unsigned)(wm * 4096 + lane * 16);
+    const unsigned b_off = lds0 + 24576u + (unsigned)((wn * 64 + li) * 32 + kh * 16);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        // my DMAs of stage kt have landed (the 6 of stage kt+1 may be in flight); after the barrier everybody's have,
+        // and everybody has finished reading stage kt-1, whose buffer the DMAs of stage kt+2 overwrite
+        if (kt + 1 < ktiles)
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < ktiles) issue(kt + 2);
+        const unsigned sa = a_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
+        const unsigned sb = b_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
+        bf16x8_t a[4][3], b[2][3];
+        // reads in order of first use: the products run (weight part, point part) = (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
+#define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+        G3_RD(a[0][2], sa, 16384); G3_RD(a[1][2], sa, 17408); G3_RD(a[2][2], sa, 18432); G3_RD(a[3][2], sa, 19456);
+        G3_RD(b[0][0], sb, 0);     G3_RD(b[1][0], sb, 1024);
+        G3_RD(a[0][1], sa, 8192);  G3_RD(a[1][1], sa, 9216);  G3_RD(a[2][1], sa, 10240); G3_RD(a[3][1], sa, 11264);
+        G3_RD(b[0][1], sb, 8192);  G3_RD(b[1][1], sb, 9216);
+        G3_RD(a[0][0], sa, 0);     G3_RD(a[1][0], sa, 1024);  G3_RD(a[2][0], sa, 2048);  G3_RD(a[3][0], sa, 3072);
+        G3_RD(b[0][2], sb, 16384); G3_RD(b[1][2], sb, 17408);
+#undef G3_RD
+        auto mm = [&](int pa, int pb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+        };
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a[0][2]), "+v"(a[1][2]), "+v"(a[2][2]), "+v"(a[3][2]), "+v"(b[0][0]), "+v"(b[1][0]));
+        mm(2, 0);
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][1]), "+v"(a[1][1]), "+v"(a[2][1]), "+v"(a[3][1]), "+v"(b[0][1]), "+v"(b[1][1]));
+        mm(1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]), "+v"(b[0][2]), "+v"(b[1][2]));
+        mm(0, 2);
+        mm(1, 0);
+        mm(0, 1);
+        mm(0, 0);
+    }
+
+    // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's 128, column 32j + li; bias, LeakyReLU, split,
+    // pair lanes l / l+32 so each owns 8 consecutive rows = 16 bytes of the next layer's operand (see gemm_x3s_kernel)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wn * 64 + j * 32 + li;
+            const int mrow = m0 + wm * 128 + i * 32;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][4 * g + r] + bias[mrow + 8 * g + 4 * kh + r];
+                    v[4 * g + r] = t > 0.0f ? t : 0.01f * t;
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned e[3][2], o[3][2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    unsigned short x0[3], x1[3], y0[3], y1[3];
+                    split3_bf16(v[8 * q + 2 * d], x0[0], x0[1], x0[2]);
+                    split3_bf16(v[8 * q + 2 * d + 1], x1[0], x1[1], x1[2]);
+                    split3_bf16(v[8 * q + 4 + 2 * d], y0[0], y0[1], y0[2]);
+                    split3_bf16(v[8 * q + 4 + 2 * d + 1], y1[0], y1[1], y1[2]);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        e[p][d] = (unsigned)x0[p] | ((unsigned)x1[p] << 16);
+                        o[p][d] = (unsigned)y0[p] | ((unsigned)y1[p] << 16);
+                    }
+                }
+                unsigned short *dst = Ys + ((long long)((mrow >> 4) + q) * np + n) * 16 + kh * 8;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const auto t0 = __builtin_amdgcn_permlane32_swap(e[p][0], o[p][0], false, false);
+                    const auto t1 = __builtin_amdgcn_permlane32_swap(e[p][1], o[p][1], false, false);
+                    u32x4 w = {t0[0], t1[0], t0[1], t1[1]};
+                    *reinterpret_cast<u32x4 *>(dst + p * ys_part) = w;
+                }
+            }
+        }
+}
+
 // last layer (Cout = 1) + sigmoid * mask.  One thread per point, coalesced over points.
 //   logit = b4 + w4[0:128].Y3[:,n] + w4[128:128+336].F[:,n];  pred = mask * sigmoid(logit)
 __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__ w4,
                                                        const float *__restrict__ Y3, const float *__restrict__ F,
                                                        long long ld, long long n, const float *__restrict__ mask,
                                                        float *__restrict__ pred, float *__restrict__ logit,
-                                                       float *__restrict__ p_slot) {
+                                                       float *__restrict__ p_slot, unsigned short *__restrict__ Fs,
+                                                       long long fs_part) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     float acc = w4[D4 + C0PAD];  // b4
@@ -399,6 +800,14 @@ __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__
     pred[t] = p;
     if (logit) logit[t] = acc;
     if (p_slot) p_slot[t] = p;
+    if (Fs) {   // row 321 of the split image of F
+        unsigned short a, b, c;
+        split3_bf16(p, a, b, c);
+        unsigned short *dst = Fs + ((long long)(C_G / 16) * ld + t) * 16 + 1;
+        dst[0] = a;
+        dst[fs_part] = b;
+        dst[2 * fs_part] = c;
+    }
 }
 
 // multi-view (num_views > 1, SurfaceClassifier.py:70-76): out[r][t] = (sum_v in[v][r][t]) * (1/V), views summed in order
@@ -438,21 +847,31 @@ __global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__rest
 // ------------------------------------------------------------------------------------------------
 struct Fp32Workspace {
     float *F, *Y0, *Y1, *Y2, *Y3, *mask;
+    unsigned short *Fs, *Y0s, *Y1s, *Y2s;   // split images (split-bf16 layer kernels); they overlay Y0..Y2
     long long np;  // padded point count (multiple of 128)
 };
 
-static size_t fp32_ws_bytes(long long np) { return (size_t)np * (C0PAD + D1 + D2 + D3 + D4 + 1) * sizeof(float) + 4096; }
+// F, Y3 and the mask in fp32; the hidden activations either as split images (6 bytes per value, with the split image of
+// F) or - SURS_GEMM_X3=0 - as fp32 in the same region
+static size_t fp32_ws_bytes(long long np) {
+    return (size_t)np * ((C0PAD + D4 + 1) * sizeof(float) + (size_t)(C0PAD + D1 + D2 + D3) * 6) + 4096;
+}
 
 static Fp32Workspace carve_fp32(void *ws, long long np) {
     Fp32Workspace w;
     float *p = (float *)ws;
     w.np = np;
     w.F = p; p += (size_t)C0PAD * np;
-    w.Y0 = p; p += (size_t)D1 * np;
-    w.Y1 = p; p += (size_t)D2 * np;
-    w.Y2 = p; p += (size_t)D3 * np;
     w.Y3 = p; p += (size_t)D4 * np;
-    w.mask = p;
+    w.mask = p; p += np;
+    w.Y0 = p;
+    w.Y1 = w.Y0 + (size_t)D1 * np;
+    w.Y2 = w.Y1 + (size_t)D2 * np;
+    unsigned short *q = (unsigned short *)p;
+    w.Fs = q; q += (size_t)3 * C0PAD * np;
+    w.Y0s = q; q += (size_t)3 * D1 * np;
+    w.Y1s = q; q += (size_t)3 * D2 * np;
+    w.Y2s = q;
     return w;
 }
 
@@ -466,21 +885,69 @@ static bool gemm_use_x3() {
     return v == 1;
 }
 
+// SURS_GEMM_BIG=0 keeps the 128 x 128 layer kernel for every layer (A/B comparisons)
+static bool gemm_use_big() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SURS_GEMM_BIG");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const void *W3, int M, const float *X1, int K1,
                        long long ld1, const float *X2, int K2, long long ld2, const float *bias, int act, float *Y,
                        long long ldy, long long np) {
-    dim3 grid((unsigned)(np / 128), (unsigned)(M / 128));
+    const int nblocks = (int)(np / 128);
+    dim3 grid(gemm_grid(M / 128, nblocks));
     if (W3 && gemm_use_x3()) {
         const unsigned short *w3 = (const unsigned short *)W3;
         if (transposed)
-            hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+            hipLaunchKernelGGL(gemm_x3_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy, nblocks);
         else
-            hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(256), 0, st, w3, M, K1 + K2, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+            hipLaunchKernelGGL(gemm_x3_kernel<false>, grid, dim3(256), 0, st, w3, M, K1 + K2, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy, nblocks);
     } else if (transposed)
-        hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+        hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy, nblocks);
     else
-        hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy);
+        hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, dim3(256), 0, st, Wt, M, X1, K1, ld1, X2, K2, ld2, bias, act, Y, ldy, nblocks);
     SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned short *X1s, int K1, const unsigned short *X2s,
+                         int K2, const float *bias, float *Y, unsigned short *Ys, long long np) {
+    SplitSeg s1 = {X1s, (long long)K1 * np, K1 / 16}, s2 = {X2s, (long long)K2 * np, K2 / 16};
+    const int nblocks = (int)(np / 128);
+    dim3 grid(gemm_grid(M / 128, nblocks));
+    const unsigned short *w3 = (const unsigned short *)W3;
+    if (Ys && M % 256 == 0 && np % 256 == 0 && gemm_use_big()) {
+        static bool once = false;
+        if (!once) {
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+            once = true;
+        }
+        const int nb256 = (int)(np / 256);
+        hipLaunchKernelGGL(gemm_x3g_kernel, dim3(gemm_grid(M / 256, nb256)), dim3(512), G3_LDS_BYTES, st, w3, M, K1 + K2, s1, s2, np,
+                           bias, Ys, (long long)M * np, nb256);
+    } else if (Ys)
+        hipLaunchKernelGGL(gemm_x3s_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, s1, s2, np, bias, 1, (float *)nullptr,
+                           0LL, Ys, (long long)M * np, nblocks);
+    else
+        hipLaunchKernelGGL(gemm_x3s_kernel<false>, grid, dim3(256), 0, st, w3, M, K1 + K2, s1, s2, np, bias, 1, Y, np,
+                           (unsigned short *)nullptr, 0LL, nblocks);
+    SURS_LAUNCH_CHECK();
+#ifdef SURS_GEMM_TRACE
+    if (getenv("SURS_GEMM_TRACE")) {
+        unsigned long long t[64];
+        SURS_HIP_CHECK(hipStreamSynchronize(st));
+        SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gemm_trace), sizeof(t)));
+        fprintf(stderr, "gemm trace M=%d K=%d np=%lld (issue, mfma, store, barrier+):", M, K1 + K2, np);
+        for (int i = 0; i < 15; ++i)
+            fprintf(stderr, " [%llu %llu %llu %llu]", t[4 * i + 1] - t[4 * i], t[4 * i + 2] - t[4 * i + 1], t[4 * i + 3] - t[4 * i + 2],
+                    t[4 * i + 4] - t[4 * i + 3]);
+        fprintf(stderr, "\n");
+    }
+#endif
     return 0;
 }
 
@@ -489,23 +956,35 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
                            const float *feat_hr, int hh, int wh, const char *blob, const MlpBlobHeader &h,
                            const Fp32Workspace &w, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr) {
     const long long np = w.np;
-    // rows 322..335 of F meet zero weights and must be finite: the caller zeroes them once (zero_pad_rows);
-    // rows < 322 are fully written for t < n; columns n..np-1 only feed outputs that are never read
+    const bool x3 = gemm_use_x3();
+    unsigned short *Fs = x3 ? w.Fs : nullptr;
+    const long long fs_part = (long long)C0PAD * np;
+    // rows 322..335 of F meet zero weights and must be finite: the caller zeroes them once (zero_pad_rows; the split
+    // image gets them from gather_kernel); rows < 322 are fully written for t < n; columns n..np-1 only feed outputs
+    // that are never read
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
-                       hh, wh, w.F, np, w.mask, (float *)nullptr);
+                       hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
     SURS_LAUNCH_CHECK();
     for (int m = 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
         auto W3 = [&](int l) { return (const void *)(blob + h.wt3[m][l]); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
-        if ((rc = launch_gemm(st, false, WT(0), W3(0), D1, w.F, C0PAD, np, nullptr, 0, 0, BI(0), 1, w.Y0, np, np))) return rc;
-        if ((rc = launch_gemm(st, false, WT(1), W3(1), D2, w.Y0, D1, np, nullptr, 0, 0, BI(1), 1, w.Y1, np, np))) return rc;
-        if ((rc = launch_gemm(st, false, WT(2), W3(2), D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
-        if ((rc = launch_gemm(st, false, WT(3), W3(3), D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
+        if (x3) {
+            if ((rc = launch_gemm_s(st, W3(0), D1, Fs, C0PAD, nullptr, 0, BI(0), nullptr, w.Y0s, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(1), D2, w.Y0s, D1, nullptr, 0, BI(1), nullptr, w.Y1s, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(2), D3, w.Y1s, D2, Fs, C0PAD, BI(2), nullptr, w.Y2s, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(3), D4, w.Y2s, D3, Fs, C0PAD, BI(3), w.Y3, nullptr, np))) return rc;
+        } else {
+            if ((rc = launch_gemm(st, false, WT(0), nullptr, D1, w.F, C0PAD, np, nullptr, 0, 0, BI(0), 1, w.Y0, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(1), nullptr, D2, w.Y0, D1, np, nullptr, 0, 0, BI(1), 1, w.Y1, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(2), nullptr, D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
+            if ((rc = launch_gemm(st, false, WT(3), nullptr, D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
+        }
         hipLaunchKernelGGL(mlp_last_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                            (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
-                           m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr);
+                           m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr,
+                           m == 0 ? Fs : (unsigned short *)nullptr, fs_part);
         SURS_LAUNCH_CHECK();
     }
     return 0;
@@ -790,7 +1269,7 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 }
 
 extern "C" size_t surs_query_workspace_bytes(int max_points) {
-    long long np = (long long)ceil_div(max_points, 128) * 128;
+    long long np = (long long)ceil_div(max_points, 256) * 256;
     return fp32_ws_bytes(np);
 }
 
@@ -809,7 +1288,7 @@ extern "C" int surs_query_points(const float *points, int n, const float *calib,
     SURS_REQUIRE(points && calib && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
     SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
     hipStream_t st = as_stream(stream);
-    const long long np = (long long)ceil_div(n, 128) * 128;
+    const long long np = (long long)ceil_div(n, 256) * 256;
     SURS_REQUIRE(workspace_bytes >= fp32_ws_bytes(np), "workspace too small: need %zu bytes", fp32_ws_bytes(np));
     const MlpBlobHeader h = blob_layout(SURS_BF16);
     PointSource src;
@@ -877,7 +1356,7 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
         fill_calib(src, calibs + 12 * v, zmul, zdiv);
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
                            feat_lr + (size_t)v * hl * wl * C_LR, hl, wl, feat_hr + (size_t)v * hh * wh * C_HR, hh, wh, Fv, np,
-                           mask + (size_t)v * np, (float *)nullptr);
+                           mask + (size_t)v * np, (float *)nullptr, (unsigned short *)nullptr, 0LL);
         SURS_LAUNCH_CHECK();
     }
     for (int m = 0; m < 2; ++m) {
@@ -1051,7 +1530,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         const long long ncp = (long long)ceil_div(nc, 128) * 128;
         src.base = (long long)i0 * ry + c0;
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
-                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr);
+                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, (unsigned short *)nullptr, 0LL);
         SURS_LAUNCH_CHECK();
         rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
                          (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
@@ -1138,7 +1617,7 @@ extern "C" int surs_query_grid_indexed(const long long *idx, int n, int ry, int 
     if (n == 0) return 0;
     SURS_REQUIRE(idx && mat && calib && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
     hipStream_t st = as_stream(stream);
-    const long long np = (long long)ceil_div(n, 128) * 128;
+    const long long np = (long long)ceil_div(n, 256) * 256;
     SURS_REQUIRE(workspace_bytes >= fp32_ws_bytes(np), "workspace too small: need %zu bytes", fp32_ws_bytes(np));
     const MlpBlobHeader h = blob_layout(SURS_BF16);
     PointSource src;

@@ -223,3 +223,13 @@ def test_mlp_blob_fragment_images_and_bias_split():
         parts = bf[m, :, :32, :3].reshape(512, 3)
         assert np.array_equal((parts[:, 0] + parts[:, 1]) + parts[:, 2], b1)
         assert np.all(bf[m, :, 32:, :] == 0) and np.all(bf[m, :, :, 3:] == 0)
+    # --- split-bf16 images of the fp32 layer matrices (header words 29..36 = wt3[2][4], 37 = wc3):
+    #     [3 parts][K/16][M/32][2][32][8], parts sum to the fp32 weight exactly; hr MLP layer 1 (K = 1024, M = 512)
+    K, M = 1024, 512
+    off = int(hdr[29 + 4 * 1 + 1])
+    img3 = _bf16_to_f32(blob[off:off + K * M * 6].view(np.uint16)).reshape(3, K // 16, M // 32, 2, 32, 8)
+    s_, T = 37, 9
+    got = (img3[0, s_, T] + img3[1, s_, T]) + img3[2, s_, T]            # [h][r][j] = W1[32T + r][16s + 8h + j]
+    want = w1[32 * T:32 * T + 32, 16 * s_:16 * s_ + 16].reshape(32, 2, 8).transpose(1, 0, 2)
+    assert np.array_equal(got, want)
+    assert np.array_equal(img3[0, s_, T], rnd(np.ascontiguousarray(want)))
