@@ -680,19 +680,26 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
 
     // DMA sources of this wave: piece `wave` (32 rows) of the weight tile and of the point tile, lane-linear
     const unsigned short *wsrc = W3 + ((size_t)(m0 + 32 * wave)) * 16 + lane * 8;
+    // DMAs of step kt: part p of the weights (which = 0) or of the points (which = 1)
+    auto issue1 = [&](int kt, int p, int which) {
+        lds_u8 *dst = smem + (kt % G3_STAGES) * G3_STAGE + wave * 1024 + p * 8192;
+        if (which == 0) {
+            const unsigned short *wk = wsrc + (size_t)kt * M * 16 + p * per_part;
+            __builtin_amdgcn_global_load_lds((gptr_t *)wk, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else {
+            const bool first = kt < s1.ktiles;
+            const unsigned short *xb = first ? s1.base : s2.base;
+            const long long xpart = first ? s1.part : s2.part;
+            const int k = first ? kt : kt - s1.ktiles;
+            const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * wave) * 16 + lane * 8 + p * xpart;
+            __builtin_amdgcn_global_load_lds((gptr_t *)xsrc, (__attribute__((address_space(3))) void *)(dst + 24576), 16, 0, 0);
+        }
+    };
     auto issue = [&](int kt) {
-        const int stage = kt % G3_STAGES;
-        const bool first = kt < s1.ktiles;
-        const unsigned short *xb = first ? s1.base : s2.base;
-        const long long xpart = first ? s1.part : s2.part;
-        const int k = first ? kt : kt - s1.ktiles;
-        const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * wave) * 16 + lane * 8;
-        const unsigned short *wk = wsrc + (size_t)kt * M * 16;
-        lds_u8 *dst = smem + stage * G3_STAGE + wave * 1024;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            __builtin_amdgcn_global_load_lds((gptr_t *)(wk + p * per_part), (__attribute__((address_space(3))) void *)(dst + p * 8192), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t *)(xsrc + p * xpart), (__attribute__((address_space(3))) void *)(dst + 24576 + p * 8192), 16, 0, 0);
+            issue1(kt, p, 0);
+            issue1(kt, p, 1);
         }
     };
 
@@ -701,18 +708,22 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
     // fragment addresses inside a stage: weights piece (4 wm + i) at lane * 16; points rows 64 wn + 32 j + r, half h
     const unsigned a_off = lds0 + (unsigned)(wm * 4096 + lane * 16);
     const unsigned b_off = lds0 + 24576u + (unsigned)((wn * 64 + li) * 32 + kh * 16);
-    for (int kt = 0; kt < ktiles; ++kt) {
-        // my DMAs of stage kt have landed (the 6 of stage kt+1 may be in flight); after the barrier everybody's have,
-        // and everybody has finished reading stage kt-1, whose buffer the DMAs of stage kt+2 overwrite
-        if (kt + 1 < ktiles)
-            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 < ktiles) issue(kt + 2);
+    bf16x8_t a[4][3], b[2][3];
+    auto mm = [&](int pa, int pb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+    };
+    // A step = phase 1 (fragment reads of stage kt, the first 24 MFMAs, behind each group of 8 two of the 6 DMAs of stage
+    // kt+2, where their issue cost is shared with the matrix pipe) + phase 2 (the other 24 MFMAs, registers only).  The
+    // products run (weight part, point part) = (2,0) (1,1) (0,2) | (1,0) (0,1) (0,0); fragments are read in order of first use.
+    auto phase1 = [&](int kt) {
+        const bool more = kt + 2 < ktiles;
         const unsigned sa = a_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
         const unsigned sb = b_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
-        bf16x8_t a[4][3], b[2][3];
-        // reads in order of first use: the products run (weight part, point part) = (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
+        GEMM_STAMP(0);
 #define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
         G3_RD(a[0][2], sa, 16384); G3_RD(a[1][2], sa, 17408); G3_RD(a[2][2], sa, 18432); G3_RD(a[3][2], sa, 19456);
         G3_RD(b[0][0], sb, 0);     G3_RD(b[1][0], sb, 1024);
@@ -721,22 +732,54 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
         G3_RD(a[0][0], sa, 0);     G3_RD(a[1][0], sa, 1024);  G3_RD(a[2][0], sa, 2048);  G3_RD(a[3][0], sa, 3072);
         G3_RD(b[0][2], sb, 16384); G3_RD(b[1][2], sb, 17408);
 #undef G3_RD
-        auto mm = [&](int pa, int pb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
-        };
         asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a[0][2]), "+v"(a[1][2]), "+v"(a[2][2]), "+v"(a[3][2]), "+v"(b[0][0]), "+v"(b[1][0]));
+        GEMM_STAMP(1);
         mm(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { issue1(kt + 2, 0, 0); issue1(kt + 2, 0, 1); }
         asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][1]), "+v"(a[1][1]), "+v"(a[2][1]), "+v"(a[3][1]), "+v"(b[0][1]), "+v"(b[1][1]));
         mm(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { issue1(kt + 2, 1, 0); issue1(kt + 2, 1, 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]), "+v"(b[0][2]), "+v"(b[1][2]));
         mm(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { issue1(kt + 2, 2, 0); issue1(kt + 2, 2, 1); }
+        GEMM_STAMP(2);
+    };
+    auto phase2 = [&](int kt) {
         mm(1, 0);
         mm(0, 1);
         mm(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        GEMM_STAMP(3);
+    };
+    // step barrier: my DMAs of stage kt have landed (the 6 of stage kt+1 may be in flight); after the barrier everybody's
+    // have, and everybody has finished reading stage kt-1, whose buffer the DMAs of stage kt+2 overwrite
+    auto step_barrier = [&](int kt) {
+        if (kt + 1 < ktiles)
+            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // Waves w and w+4 share a SIMD.  Waves 0-3 run barrier, phase 1, phase 2; waves 4-7 run barrier, phase 2 of the
+    // PREVIOUS step (its operands are in registers), phase 1: while one wave waits for its fragment reads or issues DMAs
+    // the other one has MFMAs to issue (step 5200 -> 4600 cycles, tools/gpu_gemm_trace.py; 3072 is the MFMA time).
+    if (wave < 4) {
+        for (int kt = 0; kt < ktiles; ++kt) {
+            step_barrier(kt);
+            phase1(kt);
+            phase2(kt);
+        }
+    } else {
+        step_barrier(0);
+        phase1(0);
+        for (int kt = 1; kt < ktiles; ++kt) {
+            step_barrier(kt);
+            phase2(kt - 1);
+            phase1(kt);
+        }
+        phase2(ktiles - 1);
     }
 
     // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's 128, column 32j + li; bias, LeakyReLU, split,
