@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void gemm_x3s_kernel(const unsigned short *__r
 // staging is LDS-DMA (global_load_lds_dwordx4, no staging registers) into a 3-stage ring, two stages in flight:
 //   stage = [3 parts][8 pieces] weights + [3 parts][8 pieces] points, a piece = 32 rows x 16 k = 1 KB = one wave-wide DMA;
 //   the weight image is fragment-ordered (surs_pack.cpp) so a weight piece IS an MFMA A operand in lane order; a point
-//   piece is row-linear (lane l of the DMA = row l/2, half l&1) and is read as lane (r, h) -> 32 r + 16 h (2-way conflict).
+//   piece is put in the same order by the DMA's per-lane source address (lane (h, r) fetches half h of row r).
 //   Wave w issues piece w of every part of both operands: 6 DMAs per stage.
 // Waves 2 (rows) x 4 (columns), wave tile 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers.
 // Synchronisation is by hand (cdna_hip_programming.md, "Pipelining across barriers"): fragment reads are asm ds_read_b128
@@ -646,9 +646,13 @@ __global__ __launch_bounds__(256) void gemm_x3s_kernel(const unsigned short *__r
 // ------------------------------------------------------------------------------------------------
 constexpr int G3_STAGE = 49152, G3_STAGES = 3, G3_LDS_BYTES = G3_STAGE * G3_STAGES;
 
-__global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
-                                                       SplitSeg s2, long long np, const float *__restrict__ bias,
-                                                       unsigned short *__restrict__ Ys, long long ys_part, int nblocks) {
+// NW = 8 waves (2 x 4, wave tile 128 x 64) or 16 waves (4 x 4, wave tile 64 x 64, 4 waves per SIMD)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
+                                                           SplitSeg s2, long long np, const float *__restrict__ bias,
+                                                           unsigned short *__restrict__ Ys, long long ys_part, int nblocks) {
+    constexpr int TI = 32 / NW;       // MFMA row tiles per wave
+    constexpr int NDMA = 48 / NW;     // DMAs per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef const __attribute__((address_space(1))) void gptr_t;
@@ -670,20 +674,24 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
     lds_u8 *smem = (lds_u8 *)g3_smem;
     const unsigned lds0 = (unsigned)(size_t)smem;
 
-    f32x16 acc[4][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // DMA sources of this wave: piece `wave` (32 rows) of the weight tile and of the point tile, lane-linear
-    const unsigned short *wsrc = W3 + ((size_t)(m0 + 32 * wave)) * 16 + lane * 8;
-    // DMAs of step kt: part p of the weights (which = 0) or of the points (which = 1)
-    auto issue1 = [&](int kt, int p, int which) {
-        lds_u8 *dst = smem + (kt % G3_STAGES) * G3_STAGE + wave * 1024 + p * 8192;
-        if (which == 0) {
+    // DMA d of this wave and step kt.  8 waves: piece `wave` of part d>>1 of the weights (d even) / points (d odd);
+    // 16 waves: waves 0-7 piece `wave` of part d of the weights, waves 8-15 piece `wave - 8` of part d of the points.
+    // A points piece is fetched with lane (h, r) on half h of row r, so it lands in LDS in fragment order like the weights.
+    const int piece = wave & 7;
+    const unsigned short *wsrc = W3 + ((size_t)(m0 + 32 * piece)) * 16 + lane * 8;
+    auto issue1 = [&](int kt, int d) {
+        const int p = NW == 8 ? d >> 1 : d;
+        const bool points = NW == 8 ? (d & 1) : (wave >= 8);
+        lds_u8 *dst = smem + (kt % G3_STAGES) * G3_STAGE + piece * 1024 + p * 8192;
+        if (!points) {
             const unsigned short *wk = wsrc + (size_t)kt * M * 16 + p * per_part;
             __builtin_amdgcn_global_load_lds((gptr_t *)wk, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         } else {
@@ -691,60 +699,74 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
             const unsigned short *xb = first ? s1.base : s2.base;
             const long long xpart = first ? s1.part : s2.part;
             const int k = first ? kt : kt - s1.ktiles;
-            const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * wave) * 16 + lane * 8 + p * xpart;
+            const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * piece) * 16 + (li * 16 + kh * 8) + p * xpart;
             __builtin_amdgcn_global_load_lds((gptr_t *)xsrc, (__attribute__((address_space(3))) void *)(dst + 24576), 16, 0, 0);
         }
     };
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            issue1(kt, p, 0);
-            issue1(kt, p, 1);
-        }
+        for (int d = 0; d < NDMA; ++d) issue1(kt, d);
     };
 
     issue(0);
     if (ktiles > 1) issue(1);
-    // fragment addresses inside a stage: weights piece (4 wm + i) at lane * 16; points rows 64 wn + 32 j + r, half h
-    const unsigned a_off = lds0 + (unsigned)(wm * 4096 + lane * 16);
-    const unsigned b_off = lds0 + 24576u + (unsigned)((wn * 64 + li) * 32 + kh * 16);
-    bf16x8_t a[4][3], b[2][3];
+    // fragment addresses inside a stage: weights piece TI wm + i, points piece 2 wn + j, both at lane * 16
+    const unsigned a_off = lds0 + (unsigned)(wm * TI * 1024 + lane * 16);
+    const unsigned b_off = lds0 + 24576u + (unsigned)(wn * 2048 + lane * 16);
+    bf16x8_t a[TI][3], b[2][3];
     auto mm = [&](int pa, int pb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
     };
-    // A step = phase 1 (fragment reads of stage kt, the first 24 MFMAs, behind each group of 8 two of the 6 DMAs of stage
-    // kt+2, where their issue cost is shared with the matrix pipe) + phase 2 (the other 24 MFMAs, registers only).  The
-    // products run (weight part, point part) = (2,0) (1,1) (0,2) | (1,0) (0,1) (0,0); fragments are read in order of first use.
+#ifdef SURS_G3_NO_LDS   // experiment: timing without the fragment reads (results are wrong)
+#define G3_RD(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr) : "memory")
+#else
+#define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#endif
+// waits for everything but the n youngest LDS reads; naming the fragments ties their uses to the wait
+#define G3_WAIT4(n, pa, pb) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0][pa]), "+v"(a[1][pa]), "+v"(a[2][pa]), "+v"(a[3][pa]), "+v"(b[0][pb]), "+v"(b[1][pb]))
+#define G3_WAIT2(n, pa, pb) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0][pa]), "+v"(a[1][pa]), "+v"(b[0][pb]), "+v"(b[1][pb]))
+    // A step = phase 1 (fragment reads of stage kt, the first three products, behind each of them a third of the DMAs of
+    // stage kt+2, where their issue cost is shared with the matrix pipe) + phase 2 (the other three products, registers
+    // only).  The products run (weight part, point part) = (2,0) (1,1) (0,2) | (1,0) (0,1) (0,0); fragments are read in
+    // order of first use.
     auto phase1 = [&](int kt) {
+#ifdef SURS_G3_NO_DMA   // experiment: timing without the in-loop DMAs (results are wrong)
+        const bool more = false;
+#else
         const bool more = kt + 2 < ktiles;
+#endif
         const unsigned sa = a_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
         const unsigned sb = b_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
         GEMM_STAMP(0);
-#define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
-        G3_RD(a[0][2], sa, 16384); G3_RD(a[1][2], sa, 17408); G3_RD(a[2][2], sa, 18432); G3_RD(a[3][2], sa, 19456);
+        G3_RD(a[0][2], sa, 16384); G3_RD(a[1][2], sa, 17408);
+        if constexpr (TI == 4) { G3_RD(a[2][2], sa, 18432); G3_RD(a[3][2], sa, 19456); }
         G3_RD(b[0][0], sb, 0);     G3_RD(b[1][0], sb, 1024);
-        G3_RD(a[0][1], sa, 8192);  G3_RD(a[1][1], sa, 9216);  G3_RD(a[2][1], sa, 10240); G3_RD(a[3][1], sa, 11264);
+        G3_RD(a[0][1], sa, 8192);  G3_RD(a[1][1], sa, 9216);
+        if constexpr (TI == 4) { G3_RD(a[2][1], sa, 10240); G3_RD(a[3][1], sa, 11264); }
         G3_RD(b[0][1], sb, 8192);  G3_RD(b[1][1], sb, 9216);
-        G3_RD(a[0][0], sa, 0);     G3_RD(a[1][0], sa, 1024);  G3_RD(a[2][0], sa, 2048);  G3_RD(a[3][0], sa, 3072);
+        G3_RD(a[0][0], sa, 0);     G3_RD(a[1][0], sa, 1024);
+        if constexpr (TI == 4) { G3_RD(a[2][0], sa, 2048); G3_RD(a[3][0], sa, 3072); }
         G3_RD(b[0][2], sb, 16384); G3_RD(b[1][2], sb, 17408);
-#undef G3_RD
-        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a[0][2]), "+v"(a[1][2]), "+v"(a[2][2]), "+v"(a[3][2]), "+v"(b[0][0]), "+v"(b[1][0]));
+        if constexpr (TI == 4) G3_WAIT4(12, 2, 0); else G3_WAIT2(8, 2, 0);
         GEMM_STAMP(1);
         mm(2, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { issue1(kt + 2, 0, 0); issue1(kt + 2, 0, 1); }
-        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][1]), "+v"(a[1][1]), "+v"(a[2][1]), "+v"(a[3][1]), "+v"(b[0][1]), "+v"(b[1][1]));
+        if (more)
+            for (int d = 0; d < NDMA / 3; ++d) issue1(kt + 2, d);
+        if constexpr (TI == 4) G3_WAIT4(6, 1, 1); else G3_WAIT2(4, 1, 1);
         mm(1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { issue1(kt + 2, 1, 0); issue1(kt + 2, 1, 1); }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[1][0]), "+v"(a[2][0]), "+v"(a[3][0]), "+v"(b[0][2]), "+v"(b[1][2]));
+        if (more)
+            for (int d = NDMA / 3; d < 2 * NDMA / 3; ++d) issue1(kt + 2, d);
+        if constexpr (TI == 4) G3_WAIT4(0, 0, 2); else G3_WAIT2(0, 0, 2);
         mm(0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { issue1(kt + 2, 2, 0); issue1(kt + 2, 2, 1); }
+        if (more)
+            for (int d = 2 * NDMA / 3; d < NDMA; ++d) issue1(kt + 2, d);
         GEMM_STAMP(2);
     };
     auto phase2 = [&](int kt) {
@@ -754,18 +776,23 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
         __builtin_amdgcn_sched_barrier(0);
         GEMM_STAMP(3);
     };
-    // step barrier: my DMAs of stage kt have landed (the 6 of stage kt+1 may be in flight); after the barrier everybody's
+    // step barrier: my DMAs of stage kt have landed (those of stage kt+1 may be in flight); after the barrier everybody's
     // have, and everybody has finished reading stage kt-1, whose buffer the DMAs of stage kt+2 overwrite
     auto step_barrier = [&](int kt) {
+#ifdef SURS_G3_NO_DMA
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#else
         if (kt + 1 < ktiles)
-            asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     };
-    // Waves w and w+4 share a SIMD.  Waves 0-3 run barrier, phase 1, phase 2; waves 4-7 run barrier, phase 2 of the
-    // PREVIOUS step (its operands are in registers), phase 1: while one wave waits for its fragment reads or issues DMAs
-    // the other one has MFMAs to issue (step 5200 -> 4600 cycles, tools/gpu_gemm_trace.py; 3072 is the MFMA time).
-    if (wave < 4) {
+    // Waves w and w+4 (+8, +12) share a SIMD.  Half of them run barrier, phase 1, phase 2; the others barrier, phase 2 of
+    // the PREVIOUS step (its operands are in registers), phase 1: while one wave waits for its fragment reads or issues
+    // DMAs another one has MFMAs to issue (8 waves: step 5200 -> 4600 cycles, tools/gpu_gemm_trace.py; 3072 = MFMA time).
+    if (((wave >> 2) & 1) == 0) {
         for (int kt = 0; kt < ktiles; ++kt) {
             step_barrier(kt);
             phase1(kt);
@@ -782,14 +809,17 @@ __global__ __launch_bounds__(512) void gemm_x3g_kernel(const unsigned short *__r
         phase2(ktiles - 1);
     }
 
-    // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's 128, column 32j + li; bias, LeakyReLU, split,
+#undef G3_RD
+#undef G3_WAIT4
+#undef G3_WAIT2
+    // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's rows, column 32j + li; bias, LeakyReLU, split,
     // pair lanes l / l+32 so each owns 8 consecutive rows = 16 bytes of the next layer's operand (see gemm_x3s_kernel)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const long long n = n0 + wn * 64 + j * 32 + li;
-            const int mrow = m0 + wm * 128 + i * 32;
+            const int mrow = m0 + wm * (TI * 32) + i * 32;
             float v[16];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -966,12 +996,18 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
     if (Ys && M % 256 == 0 && np % 256 == 0 && gemm_use_big()) {
         static bool once = false;
         if (!once) {
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
             once = true;
         }
         const int nb256 = (int)(np / 256);
-        hipLaunchKernelGGL(gemm_x3g_kernel, dim3(gemm_grid(M / 256, nb256)), dim3(512), G3_LDS_BYTES, st, w3, M, K1 + K2, s1, s2, np,
-                           bias, Ys, (long long)M * np, nb256);
+        static const int nw = getenv("SURS_GEMM_WAVES") ? atoi(getenv("SURS_GEMM_WAVES")) : 8;
+        if (nw == 16)
+            hipLaunchKernelGGL(gemm_x3g_kernel<16>, dim3(gemm_grid(M / 256, nb256)), dim3(1024), G3_LDS_BYTES, st, w3, M, K1 + K2, s1,
+                               s2, np, bias, Ys, (long long)M * np, nb256);
+        else
+            hipLaunchKernelGGL(gemm_x3g_kernel<8>, dim3(gemm_grid(M / 256, nb256)), dim3(512), G3_LDS_BYTES, st, w3, M, K1 + K2, s1,
+                               s2, np, bias, Ys, (long long)M * np, nb256);
     } else if (Ys)
         hipLaunchKernelGGL(gemm_x3s_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, s1, s2, np, bias, 1, (float *)nullptr,
                            0LL, Ys, (long long)M * np, nblocks);
