@@ -153,24 +153,41 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
         const float *feat = is_hr ? feat_hr : feat_lr;
         const int H = is_hr ? hh : hl, W = is_hr ? wh : wl, C = is_hr ? C_HR : C_LR;
         const int c0 = is_hr ? 0 : chunk * 64;
-        for (int q = 0; q < 16; ++q) {
-            const int p = wave * 16 + q;
-            const float u = sx[p], v = sy[p];
-            const float ix = ((u + 1.0f) / 2.0f) * (float)(W - 1);
-            const float iy = ((v + 1.0f) / 2.0f) * (float)(H - 1);
-            const float fx = floorf(ix), fy = floorf(iy);
-            const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-            const float wnw = ((float)x1 - ix) * ((float)y1 - iy), wne = (ix - (float)x0) * ((float)y1 - iy);
-            const float wsw = ((float)x1 - ix) * (iy - (float)y0), wse = (ix - (float)x0) * (iy - (float)y0);
-            const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H,
-                       vy1 = y1 >= 0 && y1 < H;
-            float a = 0.0f;
-            const long long ch = c0 + lane;
-            if (vy0 && vx0) a += feat[((long long)y0 * W + x0) * C + ch] * wnw;
-            if (vy0 && vx1) a += feat[((long long)y0 * W + x1) * C + ch] * wne;
-            if (vy1 && vx0) a += feat[((long long)y1 * W + x0) * C + ch] * wsw;
-            if (vy1 && vx1) a += feat[((long long)y1 * W + x1) * C + ch] * wse;
-            tile[lane][p] = a;
+        // four points at a time, all 16 tap loads issued before the first use: with one workgroup per CU (the column
+        // batches of the sweep) the kernel is a chain of load latencies.  Taps outside the image are loaded from a
+        // clamped address and weighted with zero (zeros padding: the same sum).
+        for (int q0 = 0; q0 < 16; q0 += 4) {
+            float t[4][4], w[4][4];
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const int p = wave * 16 + q0 + u4;
+                const float u = sx[p], v = sy[p];
+                const float ix = ((u + 1.0f) / 2.0f) * (float)(W - 1);
+                const float iy = ((v + 1.0f) / 2.0f) * (float)(H - 1);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+                const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+                w[u4][0] = (vy0 && vx0) ? ((float)x1 - ix) * ((float)y1 - iy) : 0.0f;
+                w[u4][1] = (vy0 && vx1) ? (ix - (float)x0) * ((float)y1 - iy) : 0.0f;
+                w[u4][2] = (vy1 && vx0) ? ((float)x1 - ix) * (iy - (float)y0) : 0.0f;
+                w[u4][3] = (vy1 && vx1) ? (ix - (float)x0) * (iy - (float)y0) : 0.0f;
+                const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+                const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+                const long long ch = c0 + lane;
+                t[u4][0] = feat[((long long)cy0 * W + cx0) * C + ch];
+                t[u4][1] = feat[((long long)cy0 * W + cx1) * C + ch];
+                t[u4][2] = feat[((long long)cy1 * W + cx0) * C + ch];
+                t[u4][3] = feat[((long long)cy1 * W + cx1) * C + ch];
+            }
+#pragma unroll
+            for (int u4 = 0; u4 < 4; ++u4) {
+                float a = 0.0f;   // nw, ne, sw, se in this order, as grid_sample accumulates them
+                a += t[u4][0] * w[u4][0];
+                a += t[u4][1] * w[u4][1];
+                a += t[u4][2] * w[u4][2];
+                a += t[u4][3] * w[u4][3];
+                tile[lane][wave * 16 + q0 + u4] = a;
+            }
         }
         __syncthreads();
         const int cbase = is_hr ? C_LR : chunk * 64;
