@@ -136,6 +136,29 @@ def test_channel_split_kernels_match_point_split_kernel(tmp_path):
             assert d <= (1e-6 if (k.endswith("_lr") and ver == "3") else 2e-3), (ver, k, d)
 
 
+def test_layer_kernel_generations_agree(tmp_path):
+    """The fp32 point path has three layer-kernel generations behind environment switches: fp32 MFMA (SURS_GEMM_X3=0),
+    split-bf16 128x128 (SURS_GEMM_BIG=0), split-bf16 256x256 LDS-DMA with 8 (default) or 16 waves.  The split-bf16 kernels
+    accumulate the same six products per k step in the same order, so they agree bit for bit; against the fp32-MFMA kernel
+    the logits differ by summation order and the 24-bit operand split: <= 2e-5."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    ref = str(tmp_path / "default.npz")
+    for name, extra, mode in (("default", {}, "save"), ("small", {"SURS_GEMM_BIG": "0"}, "cmp"),
+                              ("waves16", {"SURS_GEMM_WAVES": "16"}, "cmp"), ("f32", {"SURS_GEMM_X3": "0"}, "cmp")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_points_cmp.py"), mode, ref],
+                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        if mode == "save":
+            continue
+        lines = [l for l in r.stdout.splitlines() if "max|diff|" in l]
+        assert len(lines) == 8, r.stdout
+        for l in lines:
+            d, eq = float(l.split("=")[1].split()[0]), l.rstrip().endswith("equal=1")
+            assert eq if name != "f32" else d <= 2e-5, (name, l)
+
+
 def test_multiview_and_perspective_vs_reference(setup, golden_dir):
     """num_views = 2 (orthogonal) and 3 (perspective) through surs_query_points_views against the outputs of the
     reference's own multi-view path (tests/golden/query_views.npz): 1e-4 on occupancies and logits."""
