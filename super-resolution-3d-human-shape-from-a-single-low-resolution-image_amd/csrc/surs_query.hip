@@ -910,6 +910,28 @@ __global__ __launch_bounds__(256) void mean_views_kernel(const float *__restrict
     out[t] = acc * inv;
 }
 
+// fp32 k-major X[16 * ktiles][ld] -> its split image [3][ktiles][ld][16] (the view means of the multi-view path)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, long long ld, int ktiles,
+                                                         unsigned short *__restrict__ Xs, long long part) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int kt = blockIdx.y;
+    if (n >= ld) return;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        u16x8_t q0, q1, q2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned short a, b, c;
+            split3_bf16(X[(long long)(16 * kt + 8 * half + j) * ld + n], a, b, c);
+            q0[j] = a; q1[j] = b; q2[j] = c;
+        }
+        unsigned short *dst = Xs + ((long long)kt * ld + n) * 16 + half * 8;
+        *reinterpret_cast<u16x8_t *>(dst) = q0;
+        *reinterpret_cast<u16x8_t *>(dst + part) = q1;
+        *reinterpret_cast<u16x8_t *>(dst + 2 * part) = q2;
+    }
+}
+
 // multi-view last layer: one logit per point from the view means; every view gets it under its own in-image mask
 // (SuRSNet.py:156,183: `in_img[:, None].float() * mlp(...)` broadcasts the [1,1,N] prediction over the V masks)
 __global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__restrict__ w4, const float *__restrict__ Y3,
@@ -917,7 +939,9 @@ __global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__rest
                                                              int nviews, const float *__restrict__ mask /*[V][ld]*/,
                                                              float *__restrict__ pred /*[V][n]*/, float *__restrict__ logit,
                                                              float *__restrict__ p_slot /*row 321 of view 0's F*/,
-                                                             long long f_view_stride) {
+                                                             long long f_view_stride,
+                                                             unsigned short *__restrict__ Fs /*view 0's split image*/,
+                                                             long long fs_part) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     float acc = w4[D4 + C0PAD];
@@ -929,6 +953,14 @@ __global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__rest
         const float p = mask[(long long)v * ld + t] * y;
         pred[(long long)v * n + t] = p;
         if (p_slot) p_slot[(long long)v * f_view_stride + t] = p;
+        if (Fs) {   // a view's split image follows the previous view's three parts
+            unsigned short a, b, c;
+            split3_bf16(p, a, b, c);
+            unsigned short *dst = Fs + (long long)v * 3 * fs_part + ((long long)(C_G / 16) * ld + t) * 16 + 1;
+            dst[0] = a;
+            dst[fs_part] = b;
+            dst[2 * fs_part] = c;
+        }
     }
 }
 
@@ -1405,11 +1437,13 @@ extern "C" int surs_query_points(const float *points, int n, const float *calib,
 // ------------------------------------------------------------------------------------------------
 static size_t views_ws_bytes(long long np, int nviews) {
     // per view: F (C0PAD rows), Y2 (D3 rows), mask; shared: Y0, Y1, Y3, mean F, mean Y2
-    return ((size_t)nviews * (C0PAD + D3 + 1) + (D1 + D2 + D4 + C0PAD + D3)) * (size_t)np * sizeof(float) + 4096;
+    // + the split images of the split-bf16 layer kernels: every view's F, Y0, Y1, the two means
+    return ((size_t)nviews * (C0PAD + D3 + 1) + (D1 + D2 + D4 + C0PAD + D3)) * (size_t)np * sizeof(float) +
+           ((size_t)nviews * C0PAD + D1 + D2 + D3 + C0PAD) * (size_t)np * 6 + 4096;
 }
 
 extern "C" size_t surs_query_views_workspace_bytes(int max_points, int num_views) {
-    return views_ws_bytes((long long)ceil_div(max_points, 128) * 128, num_views < 1 ? 1 : num_views);
+    return views_ws_bytes((long long)ceil_div(max_points, 256) * 256, num_views < 1 ? 1 : num_views);
 }
 
 extern "C" int surs_query_points_views(const float *points, int n, int num_views, int projection, const float *calibs,
@@ -1423,7 +1457,7 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
     SURS_REQUIRE(points && calibs && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
     SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
     hipStream_t st = as_stream(stream);
-    const long long np = (long long)ceil_div(n, 128) * 128;
+    const long long np = (long long)ceil_div(n, 256) * 256;
     SURS_REQUIRE(workspace_bytes >= views_ws_bytes(np, num_views), "workspace too small: need %zu bytes",
                  views_ws_bytes(np, num_views));
     const MlpBlobHeader h = blob_layout(SURS_BF16);
@@ -1437,8 +1471,15 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
     float *Y1 = p;     p += (size_t)D2 * np;
     float *Y3 = p;     p += (size_t)D4 * np;
     float *Fm = p;     p += (size_t)C0PAD * np;
-    float *Y2m = p;
+    float *Y2m = p;    p += (size_t)D3 * np;
     const long long fstride = (long long)C0PAD * np;
+    const bool x3 = gemm_use_x3();
+    unsigned short *q = (unsigned short *)p;
+    unsigned short *Fs = q;   q += (size_t)V * 3 * fstride;   // [V][3][C0PAD/16][np][16]
+    unsigned short *Y0s = q;  q += (size_t)3 * D1 * np;
+    unsigned short *Y1s = q;  q += (size_t)3 * D2 * np;
+    unsigned short *Y2ms = q; q += (size_t)3 * D3 * np;
+    unsigned short *Fms = q;
     // gather every view with its own calibration and feature maps; zero the padding rows of every F
     for (int v = 0; v < V; ++v) {
         float *Fv = F + (size_t)v * fstride;
@@ -1452,7 +1493,8 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
         fill_calib(src, calibs + 12 * v, zmul, zdiv);
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
                            feat_lr + (size_t)v * hl * wl * C_LR, hl, wl, feat_hr + (size_t)v * hh * wh * C_HR, hh, wh, Fv, np,
-                           mask + (size_t)v * np, (float *)nullptr, (unsigned short *)nullptr, 0LL);
+                           mask + (size_t)v * np, (float *)nullptr, x3 ? Fs + (size_t)v * 3 * fstride : (unsigned short *)nullptr,
+                           fstride);
         SURS_LAUNCH_CHECK();
     }
     for (int m = 0; m < 2; ++m) {
@@ -1460,7 +1502,13 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
         auto W3 = [&](int l) { return (const void *)(blob + h.wt3[m][l]); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
-        for (int v = 0; v < V; ++v) {
+        for (int v = 0; v < V && x3; ++v) {   // split images between the layers, fp32 out of layer 2 for the mean
+            const unsigned short *Fsv = Fs + (size_t)v * 3 * fstride;
+            if ((rc = launch_gemm_s(st, W3(0), D1, Fsv, C0PAD, nullptr, 0, BI(0), nullptr, Y0s, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(1), D2, Y0s, D1, nullptr, 0, BI(1), nullptr, Y1s, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(2), D3, Y1s, D2, Fsv, C0PAD, BI(2), Y2 + (size_t)v * D3 * np, nullptr, np))) return rc;
+        }
+        for (int v = 0; v < V && !x3; ++v) {
             const float *Fv = F + (size_t)v * fstride;
             if ((rc = launch_gemm(st, false, WT(0), W3(0), D1, Fv, C0PAD, np, nullptr, 0, 0, BI(0), 1, Y0, np, np))) return rc;
             if ((rc = launch_gemm(st, false, WT(1), W3(1), D2, Y0, D1, np, nullptr, 0, 0, BI(1), 1, Y1, np, np))) return rc;
@@ -1475,10 +1523,20 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
         hipLaunchKernelGGL(mean_views_kernel, dim3((unsigned)ceil_div(fstride, 256)), dim3(256), 0, st, F, fstride, V, fstride,
                            inv, Fm);
         SURS_LAUNCH_CHECK();
-        if ((rc = launch_gemm(st, false, WT(3), W3(3), D4, Y2m, D3, np, Fm, C0PAD, np, BI(3), 1, Y3, np, np))) return rc;
+        if (x3) {
+            hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)ceil_div(np, 256), D3 / 16), dim3(256), 0, st, Y2m, np, D3 / 16,
+                               Y2ms, (long long)D3 * np);
+            SURS_LAUNCH_CHECK();
+            hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)ceil_div(np, 256), C0PAD / 16), dim3(256), 0, st, Fm, np,
+                               C0PAD / 16, Fms, fstride);
+            SURS_LAUNCH_CHECK();
+            if ((rc = launch_gemm_s(st, W3(3), D4, Y2ms, D3, Fms, C0PAD, BI(3), Y3, nullptr, np))) return rc;
+        } else if ((rc = launch_gemm(st, false, WT(3), W3(3), D4, Y2m, D3, np, Fm, C0PAD, np, BI(3), 1, Y3, np, np)))
+            return rc;
         hipLaunchKernelGGL(mlp_last_views_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                            (const float *)(blob + h.w4[m]), Y3, Fm, np, (long long)n, V, mask, m == 0 ? pred_lr : pred_hr,
-                           m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride);
+                           m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride,
+                           (m == 0 && x3) ? Fs : (unsigned short *)nullptr, fstride);
         SURS_LAUNCH_CHECK();
     }
     return 0;
