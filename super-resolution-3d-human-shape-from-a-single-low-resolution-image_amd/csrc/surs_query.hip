@@ -661,15 +661,23 @@ __global__ __launch_bounds__(256) void gemm_x3s_kernel(const unsigned short *__r
 // with counted lgkmcnt waits, the step barrier is a raw s_barrier behind `s_waitcnt vmcnt(6)` = "my DMAs of this step
 // have landed, those of the next may still fly"; the compiler sees no LDS read and therefore adds no vmcnt(0) of its own.
 // ------------------------------------------------------------------------------------------------
-constexpr int G3_STAGE = 49152, G3_STAGES = 3, G3_LDS_BYTES = G3_STAGE * G3_STAGES;
+constexpr int G3_STAGES = 3;
+constexpr int g3_stage_bytes(int bm) { return 3 * (bm / 32) * 1024 + 24576; }   // weights [3][bm/32] + points [3][8] pieces
+constexpr int g3_lds_bytes(int bm) { return G3_STAGES * g3_stage_bytes(bm); }
 
-// NW = 8 waves (2 x 4, wave tile 128 x 64) or 16 waves (4 x 4, wave tile 64 x 64, 4 waves per SIMD)
-template <int NW>
+// NW = 8 waves (2 x 4) or 16 waves (4 x 4, 4 waves per SIMD; BM = 256 only); BM = 256 or 128 rows per workgroup (128: the
+// last hidden layer, M = 128); SPLIT_OUT: split image for the next layer, or fp32 [m][n] (in front of mlp_last_kernel / the
+// view mean).  The tile is always 256 points wide.
+template <int NW, int BM, bool SPLIT_OUT>
 __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
                                                            SplitSeg s2, long long np, const float *__restrict__ bias,
-                                                           unsigned short *__restrict__ Ys, long long ys_part, int nblocks) {
-    constexpr int TI = 32 / NW;       // MFMA row tiles per wave
-    constexpr int NDMA = 48 / NW;     // DMAs per wave and stage
+                                                           float *__restrict__ Y, unsigned short *__restrict__ Ys,
+                                                           long long ys_part, int nblocks) {
+    constexpr int AP = BM / 32;              // weight pieces per part and stage
+    constexpr int TI = AP / (NW / 4);        // MFMA row tiles per wave
+    constexpr int ASZ = 3 * AP * 1024;       // bytes of weights per stage; the points follow
+    constexpr int G3_STAGE = g3_stage_bytes(BM);
+    static_assert(TI == 4 || TI == 2, "wave tile is 128 or 64 rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
     typedef __attribute__((address_space(3))) unsigned char lds_u8;
     typedef const __attribute__((address_space(1))) void gptr_t;
@@ -677,15 +685,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
     const int wm = wave >> 2, wn = wave & 3;
     const int kh = lane >> 5, li = lane & 31;
     int mb, nb;
-    {   // same XCD-aware order as gemm_block_tile, on 256-wide tiles
-        const unsigned mblocks = (unsigned)M / 256u, total = mblocks * (unsigned)nblocks, per = gridDim.x >> 3;
+    {   // same XCD-aware order as gemm_block_tile
+        const unsigned mblocks = (unsigned)M / (unsigned)BM, total = mblocks * (unsigned)nblocks, per = gridDim.x >> 3;
         const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
         if (logical >= total) return;
         mb = (int)(logical % mblocks);
         nb = (int)(logical / mblocks);
     }
     const long long n0 = (long long)nb * 256;
-    const int m0 = mb * 256;
+    const int m0 = mb * BM;
     const int ktiles = s1.ktiles + s2.ktiles;
     const size_t per_part = (size_t)Ktot * M;
     lds_u8 *smem = (lds_u8 *)g3_smem;
@@ -699,37 +707,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // DMA d of this wave and step kt.  8 waves: piece `wave` of part d>>1 of the weights (d even) / points (d odd);
-    // 16 waves: waves 0-7 piece `wave` of part d of the weights, waves 8-15 piece `wave - 8` of part d of the points.
+    // DMA d of this wave and step kt, nd per wave and stage (a multiple of 3: one third goes out behind each product):
+    //   8 waves, BM 256: piece `wave` of part d>>1 of the weights (d even) / points (d odd), nd = 6;
+    //   8 waves, BM 128: the same for waves 0-3; waves 4-7 piece `wave` of part d of the points only, nd = 3;
+    //   16 waves: waves 0-7 piece `wave` of part d of the weights, waves 8-15 piece `wave - 8` of part d of the points, nd = 3.
     // A points piece is fetched with lane (h, r) on half h of row r, so it lands in LDS in fragment order like the weights.
     const int piece = wave & 7;
+    const bool both = NW == 8 && (BM == 256 || wave < 4);
+    const int nd = both ? 6 : 3;
     const unsigned short *wsrc = W3 + ((size_t)(m0 + 32 * piece)) * 16 + lane * 8;
     auto issue1 = [&](int kt, int d) {
-        const int p = NW == 8 ? d >> 1 : d;
-        const bool points = NW == 8 ? (d & 1) : (wave >= 8);
-        lds_u8 *dst = smem + (kt % G3_STAGES) * G3_STAGE + piece * 1024 + p * 8192;
+        const int p = both ? d >> 1 : d;
+        const bool points = both ? (d & 1) : (NW == 8 || wave >= 8);
+        lds_u8 *stage = smem + (kt % G3_STAGES) * G3_STAGE + piece * 1024;
         if (!points) {
             const unsigned short *wk = wsrc + (size_t)kt * M * 16 + p * per_part;
-            __builtin_amdgcn_global_load_lds((gptr_t *)wk, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)wk, (__attribute__((address_space(3))) void *)(stage + p * (AP * 1024)), 16, 0, 0);
         } else {
             const bool first = kt < s1.ktiles;
             const unsigned short *xb = first ? s1.base : s2.base;
             const long long xpart = first ? s1.part : s2.part;
             const int k = first ? kt : kt - s1.ktiles;
             const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * piece) * 16 + (li * 16 + kh * 8) + p * xpart;
-            __builtin_amdgcn_global_load_lds((gptr_t *)xsrc, (__attribute__((address_space(3))) void *)(dst + 24576), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)xsrc, (__attribute__((address_space(3))) void *)(stage + ASZ + p * 8192), 16, 0, 0);
         }
     };
     auto issue = [&](int kt) {
-#pragma unroll
-        for (int d = 0; d < NDMA; ++d) issue1(kt, d);
+        for (int d = 0; d < nd; ++d) issue1(kt, d);
     };
 
     issue(0);
     if (ktiles > 1) issue(1);
     // fragment addresses inside a stage: weights piece TI wm + i, points piece 2 wn + j, both at lane * 16
     const unsigned a_off = lds0 + (unsigned)(wm * TI * 1024 + lane * 16);
-    const unsigned b_off = lds0 + 24576u + (unsigned)(wn * 2048 + lane * 16);
+    const unsigned b_off = lds0 + (unsigned)ASZ + (unsigned)(wn * 2048 + lane * 16);
     bf16x8_t a[TI][3], b[2][3];
     auto mm = [&](int pa, int pb) {
 #pragma unroll
@@ -741,7 +752,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
 #ifdef SURS_G3_NO_LDS   // experiment: timing without the fragment reads (results are wrong)
 #define G3_RD(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr) : "memory")
 #else
-#define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+#define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #endif
 // waits for everything but the n youngest LDS reads; naming the fragments ties their uses to the wait
 #define G3_WAIT4(n, pa, pb) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0][pa]), "+v"(a[1][pa]), "+v"(a[2][pa]), "+v"(a[3][pa]), "+v"(b[0][pb]), "+v"(b[1][pb]))
@@ -759,11 +770,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
         const unsigned sa = a_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
         const unsigned sb = b_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
         GEMM_STAMP(0);
-        G3_RD(a[0][2], sa, 16384); G3_RD(a[1][2], sa, 17408);
-        if constexpr (TI == 4) { G3_RD(a[2][2], sa, 18432); G3_RD(a[3][2], sa, 19456); }
+        constexpr int PA = AP * 1024;   // bytes between the weight parts of a stage
+        G3_RD(a[0][2], sa, 2 * PA); G3_RD(a[1][2], sa, 2 * PA + 1024);
+        if constexpr (TI == 4) { G3_RD(a[2][2], sa, 2 * PA + 2048); G3_RD(a[3][2], sa, 2 * PA + 3072); }
         G3_RD(b[0][0], sb, 0);     G3_RD(b[1][0], sb, 1024);
-        G3_RD(a[0][1], sa, 8192);  G3_RD(a[1][1], sa, 9216);
-        if constexpr (TI == 4) { G3_RD(a[2][1], sa, 10240); G3_RD(a[3][1], sa, 11264); }
+        G3_RD(a[0][1], sa, PA);  G3_RD(a[1][1], sa, PA + 1024);
+        if constexpr (TI == 4) { G3_RD(a[2][1], sa, PA + 2048); G3_RD(a[3][1], sa, PA + 3072); }
         G3_RD(b[0][1], sb, 8192);  G3_RD(b[1][1], sb, 9216);
         G3_RD(a[0][0], sa, 0);     G3_RD(a[1][0], sa, 1024);
         if constexpr (TI == 4) { G3_RD(a[2][0], sa, 2048); G3_RD(a[3][0], sa, 3072); }
@@ -773,17 +785,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
         mm(2, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (more)
-            for (int d = 0; d < NDMA / 3; ++d) issue1(kt + 2, d);
+            for (int d = 0; d < nd / 3; ++d) issue1(kt + 2, d);
         if constexpr (TI == 4) G3_WAIT4(6, 1, 1); else G3_WAIT2(4, 1, 1);
         mm(1, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (more)
-            for (int d = NDMA / 3; d < 2 * NDMA / 3; ++d) issue1(kt + 2, d);
+            for (int d = nd / 3; d < 2 * nd / 3; ++d) issue1(kt + 2, d);
         if constexpr (TI == 4) G3_WAIT4(0, 0, 2); else G3_WAIT2(0, 0, 2);
         mm(0, 2);
         __builtin_amdgcn_sched_barrier(0);
         if (more)
-            for (int d = 2 * NDMA / 3; d < NDMA; ++d) issue1(kt + 2, d);
+            for (int d = 2 * nd / 3; d < nd; ++d) issue1(kt + 2, d);
         GEMM_STAMP(2);
     };
     auto phase2 = [&](int kt) {
@@ -800,7 +812,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #else
         if (kt + 1 < ktiles)
-            if constexpr (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            if (nd == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -845,6 +857,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short 
                     float t = acc[i][j][4 * g + r] + bias[mrow + 8 * g + 4 * kh + r];
                     v[4 * g + r] = t > 0.0f ? t : 0.01f * t;
                 }
+            if constexpr (!SPLIT_OUT) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Y[(long long)(mrow + 8 * g + 4 * kh + r) * np + n] = v[4 * g + r];
+            } else
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 unsigned e[3][2], o[3][2];
@@ -1042,21 +1060,31 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
     const int nblocks = (int)(np / 128);
     dim3 grid(gemm_grid(M / 128, nblocks));
     const unsigned short *w3 = (const unsigned short *)W3;
-    if (Ys && M % 256 == 0 && np % 256 == 0 && gemm_use_big()) {
+    if (np % 256 == 0 && gemm_use_big() && (M % 256 == 0 || !Ys)) {
+        // 256-point tiles: 256 rows per workgroup where M allows, else 128 (fp32 output only: the last hidden layer)
         static bool once = false;
         if (!once) {
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES));
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
             once = true;
         }
         const int nb256 = (int)(np / 256);
         static const int nw = getenv("SURS_GEMM_WAVES") ? atoi(getenv("SURS_GEMM_WAVES")) : 8;
-        if (nw == 16)
-            hipLaunchKernelGGL(gemm_x3g_kernel<16>, dim3(gemm_grid(M / 256, nb256)), dim3(1024), G3_LDS_BYTES, st, w3, M, K1 + K2, s1,
-                               s2, np, bias, Ys, (long long)M * np, nb256);
+        const long long yp = (long long)M * np;
+        if (Ys && nw == 16)
+            hipLaunchKernelGGL((gemm_x3g_kernel<16, 256, true>), dim3(gemm_grid(M / 256, nb256)), dim3(1024), g3_lds_bytes(256), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, (float *)nullptr, Ys, yp, nb256);
+        else if (Ys)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, true>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, (float *)nullptr, Ys, yp, nb256);
+        else if (M % 256 == 0)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, false>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, Y, (unsigned short *)nullptr, 0LL, nb256);
         else
-            hipLaunchKernelGGL(gemm_x3g_kernel<8>, dim3(gemm_grid(M / 256, nb256)), dim3(512), G3_LDS_BYTES, st, w3, M, K1 + K2, s1,
-                               s2, np, bias, Ys, (long long)M * np, nb256);
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, false>), dim3(gemm_grid(M / 128, nb256)), dim3(512), g3_lds_bytes(128), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, Y, (unsigned short *)nullptr, 0LL, nb256);
     } else if (Ys)
         hipLaunchKernelGGL(gemm_x3s_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, s1, s2, np, bias, 1, (float *)nullptr,
                            0LL, Ys, (long long)M * np, nblocks);
