@@ -218,678 +218,7 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Workgroup -> output tile for the layer GEMMs.  The point tile (128 columns of X, up to 1360 x 128 values) is the big
-// operand and every row block of the layer re-reads it, so the row blocks of one point tile must run together and on
-// ONE XCD (its L2 then serves the re-reads; with the row index slow every layer read its input M/128 times from HBM).
-// Workgroup ids go round-robin over the 8 XCDs: XCD x takes the logical range [x*per, (x+1)*per), row block fastest.
-// The grid is 8*per workgroups, per = ceil(mblocks*nblocks / 8).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool gemm_block_tile(int mblocks, int nblocks, int &mb, int &nb) {
-    const unsigned total = (unsigned)mblocks * (unsigned)nblocks, per = gridDim.x >> 3;
-    const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    mb = (int)(logical % (unsigned)mblocks);
-    nb = (int)(logical / (unsigned)mblocks);
-    return logical < total;
-}
-
-static inline unsigned gemm_grid(int mblocks, long long nblocks) {
-    const long long total = (long long)mblocks * nblocks;
-    return (unsigned)(((total + 7) / 8) * 8);
-}
-
-// ------------------------------------------------------------------------------------------------
-// fp32 GEMM on MFMA:  Y[m][n] = act( sum_k Wt[k][m] * X[k][n] + bias[m] ),  k over two segments (X1 then X2)
-//   M, N multiples of 128; K1, K2 multiples of 16.  128x128 block tile, BK = 16, 4 waves as 2x2, each wave
-//   64x64 = 2x2 tiles of v_mfma_f32_32x32x2_f32.  Operands are k-major in global memory and in LDS, so global
-//   loads are 512 B coalesced per row and LDS fragment reads are conflict-free consecutive dwords.
-// ------------------------------------------------------------------------------------------------
-template <bool TRANSPOSED_OUT>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float *__restrict__ Wt, int M,
-                                                       const float *__restrict__ X1, int K1, long long ld1,
-                                                       const float *__restrict__ X2, int K2, long long ld2,
-                                                       const float *__restrict__ bias, int act,
-                                                       float *__restrict__ Y, long long ldy, int nblocks) {
-    __shared__ __attribute__((aligned(16))) float As[2][16][128];
-    __shared__ __attribute__((aligned(16))) float Bs[2][16][128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int mb, nb;
-    if (!gemm_block_tile(M / 128, nblocks, mb, nb)) return;
-    const long long n0 = (long long)nb * 128;
-    const int m0 = mb * 128;
-    const int ktiles = (K1 + K2) / 16;
-    const int lrow = tid >> 5, lcol = (tid & 31) * 4;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    f32x4 ra[2], rb[2];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * 16;
-        const float *X;
-        long long ld;
-        int kx;
-        if (k0 < K1) { X = X1; ld = ld1; kx = k0; } else { X = X2; ld = ld2; kx = k0 - K1; }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = lrow + 8 * i;
-            ra[i] = *reinterpret_cast<const f32x4 *>(Wt + (long long)(k0 + row) * M + m0 + lcol);
-            rb[i] = *reinterpret_cast<const f32x4 *>(X + (long long)(kx + row) * ld + n0 + lcol);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = lrow + 8 * i;
-            *reinterpret_cast<f32x4 *>(&As[buf][row][lcol]) = ra[i];
-            *reinterpret_cast<f32x4 *>(&Bs[buf][row][lcol]) = rb[i];
-        }
-    };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ktiles) load_tile(kt + 1);
-        const int kh = lane >> 5, li = lane & 31;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = As[buf][2 * kk + kh][wm * 64 + i * 32 + li];
-                b[i] = Bs[buf][2 * kk + kh][wn * 64 + i * 32 + li];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < ktiles) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-    // epilogue: acc[i][j][r] is row m = (r&3) + 8*(r>>2) + 4*(lane>>5), column n = lane&31 of its 32x32 tile
-    const int kh = lane >> 5, li = lane & 31;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long n = n0 + wn * 64 + j * 32 + li;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int m = m0 + wm * 64 + i * 32 + 8 * g + 4 * kh;
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][4 * g + r] + (bias ? bias[m + r] : 0.0f);
-                    if (act == 1) t = t > 0.0f ? t : 0.01f * t;
-                    v[r] = t;
-                }
-                if (TRANSPOSED_OUT) {
-                    *reinterpret_cast<f32x4 *>(Y + n * ldy + m) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Y[(long long)(m + r) * ldy + n] = v[r];
-                }
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same GEMM on the bf16 matrix pipe with fp32 accuracy (see conv_x3_kernel in surs_encoder.hip): every operand as
-// three exact bf16 parts, the six significant partial products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -
-// 2.7x the rate of v_mfma_f32_32x32x2_f32.  W3: the packer's split image of Wt, [3][K/16][M/32][2][32][8] = MFMA A-fragment
-// order (surs_pack.cpp), so a 128-row tile of one k step is 4 KB contiguous and thread t stages its t-th 16 bytes.
-// column (8 coalesced dword loads), splits them and stores three 16-byte fragments pieces, i.e. the transposition
-// happens in registers.  LDS rows have a 48-byte pitch (conflict-free ds_read_b128 across 32 rows).
-// ------------------------------------------------------------------------------------------------
-template <bool TRANSPOSED_OUT>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(const unsigned short *__restrict__ W3, int M, int Ktot,
-                                                      const float *__restrict__ X1, int K1, long long ld1,
-                                                      const float *__restrict__ X2, int K2, long long ld2,
-                                                      const float *__restrict__ bias, int act,
-                                                      float *__restrict__ Y, long long ldy, int nblocks) {
-    constexpr int PITCH = 24;   // halfwords per row (48 B)
-    __shared__ __attribute__((aligned(16))) unsigned short At[2][3][128][PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][3][128][PITCH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    int mb, nb;
-    if (!gemm_block_tile(M / 128, nblocks, mb, nb)) return;
-    const long long n0 = (long long)nb * 128;
-    const int m0 = mb * 128;
-    const int ktiles = (K1 + K2) / 16;
-    const size_t per_part = (size_t)Ktot * M;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // staging roles: A: thread t copies 16 bytes (half a row) of each part; X: thread (n = t & 127, h = t >> 7) owns
-    // k = 8h..8h+7 of column n
-    const int arow = (tid >> 6) * 32 + (tid & 31), ahalf = (tid >> 5) & 1;
-    const int xn = tid & 127, xh = tid >> 7;
-    f32x4 ra[3];
-    float rx[8];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * 16;
-        const float *X;
-        long long ld;
-        int kx;
-        if (k0 < K1) { X = X1; ld = ld1; kx = k0; } else { X = X2; ld = ld2; kx = k0 - K1; }
-#pragma unroll
-        for (int p = 0; p < 3; ++p)   // fragment-ordered image: thread t copies the t-th 16 bytes of the 4 KB tile
-            ra[p] = *reinterpret_cast<const f32x4 *>(W3 + p * per_part + ((size_t)kt * M + m0) * 16 + tid * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rx[j] = X[(long long)(kx + 8 * xh + j) * ld + n0 + xn];
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4 *>(&At[buf][p][arow][ahalf * 8]) = ra[p];
-        u16x8_t q0, q1, q2;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned short a, b, c;
-            split3_bf16(rx[j], a, b, c);
-            q0[j] = a; q1[j] = b; q2[j] = c;
-        }
-        *reinterpret_cast<u16x8_t *>(&Xt[buf][0][xn][xh * 8]) = q0;
-        *reinterpret_cast<u16x8_t *>(&Xt[buf][1][xn][xh * 8]) = q1;
-        *reinterpret_cast<u16x8_t *>(&Xt[buf][2][xn][xh * 8]) = q2;
-    };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    const int kh = lane >> 5, li = lane & 31;
-    for (int kt = 0; kt < ktiles; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < ktiles) load_tile(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs
-        bf16x8_t a[2][3], b[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[i][p] = *reinterpret_cast<const bf16x8_t *>(&At[buf][p][wm * 64 + i * 32 + li][kh * 8]);
-                b[i][p] = *reinterpret_cast<const bf16x8_t *>(&Xt[buf][p][wn * 64 + i * 32 + li][kh * 8]);
-            }
-        // the six partial products, smallest first (weight part, activation part); consecutive MFMAs on different tiles
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < ktiles) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-    // epilogue: acc[i][j][r] is row m = (r&3) + 8*(r>>2) + 4*(lane>>5), column n = lane&31 of its 32x32 tile
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long n = n0 + wn * 64 + j * 32 + li;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int m = m0 + wm * 64 + i * 32 + 8 * g + 4 * kh;
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][4 * g + r] + (bias ? bias[m + r] : 0.0f);
-                    if (act == 1) t = t > 0.0f ? t : 0.01f * t;
-                    v[r] = t;
-                }
-                if (TRANSPOSED_OUT) {
-                    *reinterpret_cast<f32x4 *>(Y + n * ldy + m) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Y[(long long)(m + r) * ldy + n] = v[r];
-                }
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The layer kernel of the fp32 point path: both operands arrive as split images, the output leaves as one.
-//   Ys[m][n] = split(act(sum_k W[k][m] X[k][n] + bias[m]))   or   Y[m][n] fp32 (the layer in front of mlp_last_kernel)
-// Same 128x128 block / 2x2 waves / 2x2 MFMA tiles as above, but per 16-k step a thread issues only 16-byte moves:
-//   weights  6 global loads (3 parts x 2 row tiles) straight into the MFMA A registers - a wave's loads cover 1 KB
-//            contiguous, the 2 waves sharing the rows hit L1/L2 - prefetched one step ahead;
-//   points   3 global loads -> 3 LDS stores (the 128 x 16 x 3 activation tile, 48-byte pitch), 6 LDS fragment reads;
-// and 24 MFMAs.  No conversion work in the loop: the producer (gather_kernel, this kernel's epilogue) stores the parts.
-// The epilogue pairs the accumulator groups of lanes l and l+32 (v_permlane32_swap) so every lane owns 8 consecutive
-// output rows = one 16-byte piece of the next layer's operand per part.
-// ------------------------------------------------------------------------------------------------
-#ifdef SURS_GEMM_TRACE
-__device__ unsigned long long g_gemm_trace[4 * 16];
-#define GEMM_STAMP(i)                                                                                          \
-    do {                                                                                                       \
-        if (kt >= 8 && kt < 24 && tid == 0 && blockIdx.x == (gridDim.x / 16) * 8 + 3)                            \
-            g_gemm_trace[4 * (kt - 8) + (i)] = __builtin_readcyclecounter();                                   \
-    } while (0)
-#else
-#define GEMM_STAMP(i) do { } while (0)
-#endif
-
-struct SplitSeg {
-    const unsigned short *base;   // [3][ktiles][np][16]
-    long long part;               // halfwords between parts
-    int ktiles;
-};
-
-template <bool SPLIT_OUT>
-__global__ __launch_bounds__(256) void gemm_x3s_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
-                                                       SplitSeg s2, long long np, const float *__restrict__ bias, int act,
-                                                       float *__restrict__ Y, long long ldy,
-                                                       unsigned short *__restrict__ Ys, long long ys_part, int nblocks) {
-    constexpr int PITCH = 24;
-    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][3][128][PITCH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kh = lane >> 5, li = lane & 31;
-    int mb, nb;
-    if (!gemm_block_tile(M / 128, nblocks, mb, nb)) return;
-    const long long n0 = (long long)nb * 128;
-    const int m0 = mb * 128;
-    const int ktiles = s1.ktiles + s2.ktiles;
-    const size_t per_part = (size_t)Ktot * M;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const unsigned short *wlane = W3 + ((size_t)(m0 + wm * 64)) * 16 + lane * 8;   // fragment-ordered image
-    const int xr = tid >> 1, xhalf = tid & 1;
-    auto load_w = [&](int kt, bf16x8_t (&a)[2][3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i][p] = *reinterpret_cast<const bf16x8_t *>(wlane + p * per_part + ((size_t)kt * M + i * 32) * 16);
-    };
-    auto load_x = [&](int kt, f32x4 (&rx)[3]) {
-        const bool first = kt < s1.ktiles;
-        const unsigned short *b = first ? s1.base : s2.base;
-        const long long part = first ? s1.part : s2.part;
-        const int k = first ? kt : kt - s1.ktiles;
-        const unsigned short *src = b + ((long long)k * np + n0 + xr) * 16 + xhalf * 8;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) rx[p] = *reinterpret_cast<const f32x4 *>(src + p * part);
-    };
-    auto store_x = [&](int buf, const f32x4 (&rx)[3]) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<f32x4 *>(&Xt[buf][p][xr][xhalf * 8]) = rx[p];
-    };
-    // step kt: MFMAs on LDS buffer kt&1 and a; issues the weight loads of step kt+1 (-> an) and the point loads of step
-    // kt+2 (-> xn: HBM latency under load is about two steps); stores the point tile of step kt+1 (xs, loaded one step
-    // ago) into the other buffer.  Weights first: the counters retire in order and the weights are needed first.
-    auto step = [&](auto full, int kt, const bf16x8_t (&a)[2][3], bf16x8_t (&an)[2][3], const f32x4 (&xs)[3], f32x4 (&xn)[3]) {
-        const int buf = kt & 1;
-        GEMM_STAMP(0);
-        if (full.value || kt + 1 < ktiles) load_w(kt + 1, an);
-        if (full.value || kt + 2 < ktiles) load_x(kt + 2, xn);
-        // the scheduler otherwise sinks the prefetch below the MFMAs and exposes its whole latency
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_STAMP(1);
-        bf16x8_t b[2][3];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                b[j][p] = *reinterpret_cast<const bf16x8_t *>(&Xt[buf][p][wn * 64 + j * 32 + li][kh * 8]);
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_STAMP(2);
-        if (full.value || kt + 1 < ktiles) store_x(buf ^ 1, xs);
-        GEMM_STAMP(3);
-        __syncthreads();
-    };
-    using Yes = std::integral_constant<bool, true>;
-    using No = std::integral_constant<bool, false>;
-
-    bf16x8_t a0[2][3], a1[2][3];
-    f32x4 x0[3], x1[3];
-    load_w(0, a0);
-    load_x(0, x0);
-    if (ktiles > 1) load_x(1, x1);
-    store_x(0, x0);
-    __syncthreads();
-    // x1 holds the tile of step 1; step kt stores the set loaded in step kt-1 and loads into the other one
-    int kt = 0;
-    for (; kt + 3 < ktiles; kt += 2) {   // both steps prefetch unconditionally
-        step(Yes(), kt, a0, a1, x1, x0);
-        step(Yes(), kt + 1, a1, a0, x0, x1);
-    }
-    for (; kt + 1 < ktiles; kt += 2) {
-        step(No(), kt, a0, a1, x1, x0);
-        step(No(), kt + 1, a1, a0, x0, x1);
-    }
-    if (kt < ktiles) step(No(), kt, a0, a1, x1, x0);
-
-    // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's 64, column 32j + li
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long n = n0 + wn * 64 + j * 32 + li;
-            const int mrow = m0 + wm * 64 + i * 32;
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][4 * g + r] + (bias ? bias[mrow + 8 * g + 4 * kh + r] : 0.0f);
-                    if (act == 1) t = t > 0.0f ? t : 0.01f * t;
-                    v[4 * g + r] = t;
-                }
-            if (!SPLIT_OUT) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Y[(long long)(mrow + 8 * g + 4 * kh + r) * ldy + n] = v[4 * g + r];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {   // 16 output rows = one k-tile of the next layer
-                    unsigned e[3][2], o[3][2];  // packed parts of groups g = 2q (rows 4kh..4kh+3) and 2q+1 (8+4kh..)
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        unsigned short x0[3], x1[3], y0[3], y1[3];
-                        split3_bf16(v[8 * q + 2 * d], x0[0], x0[1], x0[2]);
-                        split3_bf16(v[8 * q + 2 * d + 1], x1[0], x1[1], x1[2]);
-                        split3_bf16(v[8 * q + 4 + 2 * d], y0[0], y0[1], y0[2]);
-                        split3_bf16(v[8 * q + 4 + 2 * d + 1], y1[0], y1[1], y1[2]);
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            e[p][d] = (unsigned)x0[p] | ((unsigned)x1[p] << 16);
-                            o[p][d] = (unsigned)y0[p] | ((unsigned)y1[p] << 16);
-                        }
-                    }
-                    unsigned short *dst = Ys + ((long long)((mrow >> 4) + q) * np + n) * 16 + kh * 8;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        // lanes < 32 keep their even group and receive the partner's even group (rows 0..7);
-                        // lanes >= 32 receive the partner's odd group and keep their own (rows 8..15)
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(e[p][0], o[p][0], false, false);
-                        const auto s1v = __builtin_amdgcn_permlane32_swap(e[p][1], o[p][1], false, false);
-                        u32x4 w = {s0[0], s1v[0], s0[1], s1v[1]};
-                        *reinterpret_cast<u32x4 *>(dst + p * ys_part) = w;
-                    }
-                }
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The big-tile form of the layer kernel (M and np multiples of 256): measured on the 128x128 kernel above, the matrix pipe
-// idles because the operands cannot be fetched fast enough - 36 KB of L2 reads per 96 MFMAs is 48 B/clk/CU at full MFMA
-// rate (tools/gpu_gemm_trace.py: the 9 loads of a step take 2000 cycles to issue).  Here one workgroup of 8 waves owns a
-// 256 x 256 output tile, both operands go through LDS once per workgroup (48 KB per 384 MFMAs = 16 B/clk/CU), and the
-// staging is LDS-DMA (global_load_lds_dwordx4, no staging registers) into a 3-stage ring, two stages in flight:
-//   stage = [3 parts][8 pieces] weights + [3 parts][8 pieces] points, a piece = 32 rows x 16 k = 1 KB = one wave-wide DMA;
-//   the weight image is fragment-ordered (surs_pack.cpp) so a weight piece IS an MFMA A operand in lane order; a point
-//   piece is put in the same order by the DMA's per-lane source address (lane (h, r) fetches half h of row r).
-//   Wave w issues piece w of every part of both operands: 6 DMAs per stage.
-// Waves 2 (rows) x 4 (columns), wave tile 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers.
-// Synchronisation is by hand (cdna_hip_programming.md, "Pipelining across barriers"): fragment reads are asm ds_read_b128
-// with counted lgkmcnt waits, the step barrier is a raw s_barrier behind `s_waitcnt vmcnt(6)` = "my DMAs of this step
-// have landed, those of the next may still fly"; the compiler sees no LDS read and therefore adds no vmcnt(0) of its own.
-// ------------------------------------------------------------------------------------------------
-constexpr int G3_STAGES = 3;
-constexpr int g3_stage_bytes(int bm) { return 3 * (bm / 32) * 1024 + 24576; }   // weights [3][bm/32] + points [3][8] pieces
-constexpr int g3_lds_bytes(int bm) { return G3_STAGES * g3_stage_bytes(bm); }
-
-// NW = 8 waves (2 x 4) or 16 waves (4 x 4, 4 waves per SIMD; BM = 256 only); BM = 256 or 128 rows per workgroup (128: the
-// last hidden layer, M = 128); SPLIT_OUT: split image for the next layer, or fp32 [m][n] (in front of mlp_last_kernel / the
-// view mean).  The tile is always 256 points wide.
-template <int NW, int BM, bool SPLIT_OUT>
-__global__ __launch_bounds__(NW * 64) void gemm_x3g_kernel(const unsigned short *__restrict__ W3, int M, int Ktot, SplitSeg s1,
-                                                           SplitSeg s2, long long np, const float *__restrict__ bias,
-                                                           float *__restrict__ Y, unsigned short *__restrict__ Ys,
-                                                           long long ys_part, int nblocks) {
-    constexpr int AP = BM / 32;              // weight pieces per part and stage
-    constexpr int TI = AP / (NW / 4);        // MFMA row tiles per wave
-    constexpr int ASZ = 3 * AP * 1024;       // bytes of weights per stage; the points follow
-    constexpr int G3_STAGE = g3_stage_bytes(BM);
-    static_assert(TI == 4 || TI == 2, "wave tile is 128 or 64 rows");
-    extern __shared__ __attribute__((aligned(16))) unsigned char g3_smem[];
-    typedef __attribute__((address_space(3))) unsigned char lds_u8;
-    typedef const __attribute__((address_space(1))) void gptr_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int kh = lane >> 5, li = lane & 31;
-    int mb, nb;
-    {   // same XCD-aware order as gemm_block_tile
-        const unsigned mblocks = (unsigned)M / (unsigned)BM, total = mblocks * (unsigned)nblocks, per = gridDim.x >> 3;
-        const unsigned logical = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-        if (logical >= total) return;
-        mb = (int)(logical % mblocks);
-        nb = (int)(logical / mblocks);
-    }
-    const long long n0 = (long long)nb * 256;
-    const int m0 = mb * BM;
-    const int ktiles = s1.ktiles + s2.ktiles;
-    const size_t per_part = (size_t)Ktot * M;
-    lds_u8 *smem = (lds_u8 *)g3_smem;
-    const unsigned lds0 = (unsigned)(size_t)smem;
-
-    f32x16 acc[TI][2];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // DMA d of this wave and step kt, nd per wave and stage (a multiple of 3: one third goes out behind each product):
-    //   8 waves, BM 256: piece `wave` of part d>>1 of the weights (d even) / points (d odd), nd = 6;
-    //   8 waves, BM 128: the same for waves 0-3; waves 4-7 piece `wave` of part d of the points only, nd = 3;
-    //   16 waves: waves 0-7 piece `wave` of part d of the weights, waves 8-15 piece `wave - 8` of part d of the points, nd = 3.
-    // A points piece is fetched with lane (h, r) on half h of row r, so it lands in LDS in fragment order like the weights.
-    const int piece = wave & 7;
-    const bool both = NW == 8 && (BM == 256 || wave < 4);
-    const int nd = both ? 6 : 3;
-    const unsigned short *wsrc = W3 + ((size_t)(m0 + 32 * piece)) * 16 + lane * 8;
-    auto issue1 = [&](int kt, int d) {
-        const int p = both ? d >> 1 : d;
-        const bool points = both ? (d & 1) : (NW == 8 || wave >= 8);
-        lds_u8 *stage = smem + (kt % G3_STAGES) * G3_STAGE + piece * 1024;
-        if (!points) {
-            const unsigned short *wk = wsrc + (size_t)kt * M * 16 + p * per_part;
-            __builtin_amdgcn_global_load_lds((gptr_t *)wk, (__attribute__((address_space(3))) void *)(stage + p * (AP * 1024)), 16, 0, 0);
-        } else {
-            const bool first = kt < s1.ktiles;
-            const unsigned short *xb = first ? s1.base : s2.base;
-            const long long xpart = first ? s1.part : s2.part;
-            const int k = first ? kt : kt - s1.ktiles;
-            const unsigned short *xsrc = xb + ((long long)k * np + n0 + 32 * piece) * 16 + (li * 16 + kh * 8) + p * xpart;
-            __builtin_amdgcn_global_load_lds((gptr_t *)xsrc, (__attribute__((address_space(3))) void *)(stage + ASZ + p * 8192), 16, 0, 0);
-        }
-    };
-    auto issue = [&](int kt) {
-        for (int d = 0; d < nd; ++d) issue1(kt, d);
-    };
-
-    issue(0);
-    if (ktiles > 1) issue(1);
-    // fragment addresses inside a stage: weights piece TI wm + i, points piece 2 wn + j, both at lane * 16
-    const unsigned a_off = lds0 + (unsigned)(wm * TI * 1024 + lane * 16);
-    const unsigned b_off = lds0 + (unsigned)ASZ + (unsigned)(wn * 2048 + lane * 16);
-    bf16x8_t a[TI][3], b[2][3];
-    auto mm = [&](int pa, int pb) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
-    };
-#ifdef SURS_G3_NO_LDS   // experiment: timing without the fragment reads (results are wrong)
-#define G3_RD(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr) : "memory")
-#else
-#define G3_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#endif
-// waits for everything but the n youngest LDS reads; naming the fragments ties their uses to the wait
-#define G3_WAIT4(n, pa, pb) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0][pa]), "+v"(a[1][pa]), "+v"(a[2][pa]), "+v"(a[3][pa]), "+v"(b[0][pb]), "+v"(b[1][pb]))
-#define G3_WAIT2(n, pa, pb) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0][pa]), "+v"(a[1][pa]), "+v"(b[0][pb]), "+v"(b[1][pb]))
-    // A step = phase 1 (fragment reads of stage kt, the first three products, behind each of them a third of the DMAs of
-    // stage kt+2, where their issue cost is shared with the matrix pipe) + phase 2 (the other three products, registers
-    // only).  The products run (weight part, point part) = (2,0) (1,1) (0,2) | (1,0) (0,1) (0,0); fragments are read in
-    // order of first use.
-    auto phase1 = [&](int kt) {
-#ifdef SURS_G3_NO_DMA   // experiment: timing without the in-loop DMAs (results are wrong)
-        const bool more = false;
-#else
-        const bool more = kt + 2 < ktiles;
-#endif
-        const unsigned sa = a_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
-        const unsigned sb = b_off + (unsigned)((kt % G3_STAGES) * G3_STAGE);
-        GEMM_STAMP(0);
-        constexpr int PA = AP * 1024;   // bytes between the weight parts of a stage
-        G3_RD(a[0][2], sa, 2 * PA); G3_RD(a[1][2], sa, 2 * PA + 1024);
-        if constexpr (TI == 4) { G3_RD(a[2][2], sa, 2 * PA + 2048); G3_RD(a[3][2], sa, 2 * PA + 3072); }
-        G3_RD(b[0][0], sb, 0);     G3_RD(b[1][0], sb, 1024);
-        G3_RD(a[0][1], sa, PA);  G3_RD(a[1][1], sa, PA + 1024);
-        if constexpr (TI == 4) { G3_RD(a[2][1], sa, PA + 2048); G3_RD(a[3][1], sa, PA + 3072); }
-        G3_RD(b[0][1], sb, 8192);  G3_RD(b[1][1], sb, 9216);
-        G3_RD(a[0][0], sa, 0);     G3_RD(a[1][0], sa, 1024);
-        if constexpr (TI == 4) { G3_RD(a[2][0], sa, 2048); G3_RD(a[3][0], sa, 3072); }
-        G3_RD(b[0][2], sb, 16384); G3_RD(b[1][2], sb, 17408);
-        if constexpr (TI == 4) G3_WAIT4(12, 2, 0); else G3_WAIT2(8, 2, 0);
-        GEMM_STAMP(1);
-        mm(2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more)
-            for (int d = 0; d < nd / 3; ++d) issue1(kt + 2, d);
-        if constexpr (TI == 4) G3_WAIT4(6, 1, 1); else G3_WAIT2(4, 1, 1);
-        mm(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more)
-            for (int d = nd / 3; d < 2 * nd / 3; ++d) issue1(kt + 2, d);
-        if constexpr (TI == 4) G3_WAIT4(0, 0, 2); else G3_WAIT2(0, 0, 2);
-        mm(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more)
-            for (int d = 2 * nd / 3; d < nd; ++d) issue1(kt + 2, d);
-        GEMM_STAMP(2);
-    };
-    auto phase2 = [&](int kt) {
-        mm(1, 0);
-        mm(0, 1);
-        mm(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        GEMM_STAMP(3);
-    };
-    // step barrier: my DMAs of stage kt have landed (those of stage kt+1 may be in flight); after the barrier everybody's
-    // have, and everybody has finished reading stage kt-1, whose buffer the DMAs of stage kt+2 overwrite
-    auto step_barrier = [&](int kt) {
-#ifdef SURS_G3_NO_DMA
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-        if (kt + 1 < ktiles)
-            if (nd == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-    };
-    // Waves w and w+4 (+8, +12) share a SIMD.  Half of them run barrier, phase 1, phase 2; the others barrier, phase 2 of
-    // the PREVIOUS step (its operands are in registers), phase 1: while one wave waits for its fragment reads or issues
-    // DMAs another one has MFMAs to issue (8 waves: step 5200 -> 4600 cycles, tools/gpu_gemm_trace.py; 3072 = MFMA time).
-    if (((wave >> 2) & 1) == 0) {
-        for (int kt = 0; kt < ktiles; ++kt) {
-            step_barrier(kt);
-            phase1(kt);
-            phase2(kt);
-        }
-    } else {
-        step_barrier(0);
-        phase1(0);
-        for (int kt = 1; kt < ktiles; ++kt) {
-            step_barrier(kt);
-            phase2(kt - 1);
-            phase1(kt);
-        }
-        phase2(ktiles - 1);
-    }
-
-#undef G3_RD
-#undef G3_WAIT4
-#undef G3_WAIT2
-    // epilogue: acc[i][j][4g + r] is row 32i + 8g + 4kh + r of the wave's rows, column 32j + li; bias, LeakyReLU, split,
-    // pair lanes l / l+32 so each owns 8 consecutive rows = 16 bytes of the next layer's operand (see gemm_x3s_kernel)
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long n = n0 + wn * 64 + j * 32 + li;
-            const int mrow = m0 + wm * (TI * 32) + i * 32;
-            float v[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][4 * g + r] + bias[mrow + 8 * g + 4 * kh + r];
-                    v[4 * g + r] = t > 0.0f ? t : 0.01f * t;
-                }
-            if constexpr (!SPLIT_OUT) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Y[(long long)(mrow + 8 * g + 4 * kh + r) * np + n] = v[4 * g + r];
-            } else
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                unsigned e[3][2], o[3][2];
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    unsigned short x0[3], x1[3], y0[3], y1[3];
-                    split3_bf16(v[8 * q + 2 * d], x0[0], x0[1], x0[2]);
-                    split3_bf16(v[8 * q + 2 * d + 1], x1[0], x1[1], x1[2]);
-                    split3_bf16(v[8 * q + 4 + 2 * d], y0[0], y0[1], y0[2]);
-                    split3_bf16(v[8 * q + 4 + 2 * d + 1], y1[0], y1[1], y1[2]);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        e[p][d] = (unsigned)x0[p] | ((unsigned)x1[p] << 16);
-                        o[p][d] = (unsigned)y0[p] | ((unsigned)y1[p] << 16);
-                    }
-                }
-                unsigned short *dst = Ys + ((long long)((mrow >> 4) + q) * np + n) * 16 + kh * 8;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const auto t0 = __builtin_amdgcn_permlane32_swap(e[p][0], o[p][0], false, false);
-                    const auto t1 = __builtin_amdgcn_permlane32_swap(e[p][1], o[p][1], false, false);
-                    u32x4 w = {t0[0], t1[0], t0[1], t1[1]};
-                    *reinterpret_cast<u32x4 *>(dst + p * ys_part) = w;
-                }
-            }
-        }
-}
+#include "surs_gemm.inc"
 
 // last layer (Cout = 1) + sigmoid * mask.  One thread per point, coalesced over points.
 //   logit = b4 + w4[0:128].Y3[:,n] + w4[128:128+336].F[:,n];  pred = mask * sigmoid(logit)
