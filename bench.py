@@ -111,7 +111,7 @@ def main():
         ev[4].record()
         if timed:
             torch.cuda.synchronize()
-            # streamed path: "query" = the sweep with the marching cubes of finished layers between its launches,
+            # streamed path: "query" = the sweep (the marching cubes of finished layers run beside it on their own streams),
             # "mesh" = what is left after the last launch (last layers, last copies); the slab path also has "gather"
             names = ("encoder", "query", "mesh", "gather") if streamed[0] else ("encoder", "query", "gather", "mesh")
             for k, (a, b) in zip(names, zip(ev[:-1], ev[1:])):

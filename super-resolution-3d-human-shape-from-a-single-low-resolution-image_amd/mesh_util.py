@@ -130,6 +130,9 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
     streams = [native.MeshStream(ws, 0, vh, mat[:3].reshape(-1), 0.5, want_normals),
                native.MeshStream(ws, 1, vl, mat[:3].reshape(-1), 0.5, want_normals)]
     planes = planes or max(1, 16384 // R)   # default: one launch of the column kernel per slab
+    # the whole sweep is enqueued first (no host synchronisation in it), with an event behind every slab ...
+    sweep = torch.cuda.current_stream(dev)
+    done = []
     for i0 in range(0, R, planes):
         i1 = min(R, i0 + planes)
         try:
@@ -139,12 +142,18 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
                 raise
             prec = "fp32"   # general calibration / grid transform: the column kernel does not apply
             native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1])
-        # queued behind that launch: the layers the PREVIOUS launches completed (a cell layer needs the plane above it)
-        for s in streams:
-            s.advance(i0 - 1)
+        ev = torch.cuda.Event()
+        ev.record(sweep)
+        done.append((i1, ev))
     if timing is not None:
         timing.record()
-    outs = [s.finish() for s in streams]
+    # ... then the extraction follows it slab by slab on the fields' own streams: once planes < i1 are final the cell
+    # layers below i1 - 1 are (a cell layer needs the plane above it); the count read-backs of the extraction wait on
+    # those streams only, and its kernels run in the gaps and tails of the sweep's launches
+    for i1, ev in done[:-1]:
+        for s in streams:
+            s.advance(i1 - 1, after=ev)
+    outs = [s.finish(after=done[-1][1]) for s in streams]
     if any(o is None for o in outs):   # a buffer was too small: extract the finished volumes in one piece
         return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
     return outs[0] + outs[1]

@@ -388,11 +388,30 @@ class MeshStream:
         if getattr(ws, "_copy_stream", None) is None:
             ws._copy_stream = torch.cuda.Stream(device=dev)
         self.side = ws._copy_stream
+        # the extraction runs on a stream of its own (one per field): its kernels and its count read-backs (host syncs)
+        # then neither sit between two launches of the sweep nor keep the host from enqueueing the next launch
+        streams = getattr(ws, "_mc_streams", None)
+        if streams is None:
+            streams = ws._mc_streams = {}
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=dev)
+        self.mc = streams[key]
+        self.mc.wait_stream(torch.cuda.current_stream(dev))   # the buffers above were allocated on the caller's stream
         for t in (self.world, self.faces):
             t.record_stream(self.side)
+        for t in (self.verts, self.world, self.faces, self.normals, self.values, vol):
+            if t is not None:
+                t.record_stream(self.mc)
 
-    def advance(self, layer_end):
-        """Extract the cell layers [self.layers, layer_end): the voxel planes up to layer_end must be final."""
+    def advance(self, layer_end, after=None):
+        """Extract the cell layers [self.layers, layer_end): the voxel planes up to layer_end must be final - or final once
+        the event `after` (recorded on the sweep's stream) has happened."""
+        with torch.cuda.stream(self.mc):
+            if after is not None:
+                self.mc.wait_event(after)
+            self._advance(layer_end)
+
+    def _advance(self, layer_end):
         layer_end = min(int(layer_end), self.n0 - 1)
         if self.overflow or layer_end <= self.layers:
             return
@@ -419,9 +438,15 @@ class MeshStream:
                     self.h_faces[self.sent_f:nf].copy_(self.faces[self.sent_f:nf], non_blocking=True)
             self.sent_v, self.sent_f = nv, nf
 
-    def finish(self):
+    def finish(self, after=None):
         """Last layers, the checks of marching_cubes_lewiner, normals; -> (verts_world, faces, normals, values) numpy."""
-        self.advance(self.n0 - 1)
+        with torch.cuda.stream(self.mc):
+            if after is not None:
+                self.mc.wait_event(after)
+            return self._finish()
+
+    def _finish(self):
+        self._advance(self.n0 - 1)
         if self.overflow:
             return None
         if self.level < self.run.vmin or self.level > self.run.vmax:
