@@ -153,13 +153,13 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
         const float *feat = is_hr ? feat_hr : feat_lr;
         const int H = is_hr ? hh : hl, W = is_hr ? wh : wl, C = is_hr ? C_HR : C_LR;
         const int c0 = is_hr ? 0 : chunk * 64;
-        // four points at a time, all 16 tap loads issued before the first use: with one workgroup per CU (the column
+        // eight points at a time, all 32 tap loads issued before the first use: with one workgroup per CU (the column
         // batches of the sweep) the kernel is a chain of load latencies.  Taps outside the image are loaded from a
         // clamped address and weighted with zero (zeros padding: the same sum).
-        for (int q0 = 0; q0 < 16; q0 += 4) {
-            float t[4][4], w[4][4];
+        for (int q0 = 0; q0 < 16; q0 += 8) {
+            float t[8][4], w[8][4];
 #pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
+            for (int u4 = 0; u4 < 8; ++u4) {
                 const int p = wave * 16 + q0 + u4;
                 const float u = sx[p], v = sy[p];
                 const float ix = ((u + 1.0f) / 2.0f) * (float)(W - 1);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
                 t[u4][3] = feat[((long long)cy1 * W + cx1) * C + ch];
             }
 #pragma unroll
-            for (int u4 = 0; u4 < 4; ++u4) {
+            for (int u4 = 0; u4 < 8; ++u4) {
                 float a = 0.0f;   // nw, ne, sw, se in this order, as grid_sample accumulates them
                 a += t[u4][0] * w[u4][0];
                 a += t[u4][1] * w[u4][1];
@@ -383,6 +383,20 @@ static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const v
     return 0;
 }
 
+// the 256-point layer kernels need more than 64 KB of dynamic LDS
+static int g3_set_attributes() {
+    static bool once = false;
+    if (!once) {
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
+        once = true;
+    }
+    return 0;
+}
+
 static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned short *X1s, int K1, const unsigned short *X2s,
                          int K2, const float *bias, float *Y, unsigned short *Ys, long long np) {
     SplitSeg s1 = {X1s, (long long)K1 * np, K1 / 16}, s2 = {X2s, (long long)K2 * np, K2 / 16};
@@ -391,29 +405,23 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
     const unsigned short *w3 = (const unsigned short *)W3;
     if (np % 256 == 0 && gemm_use_big() && (M % 256 == 0 || !Ys)) {
         // 256-point tiles: 256 rows per workgroup where M allows, else 128 (fp32 output only: the last hidden layer)
-        static bool once = false;
-        if (!once) {
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
-            once = true;
-        }
+        int rca = g3_set_attributes();
+        if (rca) return rca;
         const int nb256 = (int)(np / 256);
         static const int nw = getenv("SURS_GEMM_WAVES") ? atoi(getenv("SURS_GEMM_WAVES")) : 8;
         const long long yp = (long long)M * np;
         if (Ys && nw == 16)
-            hipLaunchKernelGGL((gemm_x3g_kernel<16, 256, true>), dim3(gemm_grid(M / 256, nb256)), dim3(1024), g3_lds_bytes(256), st, w3, M,
-                               K1 + K2, s1, s2, np, bias, (float *)nullptr, Ys, yp, nb256);
+            hipLaunchKernelGGL((gemm_x3g_kernel<16, 256, G3_SPLIT>), dim3(gemm_grid(M / 256, nb256)), dim3(1024), g3_lds_bytes(256), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, (float *)nullptr, 0LL, Ys, yp, nb256);
         else if (Ys)
-            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, true>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256), st, w3, M,
-                               K1 + K2, s1, s2, np, bias, (float *)nullptr, Ys, yp, nb256);
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_SPLIT>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, (float *)nullptr, 0LL, Ys, yp, nb256);
         else if (M % 256 == 0)
-            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, false>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256), st, w3, M,
-                               K1 + K2, s1, s2, np, bias, Y, (unsigned short *)nullptr, 0LL, nb256);
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
         else
-            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, false>), dim3(gemm_grid(M / 128, nb256)), dim3(512), g3_lds_bytes(128), st, w3, M,
-                               K1 + K2, s1, s2, np, bias, Y, (unsigned short *)nullptr, 0LL, nb256);
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32>), dim3(gemm_grid(M / 128, nb256)), dim3(512), g3_lds_bytes(128), st, w3, M,
+                               K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
     } else if (Ys)
         hipLaunchKernelGGL(gemm_x3s_kernel<true>, grid, dim3(256), 0, st, w3, M, K1 + K2, s1, s2, np, bias, 1, (float *)nullptr,
                            0LL, Ys, (long long)M * np, nblocks);
@@ -944,7 +952,7 @@ static const long long COL_BATCH = 16384;
 
 static size_t col_ws_bytes(long long ncb) {
     // F rows 0..335 for the column gather + CC + mask
-    return (size_t)ncb * (C0PAD + CC_PAD + 1) * sizeof(float) + 4096;
+    return (size_t)ncb * (C0PAD + CC_PAD + 1) * sizeof(float) + (size_t)ncb * C0PAD * 6 + 4096;   // + split image of F
 }
 
 extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
@@ -1038,14 +1046,29 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
         const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
-        const long long ncp = (long long)ceil_div(nc, 128) * 128;
+        const long long ncp = (long long)ceil_div(nc, 256) * 256;   // <= COL_BATCH; rows nc.. of CC are never read
         src.base = (long long)i0 * ry + c0;
+        // column constants CC[col][2944] = Wc^T F[:, col] + bc: the split-bf16 layer kernel in its transposed-output form
+        // on the split image of F (SURS_GEMM_X3=0 / SURS_GEMM_BIG=0: the older kernels on the fp32 F)
+        const bool split = gemm_use_x3() && gemm_use_big();
+        unsigned short *Fs = (unsigned short *)(cmask + COL_BATCH);
+        const long long fs_part = (long long)C0PAD * COL_BATCH;
         hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
-                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, (unsigned short *)nullptr, 0LL);
+                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
         SURS_LAUNCH_CHECK();
-        rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
-                         (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
-        if (rc) return rc;
+        if (split) {
+            if ((rc = g3_set_attributes())) return rc;
+            SplitSeg s1 = {Fs, fs_part, C_G / 16}, s2 = {nullptr, 0, 0};
+            const int nb256 = (int)(ncp / 256);
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128),
+                               st, (const unsigned short *)(blob + h.wc3), CC_PAD, C_G, s1, s2, COL_BATCH,
+                               (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
+            SURS_LAUNCH_CHECK();
+        } else {
+            rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
+                             (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
+            if (rc) return rc;
+        }
         GridArgs a;
         a.cc = CC;
         a.colmask = cmask;
