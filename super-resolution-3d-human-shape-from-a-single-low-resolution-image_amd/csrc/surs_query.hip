@@ -948,7 +948,10 @@ extern "C" int surs_profile_read(double *launches, double *total_ms, double *poi
 
 // grid batches: fp32 mode evaluates GRID_BATCH voxels per pass; column mode COL_BATCH columns per pass
 static const long long GRID_BATCH = 65536;
-static const long long COL_BATCH = 16384;
+#ifndef SURS_COL_BATCH
+#define SURS_COL_BATCH 16384
+#endif
+static const long long COL_BATCH = SURS_COL_BATCH;
 
 static size_t col_ws_bytes(long long ncb) {
     // F rows 0..335 for the column gather + CC + mask

@@ -9,6 +9,8 @@ reference's default in gen_mesh) runs the reference's coarse-to-fine sweep (lib/
 device, shared-`dirty` artefact included, with the fp32 kernels; `use_octree=False` runs the dense
 sweep in `opt.precision` - on this hardware the dense bf16 sweep is both faster and free of the artefact.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -129,7 +131,7 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
     vl = torch.empty_like(vh)
     streams = [native.MeshStream(ws, 0, vh, mat[:3].reshape(-1), 0.5, want_normals),
                native.MeshStream(ws, 1, vl, mat[:3].reshape(-1), 0.5, want_normals)]
-    planes = planes or max(1, 16384 // R)   # default: one launch of the column kernel per slab
+    planes = planes or max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)   # default: one launch of the column kernel per slab
     # the whole sweep is enqueued first (no host synchronisation in it), with an event behind every slab ...
     sweep = torch.cuda.current_stream(dev)
     done = []
