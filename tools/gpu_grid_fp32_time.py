@@ -1,0 +1,21 @@
+"""Times the fp32 dense sweep (surs_query_grid with dtype fp32: the point evaluator over grid chunks) at R=256."""
+import os, sys, time
+import torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common, gpu_common as g, oracle
+from surs_amd import native
+R = 256
+fl, fh = common.synth_features()
+Fl, Fh = g.upload_nhwc(fl), g.upload_nhwc(fh)
+ws = native.Workspace(g.dev())
+mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+b = g.blob("bf16")
+vh = torch.empty((R, R, R), dtype=torch.float32, device=g.dev()); vl = torch.empty_like(vh)
+f = lambda: native.query_grid(0, R, R, R, mat, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, b, "fp32", ws, vh, vl)
+f(); torch.cuda.synchronize()
+t = time.time()
+f()
+torch.cuda.synchronize()
+dt = time.time() - t
+print("fp32 grid R=%d: %.3f s  %.3e pts/s" % (R, dt, R ** 3 / dt))
