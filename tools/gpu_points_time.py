@@ -9,7 +9,7 @@ fl, fh = common.synth_features(hl=256, hh=1024)
 Fl, Fh = g.upload_nhwc(fl), g.upload_nhwc(fh)
 ws = native.Workspace(g.dev())
 b = g.blob("bf16")
-for n in (50000, 400000, 2000000):
+for n in [int(a) for a in sys.argv[1:]] or (50000, 400000, 2000000):
     pts = torch.from_numpy(weights.synthetic_points(n, seed=2)).to(g.dev())
     f = lambda: native.query_points(pts, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, b, ws)
     f(); torch.cuda.synchronize()
