@@ -351,9 +351,49 @@ def marching_cubes_lewiner(vol, level, ws, want_normals=True, key=None):
         rc, verts, faces, normals, values = run(counts.n_verts, counts.n_faces)
     check(rc)
     nv, nf = counts.n_verts, counts.n_faces
-    ws.mc_capacity[key] = (int(nv * 1.125) + 1024, int(nf * 1.125) + 2048)
+    ws.mc_capacity[key] = mesh_capacity(nv, nf)
+    _warm_stream_buffers(ws, key)
+    if key is not None and (ws.mesh_ws.get(key) is None or ws.mesh_ws[key].numel() < w.numel()):
+        ws.mesh_ws[key] = torch.empty(w.numel(), dtype=torch.uint8, device=dev)   # the field's own tables (MeshStream)
     return (verts[:nv], faces[:nf], normals[:nv] if normals is not None else None,
             values[:nv] if values is not None else None)
+
+
+def mesh_capacity(nv, nf):
+    """Buffer sizes for the next extraction of a field that last had nv vertices / nf faces: 12.5 % head-room, rounded up
+    to 2^20 vertices / 2^21 faces so that meshes of similar size ask the caching allocators (device and pinned host) for
+    blocks of the same size and get the previous reconstruction's blocks back."""
+    gv, gf = 1 << 20, 1 << 21
+    return (-(-(int(nv * 1.125) + 1024) // gv) * gv, -(-(int(nf * 1.125) + 2048) // gf) * gf)
+
+
+def _warm_stream_buffers(ws, key):
+    """The streamed extraction (MeshStream) keeps its results in pinned host buffers of the capacity sizes.  Allocating
+    pinned memory is slow (17 - 140 ms for the bench's 1 GB, depending on the box) and torch's caching host allocator only
+    recycles blocks of a matching size: allocate and release them here, in the one-piece extraction that sizes the
+    buffers, so that the first streamed reconstruction already finds them cached."""
+    cap = ws.mc_capacity[key]
+    warm = getattr(ws, "_pinned_warm", None)
+    if warm is None:
+        warm = ws._pinned_warm = {}
+    if warm.get(key) == cap:
+        return
+    a = torch.empty((cap[0], 3), dtype=torch.float64, pin_memory=True)
+    b = torch.empty((cap[1], 3), dtype=torch.int32, pin_memory=True)
+    # ... and the device buffers of a MeshStream (hipMalloc is slow too, and synchronises)
+    d = [torch.empty((cap[0], 3), dtype=torch.float32, device=ws.device), torch.empty((cap[0], 3), dtype=torch.float64, device=ws.device),
+         torch.empty((cap[1], 3), dtype=torch.int32, device=ws.device), torch.empty((cap[0], 3), dtype=torch.float32, device=ws.device),
+         torch.empty((cap[0],), dtype=torch.float32, device=ws.device)]
+    del a, b, d
+    warm[key] = cap
+    # ... and the field's extraction stream: the first use of a HIP stream creates its hardware queue (milliseconds)
+    streams = getattr(ws, "_mc_streams", None)
+    if streams is None:
+        streams = ws._mc_streams = {}
+    if key not in streams:
+        streams[key] = torch.cuda.Stream(device=ws.device)
+        with torch.cuda.stream(streams[key]):
+            torch.zeros(1, device=ws.device).cpu()   # (a pageable read-back like the extraction's counts)
 
 
 class MeshStream:
@@ -454,7 +494,7 @@ class MeshStream:
         nv, nf = self.run.n_verts, self.run.n_faces
         if nv == 0:
             raise RuntimeError("No surface found at the given iso value.")
-        self.ws.mc_capacity[self.key] = (int(nv * 1.125) + 1024, int(nf * 1.125) + 2048)
+        self.ws.mc_capacity[self.key] = mesh_capacity(nv, nf)
         extra = [None, None]
         if self.want:
             check(lib().surs_mc_normalize(_ptr(self.normals), nv, _stream()))
