@@ -153,10 +153,12 @@ def test_layer_kernel_generations_agree(tmp_path):
         if mode == "save":
             continue
         lines = [l for l in r.stdout.splitlines() if "max|diff|" in l]
-        assert len(lines) == 8, r.stdout
+        assert len(lines) == 10, r.stdout   # 2 batch sizes x 4 outputs + the two fields of a small bf16 sweep
         for l in lines:
             d, eq = float(l.split("=")[1].split()[0]), l.rstrip().endswith("equal=1")
-            assert eq if name != "f32" else d <= 2e-5, (name, l)
+            # (the sweep's column constants go through the same kernels; behind them sits the bf16 column kernel, which
+            #  rounds the layer-0 activations to bf16: a constant that differs in the last fp32 bit can flip one of those)
+            assert eq if name != "f32" else d <= (2e-5 if not l.startswith("grid_") else 2e-3), (name, l)
 
 
 def test_multiview_and_perspective_vs_reference(setup, golden_dir):

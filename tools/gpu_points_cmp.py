@@ -18,6 +18,13 @@ for n in (777, 20000):
     r = native.query_points(pts, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, g.blob("bf16"), ws, want_logits=True)
     for name, t in zip(("pred_hr", "pred_lr", "logit_hr", "logit_lr"), r):
         out["%s_%d" % (name, n)] = t.cpu().numpy()
+# a small bf16 sweep: its column constants come from the same layer kernels (transposed-output form)
+import oracle
+R = 48
+mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+vh = torch.empty((R, R, R), dtype=torch.float32, device=g.dev()); vl = torch.empty_like(vh)
+native.query_grid(0, R, R, R, mat, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, g.blob("bf16"), "bf16", ws, vh, vl)
+out["grid_hr_%d" % R] = vh.cpu().numpy(); out["grid_lr_%d" % R] = vl.cpu().numpy()
 if mode == "save":
     np.savez(path, **out)
 else:
