@@ -92,6 +92,38 @@ def test_grid_column_kernel_vs_fp32(setup, dtype, tol):
     assert np.array_equal(a, vh[8:24])
 
 
+def test_full_size_sweep_properties(setup):
+    """BASELINE's full grid (512^3 = 134 217 728 queries, bf16 column kernel) through properties that do not need a CPU pass
+    over the grid: (1) four flat ranges of 65 536 voxels - a plane boundary, a slab boundary of the sweep and two interior
+    ones - against the fp32 point evaluator on the oracle's coordinates for those voxels (the fp32 evaluator is itself
+    held to the reference's goldens at 1e-4); (2) the same bits on a second run; (3) slab consistency: planes [200, 296)
+    evaluated on their own equal those planes of the full sweep."""
+    import oracle
+    R = 512
+    s, nat = setup, setup["native"]
+    mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+    cal = common.CALIB.reshape(-1)[:12]
+    dev = s["g"].dev()
+    blob = s["g"].blob("bf16")
+    vh = torch.empty((R, R, R), dtype=torch.float32, device=dev)
+    vl = torch.empty_like(vh)
+    nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, "bf16", s["ws"], vh, vl)
+    n = 65536
+    for start in (0, 31 * R * R + 509 * R - 7, 32 * R * R - n // 2, R ** 3 - n):
+        pts = torch.from_numpy(oracle.grid_points(R, [-0.5] * 3, [0.5] * 3, start, start + n)).to(dev)
+        phr, plr = nat.query_points(pts, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, s["ws"])
+        eh = (vh.view(-1)[start:start + n] - phr).abs().max().item()
+        el = (vl.view(-1)[start:start + n] - plr).abs().max().item()
+        assert eh < 3e-2 and el < 3e-2, (start, eh, el)
+    vh2 = torch.empty_like(vh)
+    vl2 = torch.empty_like(vl)
+    nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, "bf16", s["ws"], vh2, vl2)
+    assert torch.equal(vh, vh2) and torch.equal(vl, vl2)
+    nat.query_grid(200, 296, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, "bf16", s["ws"], vh2[200:296].zero_(), vl2[200:296].zero_())
+    assert torch.equal(vh[200:296], vh2[200:296]) and torch.equal(vl[200:296], vl2[200:296])
+    assert float(vh.min()) >= 0.0 and float(vh.max()) <= 1.0 and bool(torch.isfinite(vh).all())
+
+
 def test_pipelined_kernel_bitwise_equals_simple_kernel():
     """The software-pipelined column kernel (3-slab ring, counted vmcnt) must produce the same bits as the simple
     one-barrier-per-slab kernel, and the same bits on every launch (race screen), for ragged and multi-tile grids."""
