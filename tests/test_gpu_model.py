@@ -240,3 +240,16 @@ def test_bench_contract_small():
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     # (no ordering between the stage times here: at this size the mesh tail and the sweep are both ~1-3 ms)
     assert "workload" in d["config"] and set(d["config"]["stage_ms_rank0"]) == {"encoder", "query", "gather", "mesh"}
+
+
+def test_streamed_reconstruction_full_size():
+    """BASELINE configs[2] end to end at its full size (512x512 image, 512^3 grid, bf16): the streamed reconstruction -
+    marching cubes on its own streams beside the sweep - returns the vertices and faces of the one-piece extraction of the
+    same volumes bit for bit, twice in a row (tools/gpu_stream_check.py; 22 M vertices / 44 M faces on the synthetic field)."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stream_check.py"), "512"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("streamed == one piece") == 2, r.stdout
