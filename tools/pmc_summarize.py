@@ -42,6 +42,7 @@ fetch = keep("pmc_fetch", "FETCH_SIZE", "%s_pmc_fetch_size.csv" % TAG)
 write = keep("pmc_write", "WRITE_SIZE", "%s_pmc_write_size.csv" % TAG)
 hit, miss = rows("pmc_l2", "TCC_HIT_sum"), rows("pmc_l2", "TCC_MISS_sum")
 gui = rows("pmc_clk", "GRBM_GUI_ACTIVE")
+mfma = keep("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES", "%s_pmc_mfma_busy.csv" % TAG)
 f_kb, w_kb = mean(fetch), mean(write)
 s = {
     "kernel": fetch[0]["Kernel_Name"] if fetch else None,
@@ -53,6 +54,11 @@ s = {
     "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
     "effective_clock_ghz": (mean(gui) / 8.0 / (dur_ms(gui) * 1e-3) * 1e-9) if gui else None,
     "avg_launch_ms_under_pmc": dur_ms(fetch),
+    # SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipes were busy, summed over the chip's 1024 SIMDs (32 per
+    # v_mfma_f32_32x32x16_bf16); the denominator is the launch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs
+    "mfma_busy_cycles_per_launch": mean(mfma) if mfma else None,
+    "mfma_busy_fraction": (mean(mfma) / (mean(gui) / 8.0 * 1024.0)) if mfma and gui else None,
+    "mfma_busy_cycles_expected": 8388608 * 2752512 / 32768 * 32,   # executed FLOP / FLOP per MFMA x 32 cycles
     # algorithmic bytes of one launch: the per-column constants (CC_PAD floats per column), the column masks, the two
     # output fields (2 x 4 B per voxel) and the packed weight stream once (2 x 42 slabs x 32 KiB)
     "algorithmic_bytes_per_launch": 16384 * 2944 * 4 + 16384 * 4 + 8388608 * 8 + 2 * 42 * 32768,
