@@ -148,13 +148,15 @@ def main():
         k_pts_per_launch = kpts.value / max(launches.value, 1.0)
         achieved = k_pts_per_launch * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         peak = PEAK_MFMA[args.precision] / 1e12
-        traffic = None
+        traffic = mfma_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc):   # counters are collected in their own rocprofv3 --pmc passes (tools/profile_round.sh)
             try:
-                traffic = json.load(open(pmc)).get("grid_mlp_kernel_hbm_bytes_per_launch")
+                summary = json.load(open(pmc))
+                traffic = summary.get("grid_mlp_kernel_hbm_bytes_per_launch")
+                mfma_busy = summary.get("mfma_busy_fraction")
             except Exception:
-                traffic = None
+                traffic = mfma_busy = None
         out = {
             "metric": "occupancy queries/sec (dense %d^3 reconstruction: encoder + query sweep + 2x marching cubes)" % R,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +174,8 @@ def main():
             "roofline": {"kernel": "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "3")[:1], args.precision), "bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts_per_launch,
-                         "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": 2752512},
+                         "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": 2752512,
+                         "mfma_busy_fraction_pmc": mfma_busy},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, sd, R, b_min, b_max)
