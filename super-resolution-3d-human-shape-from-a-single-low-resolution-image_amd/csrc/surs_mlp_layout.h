@@ -41,6 +41,10 @@ constexpr int SLAB_BYTES = 32768, SLABS_L1 = 32, SLABS_L2 = 8, SLABS_L3 = 2, SLA
 // B_ones holds 1 / B1FRAG_SCALE there.  f16 has too little range for the low parts: they are scaled by 2^12 (exact).
 constexpr float B1FRAG_SCALE_BF16 = 1.0f, B1FRAG_SCALE_F16 = 4096.0f;
 
+// split-f16 image of the dense cores (column kernel v5): fragment index (1 KiB units) of each layer inside one MLP's image
+constexpr int X_F_L1 = 0, X_F_L2 = (D1 / 16) * (D2 / 32) * 2, X_F_L3 = X_F_L2 + (D2 / 16) * (D3 / 32) * 2,
+              X_F_MLP = X_F_L3 + (D3 / 16) * (D4 / 32) * 2;   // 2048 + 512 + 128 = 2688 KiB per MLP
+
 struct MlpBlobHeader {
     uint32_t magic;  // 'SURS'
     uint32_t dtype;  // SURS_BF16 / SURS_F16 of the core slabs
@@ -61,7 +65,10 @@ struct MlpBlobHeader {
     // three bf16 parts (hi + mid + lo = the fp32 value exactly), [3 parts][Kpad / 16][M][16] uint16
     uint32_t wt3[2][4];
     uint32_t wc3;
-    uint32_t pad[2];
+    // fp32-grade column kernel (v5): the dense cores as TWO f16 parts per weight (hi = f16(w), lo = f16(w - hi)), 1 KiB
+    // A fragments of the 32x32x16 shape in the order the waves stream them: per MLP, per layer, [k-step][row tile][part][64 lanes][8]
+    uint32_t corex;
+    uint32_t pad[1];
 };
 static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 constexpr uint32_t MLP_MAGIC = 0x53525553u;
@@ -96,6 +103,7 @@ inline MlpBlobHeader blob_layout(uint32_t dtype) {
     for (int m = 0; m < 2; ++m)
         for (int l = 0; l < 4; ++l) h.wt3[m][l] = take((size_t)kpad[l] * mout[l] * 6);
     h.wc3 = take((size_t)C_G * CC_PAD * 6);
+    h.corex = take((size_t)2 * X_F_MLP * 1024);
     h.total_bytes = (uint32_t)off;
     return h;
 }

@@ -204,6 +204,33 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
                 split_kmajor((const float *)(base + h.wt[m][l]), kpad[l], mout[l], (uint16_t *)(base + h.wt3[m][l]));
         split_kmajor((const float *)(base + h.wc), C_G, CC_PAD, (uint16_t *)(base + h.wc3));
     }
+    // ---- the dense cores as two f16 parts per weight (hi + lo), A fragments [k-step][row tile][part][lane][8]: the
+    //      fp32-grade column kernel (v5) multiplies hi*hi + hi*lo + lo*hi.  Same k order inside a k-step as `core`.
+    {
+        uint16_t *cx = (uint16_t *)(base + h.corex);
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = kDims[m][0];
+            uint16_t *p = cx + (size_t)m * X_F_MLP * 512;
+            const int rows[3] = {D2, D3, D4}, kin[3] = {D1, D2, D3}, ld[3] = {D1, D2 + c0, D3 + c0};
+            for (int l = 0; l < 3; ++l) {
+                const int nT = rows[l] / 32, nS = kin[l] / 16;
+                for (int s = 0; s < nS; ++s)
+                    for (int T = 0; T < nT; ++T)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int r = lane & 31, hh = lane >> 5;
+                                const int k = l == 0 ? 16 * s + 8 * hh + j : 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+                                const float w = W[m][l + 1][(size_t)(32 * T + r) * ld[l] + k];
+                                const uint16_t hi = f32_to_f16(w);
+                                const uint16_t lo = f32_to_f16(w - f16_to_f32(hi));
+                                const size_t f = ((size_t)s * nT + T) * 2;
+                                p[(f * 64 + lane) * 8 + j] = hi;
+                                p[((f + 1) * 64 + lane) * 8 + j] = lo;
+                            }
+                p += (size_t)nS * nT * 2 * 512;
+            }
+        }
+    }
     // ---- layer-1 biases as A fragments (three exact 16-bit parts in k-slots 0..2 of lanes 0..31)
     {
         uint16_t *bf = (uint16_t *)(base + h.b1frag);

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -383,16 +384,28 @@ static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const v
     return 0;
 }
 
+// kernels that need more than 64 KB of dynamic LDS: the attribute belongs to the (function, device) pair, so the
+// "already set" flags are per device (a second device in the same process gets its own calls)
+static bool attrs_done(int which) {
+    static std::mutex mu;
+    static bool done[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    const bool was = done[which][dev];
+    done[which][dev] = true;
+    return was;
+}
+
 // the 256-point layer kernels need more than 64 KB of dynamic LDS
 static int g3_set_attributes() {
-    static bool once = false;
+    const bool once = attrs_done(0);
     if (!once) {
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
-        once = true;
     }
     return 0;
 }
@@ -510,6 +523,7 @@ struct GridArgs {
     const float *zvec;     // [ZV_N]
     const char *core;      // SLABS_TOTAL slabs
     const char *core16;    // the same cores in 16x16x32 fragment order (kernel v4)
+    const char *corex;     // the same cores as two f16 parts per weight (kernel v5, fp32-grade)
     const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
@@ -748,6 +762,7 @@ __global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
 #include "surs_grid_v2.inc"
 #include "surs_grid_v3.inc"
 #include "surs_grid_v4.inc"
+#include "surs_grid_v5.inc"
 
 }  // namespace surs
 
@@ -913,23 +928,30 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct GridProf {
+    std::mutex mu;
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<double> pts;
 } g_prof;
 }  // namespace
 
-extern "C" int surs_profile_enable(int on) {
+static void prof_reset_locked(bool on) {
     for (auto &e : g_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     g_prof.ev.clear();
     g_prof.pts.clear();
-    g_prof.on = on != 0;
+    g_prof.on = on;
+}
+
+extern "C" int surs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    prof_reset_locked(on != 0);
     return 0;
 }
 
-// launches: number of timed grid_mlp_kernel launches since enable; total_ms: sum of their durations;
+// launches: number of timed column-kernel launches since enable; total_ms: sum of their durations;
 // points: voxels they evaluated.  Synchronises on the recorded events and resets the counters.
 extern "C" int surs_profile_read(double *launches, double *total_ms, double *points) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
     double ms = 0, p = 0;
     for (size_t i = 0; i < g_prof.ev.size(); ++i) {
         SURS_HIP_CHECK(hipEventSynchronize(g_prof.ev[i].second));
@@ -941,12 +963,11 @@ extern "C" int surs_profile_read(double *launches, double *total_ms, double *poi
     if (launches) *launches = (double)g_prof.ev.size();
     if (total_ms) *total_ms = ms;
     if (points) *points = p;
-    const bool on = g_prof.on;
-    surs_profile_enable(on);
+    prof_reset_locked(g_prof.on);
     return 0;
 }
 
-// grid batches: fp32 mode evaluates GRID_BATCH voxels per pass; column mode COL_BATCH columns per pass
+// grid batches: the general fp32 mode evaluates GRID_BATCH voxels per pass; column mode COL_BATCH columns per pass
 static const long long GRID_BATCH = 65536;
 #ifndef SURS_COL_BATCH
 #define SURS_COL_BATCH 16384
@@ -960,8 +981,36 @@ static size_t col_ws_bytes(long long ncb) {
 
 extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
     (void)ry; (void)rz;
-    if (dtype == SURS_F32) return fp32_ws_bytes(GRID_BATCH);
-    return col_ws_bytes(COL_BATCH);
+    const size_t col = col_ws_bytes(COL_BATCH);
+    if (dtype == SURS_F32) {   // column kernel v5 where the sweep allows it, the layer kernels otherwise
+        const size_t gen = fp32_ws_bytes(GRID_BATCH);
+        return gen > col ? gen : col;
+    }
+    return col;
+}
+
+// SURS_GRID_F32=gemm keeps the fp32 sweep on the per-point layer kernels (A/B comparisons; the path of general calibrations)
+static bool grid_f32_use_columns() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SURS_GRID_F32");
+        v = (e && e[0] == 'g') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+static int grid_set_attributes() {
+    if (attrs_done(1)) return 0;
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, GRID5_LDS_BYTES));
+    return 0;
 }
 
 extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
@@ -970,6 +1019,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                                float *vol_lr, void *stream) {
     SURS_REQUIRE(mat && calib && feat_lr && feat_hr && mlp_blob && workspace && vol_hr && vol_lr, "null argument");
     SURS_REQUIRE(i1 >= i0 && ry > 0 && rz > 0, "bad grid range");
+    SURS_REQUIRE(dtype == SURS_F32 || dtype == SURS_BF16 || dtype == SURS_F16, "unknown dtype %d", dtype);
     SURS_REQUIRE(workspace_bytes >= surs_query_grid_workspace_bytes(ry, rz, dtype), "workspace too small");
     if (i1 == i0) return 0;
     hipStream_t st = as_stream(stream);
@@ -983,7 +1033,13 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
     fill_calib(src, calib, zmul, zdiv);
     const char *blob = (const char *)mlp_blob;
 
-    if (dtype == SURS_F32) {
+    // column mode needs: projected X,Y independent of k; world z a function of k only
+    const float cX = (float)(calib[0] * mat[2] + calib[1] * mat[6] + calib[2] * mat[10]);
+    const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
+    const bool columns = !(cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f);
+
+    if (dtype == SURS_F32 && !(columns && grid_f32_use_columns())) {
+        // general calibration: every voxel is its own point, the five layers are GEMMs on the split-bf16 layer kernels
         const long long total = (long long)(i1 - i0) * ry * rz;
         Fp32Workspace w = carve_fp32(workspace, GRID_BATCH);
         if ((rc = zero_pad_rows(st, w))) return rc;
@@ -997,11 +1053,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         }
         return 0;
     }
-    SURS_REQUIRE(dtype == SURS_BF16 || dtype == SURS_F16, "unknown dtype %d", dtype);
-    // column mode needs: projected X,Y independent of k; world z a function of k only
-    const float cX = (float)(calib[0] * mat[2] + calib[1] * mat[6] + calib[2] * mat[10]);
-    const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
-    if (cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f)
+    if (!columns)
         return fail(SURS_E_UNSUPPORTED,
                     "column kernel needs an axis-aligned orthographic sweep (X,Y independent of k); use SURS_F32");
     const long long ncols = (long long)(i1 - i0) * ry;
@@ -1014,38 +1066,17 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    // SURS_GRID_KERNEL selects the column kernel: 3 (default) = waves split the output channels, weights straight
-    // from L2 into registers; 4 = the same on the 16x16x32 MFMA shape (experimental: higher clock, more cycles, +1 %);
-    // 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.
+    // Reduced precision: SURS_GRID_KERNEL selects the column kernel: 3 (default) = waves split the output channels, weights
+    // straight from L2 into registers; 4 = the same on the 16x16x32 MFMA shape (experimental: higher clock, more cycles,
+    // +1 %); 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.
     // 1 and 2 are bit-identical and kept as the regression reference of 3, which differs from them only in the
-    // summation order of the final 128-term dot product.
+    // summation order of the final 128-term dot product.  SURS_F32: kernel v5 (split-f16 operands, fp32-grade).
     static int kver = -1;
     if (kver < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
         kver = (e && e[0] >= '1' && e[0] <= '4') ? (e[0] - '0') : 3;
     }
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[dtype]) {
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_BF16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_F16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_BF16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_F16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_BF16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_F16>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
-        if (dtype == SURS_BF16)
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
-        else
-            SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_F16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
-        attr_set[dtype] = true;
-    }
+    if ((rc = grid_set_attributes())) return rc;
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
         const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
@@ -1078,6 +1109,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.zvec = (const float *)(blob + h.zvec);
         a.core = blob + h.core;
         a.core16 = blob + h.core16;
+        a.corex = blob + h.corex;
         a.b1frag = blob + h.b1frag;
         a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
         a.vol_hr = vol_hr + (size_t)c0 * rz;
@@ -1092,12 +1124,19 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.zdiv = zdiv;
         const unsigned grid = (unsigned)((nc < cus) ? nc : cus);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_prof.on) {
+        bool prof;
+        {
+            std::lock_guard<std::mutex> lock(g_prof.mu);
+            prof = g_prof.on;
+        }
+        if (prof) {
             SURS_HIP_CHECK(hipEventCreate(&e0));
             SURS_HIP_CHECK(hipEventCreate(&e1));
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
-        if (kver == 4) {
+        if (dtype == SURS_F32) {
+            hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
+        } else if (kver == 4) {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v4<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
             else
@@ -1118,7 +1157,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         SURS_LAUNCH_CHECK();
 #ifdef SURS_V3_TRACE
-        if (kver >= 3 && c0 == 0 && getenv("SURS_V3_TRACE")) {
+        if (dtype != SURS_F32 && kver >= 3 && c0 == 0 && getenv("SURS_V3_TRACE")) {
             unsigned long long t[64];
             SURS_HIP_CHECK(hipStreamSynchronize(st));
             SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
@@ -1133,8 +1172,9 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                     cyc / us * 1e-3, cyc / ((double)((nc + grid - 1) / grid) * ((rz + 127) / 128)));
         }
 #endif
-        if (g_prof.on) {
+        if (prof) {
             SURS_HIP_CHECK(hipEventRecord(e1, st));
+            std::lock_guard<std::mutex> lock(g_prof.mu);
             g_prof.ev.emplace_back(e0, e1);
             g_prof.pts.push_back((double)nc * rz);
         }
