@@ -1,21 +1,30 @@
 """Headline benchmark: one dense 512^3 reconstruction of one subject (BASELINE.json configs[2] at N=1,
-configs[3] at N>1) = image encoder -> 134 217 728 occupancy queries (bf16 MFMA column kernel) -> 2x Lewiner
-marching cubes -> meshes on the host.  A "step" is one such reconstruction on a synthetic 512x512 image with
+configs[3] / configs[4] at N>1) = image encoder -> 134 217 728 occupancy queries (column kernel on the matrix cores) ->
+2x Lewiner marching cubes -> meshes on the host.  A "step" is one such reconstruction on a synthetic 512x512 image with
 seeded random-init weights; `value` is queries per second over the whole job.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`--precision bf16` (default: what BASELINE configs[2] names) | `fp16` (configs[4]) | `fp32` (the parity-grade sweep:
+column kernel v5, split-f16 operands, logits within 1e-4 of the reference).  At N=1 the line also carries
+`config.fp32_mode` - the same step timed in fp32 - and `config.precision_acceptance` - what the reduced precisions do to
+the field and the meshes at full size against the fp32 sweep (tools/precision_report.py; asserted in
+tests/test_gpu_precision.py).
+
 N > 1, default `--mode replicas` (BASELINE configs[4], weak scaling): one subject per GPU (image seeds 1..N), every rank
 runs the whole reconstruction, no data-path collective - subjects are independent, which is how a batch of inputs
 is served; `value` = N x 512^3 queries per max-over-ranks step time.
 `--mode slab` (BASELINE configs[3], strong scaling of ONE subject): the grid is split into contiguous x-slabs, one per
-rank, every rank runs the (small) encoder redundantly, the occupancy slabs are gathered to rank 0 over RCCL (the one real
-exchange step of the path), rank 0 extracts the meshes.  Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle - test infrastructure, the
+rank, every rank runs the (small) encoder redundantly and extracts the mesh of its own slab while it sweeps (marching
+cubes sharded with a one-plane halo); the ranks exchange the halo planes, the per-rank vertex / face counts and the
+vertex ids of the boundary planes, and rank 0 receives meshes, not volumes (dist.reconstruction_sharded).
+Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle - test infrastructure, the
 checker, never the thing measured - on a bounded sample of the same grid.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,8 +36,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_QUERY = 4564998        # 2 x 2 282 499 MAC, both classifiers (SURVEY.md 8d / BASELINE.md section 3)
-PEAK_MFMA = {"bf16": 2.5e15, "fp16": 2.5e15}   # dense, MI355X_MICROARCH.md
+FLOP_PER_QUERY = 4564998        # 2 x 2 282 499 MAC, both classifiers, as the reference computes them
+FLOP_EXECUTED = 2752512         # what the column kernels run through the matrix pipe per query and per product (A.4)
+PRODUCTS = {"bf16": 1, "fp16": 1, "fp32": 3}   # MFMA products per MAC (fp32: hi*hi + hi*lo + lo*hi on f16 parts)
+PEAK_MFMA = 2.5e15              # dense bf16 / f16, MI355X_MICROARCH.md
 RES = 512
 IMG = 512
 
@@ -38,11 +49,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--resolution", type=int, default=RES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip config.fp32_mode and config.precision_acceptance (N=1)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "slab"],
-                    help="N>1 only: one subject per GPU (weak) or one subject split into x-slabs + RCCL gather (strong)")
+                    help="N>1 only: one subject per GPU (weak) or one subject split into x-slabs, meshes extracted per slab (strong)")
     ap.add_argument("--image", default="noise", choices=["smooth", "noise"],
                     help="synthetic input: white noise x mask (SURVEY 8d, default) or band-limited; with random-init weights both give a noise-like field")
     args = ap.parse_args()
@@ -64,8 +76,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     R = args.resolution
-    opt = options.BaseOptions().parse(["--loadSize", "1024", "--residual", "--b_min", "-0.5", "-0.5", "-0.5", "--b_max", "0.5",
-                                       "0.5", "0.5", "--resolution", str(R), "--precision", args.precision])
+    flags = ["--loadSize", "1024", "--residual", "--b_min", "-0.5", "-0.5", "-0.5", "--b_max", "0.5", "0.5", "0.5",
+             "--resolution", str(R)]
+    opt = options.BaseOptions().parse(flags + ["--precision", args.precision])
     sd = weights.synthetic_state_dict(opt, seed=0)
     net = model.SuRSNet(opt).to(device=dev)
     net.load_state_dict(sd)
@@ -77,106 +90,151 @@ def main():
     b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
     lib = _lib.lib()
 
-    stage_ms = {"encoder": 0.0, "query": 0.0, "gather": 0.0, "mesh": 0.0}
-    last = {}
-    streamed = [False]
-
-    def step(timed):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        ev[0].record()
-        _, f_lr, f_hr = net.super_res(image)
-        net.filter_hr(f_hr)
-        net.filter_lr(f_lr)
-        ev[1].record()
-        m = None
-        if not slab:
-            # the product path of reconstruction(): marching cubes and the mesh copies pipelined into the sweep (from the
-            # second reconstruction on: the first one sizes the mesh buffers); ev[2] = end of the sweep's last launch
-            m = mesh_util.reconstruction_streamed(opt, net, calib, R, b_min, b_max, None, want_normals=False, timing=ev[2])
-            streamed[0] = m is not None
-            if m is not None:
-                ev[3].record()
-        if m is None:
-            i0, i1 = sdist.slab_range(R, rank, world) if slab else (0, R)
-            vh, vl, mat = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max, None, i0, i1)
-            ev[2].record()
-            full_hr = sdist.gather_slabs(vh, R, 0) if slab else vh
-            full_lr = sdist.gather_slabs(vl, R, 0) if slab else vl
-            ev[3].record()
-            if rank == 0 or not slab:
-                # gen_mesh keeps vertices and faces only (lib/train_util.py:72)
-                m = mesh_util.meshes_from_volumes(net, [full_hr, full_lr], mat, want_normals=False)
-        if m is not None:
-            last["verts_hr"], last["faces_hr"], last["verts_lr"], last["faces_lr"] = len(m[0]), len(m[1]), len(m[4]), len(m[5])
-        ev[4].record()
-        if timed:
-            torch.cuda.synchronize()
-            # streamed path: "query" = the sweep (the marching cubes of finished layers run beside it on their own streams),
-            # "mesh" = what is left after the last launch (last layers, last copies); the slab path also has "gather"
-            names = ("encoder", "query", "mesh", "gather") if streamed[0] else ("encoder", "query", "gather", "mesh")
-            for k, (a, b) in zip(names, zip(ev[:-1], ev[1:])):
-                stage_ms[k] += a.elapsed_time(b)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    lib.surs_profile_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    dt = time.perf_counter() - t0
-    launches, kms, kpts = C.c_double(0), C.c_double(0), C.c_double(0)
-    lib.surs_profile_read(C.byref(launches), C.byref(kms), C.byref(kpts))
-    lib.surs_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def run(o, steps, warmup):
+        """warmup untimed steps, then `steps` timed ones between barriers; -> (seconds, per-stage ms, mesh sizes, kernel timing)."""
+        stage_ms = {"encoder": 0.0, "query": 0.0, "exchange": 0.0, "mesh": 0.0}
+        last = {}
+
+        def step(timed):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            _, f_lr, f_hr = net.super_res(image)
+            net.filter_hr(f_hr)
+            net.filter_lr(f_lr)
+            ev[1].record()
+            if slab:
+                m = sdist.reconstruction_sharded(o, net, calib, R, b_min, b_max, want_normals=False, timing=ev[2])
+            else:
+                # the product path of reconstruction(): marching cubes and the mesh copies pipelined into the sweep (from
+                # the second reconstruction on: the first one sizes the mesh buffers); ev[2] = end of the sweep's last launch
+                m = mesh_util.reconstruction_streamed(o, net, calib, R, b_min, b_max, None, want_normals=False, timing=ev[2])
+                if m is None:
+                    vh, vl, mat = mesh_util.eval_volumes(o, net, calib, R, b_min, b_max, None)
+                    ev[2].record()
+                    m = mesh_util.meshes_from_volumes(net, [vh, vl], mat, want_normals=False)   # gen_mesh keeps vertices and faces only
+            if m is not None:
+                last["verts_hr"], last["faces_hr"], last["verts_lr"], last["faces_lr"] = len(m[0]), len(m[1]), len(m[4]), len(m[5])
+            ev[3].record()
+            if timed:
+                torch.cuda.synchronize()
+                # "query" = the sweep (the marching cubes of finished layers run beside it on their own streams), "mesh" = what is
+                # left after the last launch (last layers, last copies; in slab mode also the exchange of counts / ids / meshes)
+                for k, (a, b) in zip(("encoder", "query", "mesh"), zip(ev[:-1], ev[1:])):
+                    stage_ms[k] += a.elapsed_time(b)
+
+        for _ in range(warmup):
+            step(False)
+        lib.surs_profile_enable(1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        barrier()
+        dt = time.perf_counter() - t0
+        launches, kms, kpts = C.c_double(0), C.c_double(0), C.c_double(0)
+        lib.surs_profile_read(C.byref(launches), C.byref(kms), C.byref(kpts))
+        lib.surs_profile_enable(0)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        k_avg_ms = kms.value / max(launches.value, 1.0)
+        return dt, {k: v / steps for k, v in stage_ms.items()}, dict(last), (k_avg_ms, kpts.value / max(launches.value, 1.0))
+
+    def roofline(prec, k_avg_ms, k_pts):
+        """The column kernel of this precision, timed with HIP events around every launch on its launch stream."""
+        nprod = PRODUCTS[prec]
+        alg = k_pts * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
+        exe = k_pts * FLOP_EXECUTED * nprod / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
+        peak = PEAK_MFMA / 1e12
+        r = {"kernel": "grid_mlp_kernel_v5 (split-f16, 3 products per MAC)" if prec == "fp32" else
+                       "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "3")[:1], prec),
+             "bound": "mfma", "unit": "TFLOP/s",
+             # contract fields: ALGORITHMIC flops (the reference's un-reduced 4 564 998 FLOP per query, SURVEY 8d) per launch /
+             # the launch's duration; peak = the dense f16/bf16 MFMA peak divided by the MFMA products one fp32-grade MAC costs
+             "achieved": alg, "peak": peak / nprod, "frac": alg / (peak / nprod),
+             "achieved_algorithmic": alg, "frac_algorithmic": alg / (peak / nprod),
+             # what the matrix pipe actually executes (column-constant reduction: 2 752 512 FLOP per query and product)
+             "achieved_executed": exe, "frac_executed": exe / peak, "mfma_products_per_mac": nprod,
+             "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts,
+             "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": FLOP_EXECUTED * nprod,
+             "traffic": None}
+        # HBM bytes / MFMA-busy cycles come from separate rocprofv3 --pmc passes (tools/profile_round.sh) and are only valid
+        # for the library they were collected on: they are reported when the sha256 of libsurs_hip.so matches, else null
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                summary = json.load(open(pmc))
+                entry = summary.get("kernels", {}).get(prec)
+                same = summary.get("lib_sha256") == hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+                r["pmc"] = {"source": "profiles/pmc_summary.json (separate rocprofv3 --pmc passes, not this run)",
+                            "lib_sha256_profiled": summary.get("lib_sha256"), "matches_this_library": same}
+                if entry and same:
+                    r["traffic"] = entry.get("hbm_bytes_per_launch")
+                    r["mfma_busy_fraction_pmc"] = entry.get("mfma_busy_fraction")
+            except Exception:
+                pass
+        return r
+
+    dt, stage_ms, last, (k_avg_ms, k_pts) = run(opt, args.steps, args.warmup)
+
+    extras = {}
+    if world == 1 and not args.no_extras and args.precision != "fp32":
+        # the same step in the parity-grade precision (fp32-grade column kernel; same network object, same blob)
+        o32 = options.BaseOptions().parse(flags + ["--precision", "fp32"])
+        d32, st32, last32, (k32, p32) = run(o32, 2, 1)
+        extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
+                               "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32),
+                               "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
+    if world == 1 and not args.no_extras and R == RES:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import precision_report as pr
+            acc = {}
+            for name, inputs in (("body", pr.body_inputs(dev)), ("noise", (sd,) + tuple(net.features()))):
+                rep = pr.report(inputs[0], inputs[1], inputs[2], R, dev)
+                acc[name] = {p: {t: {"max_abs_dlogit": rep[p][t]["max_abs_dlogit"], "mean_abs_dlogit": rep[p][t]["mean_abs_dlogit"],
+                                     "flipped_voxels": rep[p][t]["flipped_voxels"],
+                                     "verts": rep[p][t]["mesh"]["verts"], "verts_fp32": rep[p][t]["mesh"]["verts_ref"],
+                                     "faces": rep[p][t]["mesh"]["faces"], "faces_fp32": rep[p][t]["mesh"]["faces_ref"],
+                                     "nearest_vertex_voxels": {s: {k: rep[p][t]["mesh"][s].get(k) for k in ("mean", "p999", "max", "unmatched", "n")}
+                                                               for s in ("to_ref", "from_ref")}}
+                                 for t in ("hr", "lr")} for p in ("bf16", "fp16")}
+                acc[name]["sweep_s"] = rep["sweep_s"]
+            acc["reference"] = "fp32-grade sweep (column kernel v5) on the same features and weights, 512^3"
+            acc["why_bf16"] = ("BASELINE configs[2] names bf16: fp32's exponent range, no activation can overflow; fp16 (configs[4]) is "
+                               "8x tighter at 0.93x the rate but saturates at 65504 - `--precision fp16` / `fp32` select the others")
+            extras["precision_acceptance"] = acc
+        except Exception as e:   # measurement extra: never lose the bench line over it
+            extras["precision_acceptance"] = {"error": repr(e)}
 
     if rank == 0:
         queries = float(R) ** 3 * (1 if (slab or world == 1) else world)   # replicas: one full grid per rank
         ms_per_step = dt / args.steps * 1e3
         value = queries * args.steps / dt
-        # dominant kernel: grid_mlp_kernel on this rank, HIP events around every launch
-        k_avg_ms = kms.value / max(launches.value, 1.0)
-        k_pts_per_launch = kpts.value / max(launches.value, 1.0)
-        achieved = k_pts_per_launch * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
-        peak = PEAK_MFMA[args.precision] / 1e12
-        traffic = mfma_busy = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):   # counters are collected in their own rocprofv3 --pmc passes (tools/profile_round.sh)
-            try:
-                summary = json.load(open(pmc))
-                traffic = summary.get("grid_mlp_kernel_hbm_bytes_per_launch")
-                mfma_busy = summary.get("mfma_busy_fraction")
-            except Exception:
-                traffic = mfma_busy = None
+        cfg_no = 2 if world == 1 else (3 if slab else 4)
         out = {
             "metric": "occupancy queries/sec (dense %d^3 reconstruction: encoder + query sweep + 2x marching cubes)" % R,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %s 512x512 synthetic image%s, %d^3 grid each, bf16 MFMA classifier cores, "
-                                   "HIP marching cubes x2 pipelined into the sweep%s" % (2 if world == 1 else (3 if slab else 4),
-                                                                 "one" if (slab or world == 1) else str(world),
-                                                                 "" if (slab or world == 1) else "s (one subject per GPU, replicas)", R,
-                                                                 ", x-slab per rank + RCCL gather" if slab else ""),
+            "config": {"workload": "BASELINE configs[%d]: %s 512x512 synthetic image%s, %d^3 grid each, %s classifier cores on MFMA, "
+                                   "HIP marching cubes x2 pipelined into the sweep%s" %
+                                   (cfg_no, "one" if (slab or world == 1) else str(world),
+                                    "" if (slab or world == 1) else "s (one subject per GPU, replicas)", R,
+                                    "split-f16 (fp32-grade)" if args.precision == "fp32" else args.precision,
+                                    ", x-slab per rank, marching cubes per slab, meshes to rank 0" if slab else ""),
                        "resolution": R, "image": IMG, "image_kind": args.image, "queries_per_step": int(queries),
-                       "reconstruction_s": ms_per_step / 1e3,
-                       "stage_ms_rank0": {k: v / args.steps for k, v in stage_ms.items()},
-                       "mesh": dict(last), "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world)},
-            "roofline": {"kernel": "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "3")[:1], args.precision), "bound": "mfma", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts_per_launch,
-                         "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": 2752512,
-                         "mfma_busy_fraction_pmc": mfma_busy},
+                       "reconstruction_s": ms_per_step / 1e3, "stage_ms_rank0": stage_ms,
+                       "mesh": last, "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world)},
+            "roofline": roofline(args.precision, k_avg_ms, k_pts),
         }
+        out["config"].update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, sd, R, b_min, b_max)
         print(json.dumps(out))

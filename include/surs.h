@@ -216,6 +216,24 @@ int surs_mc_lewiner_range(const float *vol, int n0, int n1, int n2, int layer_be
                           int32_t *faces, int cap_faces, surs_mc_counts *run, void *stream);
 int surs_mc_normalize(float *normals, int n_verts, void *stream);
 
+/* Slab mode (the grid split into contiguous axis-0 slabs over ranks, marching cubes per slab; the reference
+ * has no counterpart - it runs lib/mesh_util.py:40,45 on the whole volume).  `vol` is ONE slab [n0][n1][n2] whose plane 0 is
+ * plane `z_offset` of the whole grid and whose last plane is the next slab's first plane (the halo), except for the top
+ * slab.  surs_mc_lewiner_range_slab is surs_mc_lewiner_range (vertices and faces only) with two differences: vertex
+ * coordinates are those of the whole grid (bit-identical to the one-piece extraction), and for z_offset > 0 the first cell
+ * layer does not create the vertices of the x- / y-edges in plane 0 - the slab below owns them - but references them as
+ * -(2 + slot), slot = axis * n1 * n2 + y * n2 + x.  Vertex / face numbers are local to the slab (run starts at 0).
+ * Afterwards: surs_mc_slab_top_ids copies the ids (local numbering) of the x- / y-edge vertices in the slab's last plane to
+ * ids[2][n1][n2] (entries of edges the surface does not cross are undefined) - they go to the slab above; and
+ * surs_mc_slab_fixup rewrites the slab's faces to the whole mesh's numbering: v >= 0 -> v + own_offset, v < 0 ->
+ * below_ids[-v - 2] + below_offset, the offsets being the exclusive sums of the slabs' vertex counts.  Concatenating the
+ * slabs' vertices and faces in slab order then gives exactly the one-piece result. */
+int surs_mc_lewiner_range_slab(const float *vol, int n0, int n1, int n2, int layer_begin, int layer_end, double level,
+                               void *workspace, size_t workspace_bytes, float *verts, int cap_verts, int32_t *faces, int cap_faces,
+                               surs_mc_counts *run, int z_offset, void *stream);
+int surs_mc_slab_top_ids(const void *workspace, size_t workspace_bytes, int n0, int n1, int n2, int32_t *ids, void *stream);
+int surs_mc_slab_fixup(int32_t *faces, long long n_faces, int own_offset, const int32_t *below_ids, int below_offset, void *stream);
+
 /* out[i] = mat[:3,:3] @ verts[i] + mat[:3,3] in float64 (mat HOST [12] doubles, rows 0..2 of the 4x4 index->world
  * matrix): the vertex transform of lib/mesh_util.py:42-43,47-48.  verts fp32 [n][3], out fp64 [n][3]. */
 int surs_transform_points(const float *verts, int n, const double *mat, double *out, void *stream);

@@ -71,6 +71,9 @@ _SIGS = {
     "surs_mc_lewiner_range": (C.c_int, [_vp, _i, _i, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i,
                                         C.POINTER(McCounts), _vp]),
     "surs_mc_normalize": (C.c_int, [_vp, _i, _vp]),
+    "surs_mc_lewiner_range_slab": (C.c_int, [_vp, _i, _i, _i, _i, _i, C.c_double, _vp, _sz, _vp, _i, _vp, _i, C.POINTER(McCounts), _i, _vp]),
+    "surs_mc_slab_top_ids": (C.c_int, [_vp, _sz, _i, _i, _i, _vp, _vp]),
+    "surs_mc_slab_fixup": (C.c_int, [_vp, C.c_longlong, _i, _vp, _i, _vp]),
     "surs_mc_lewiner": (C.c_int, [_vp, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i, C.POINTER(McCounts), _vp]),
 }
 EXPORTS = sorted(_SIGS)

@@ -49,6 +49,7 @@ struct Dims {
     long long ncells;
     long long cell_begin, cell_end;   // the flat (sweep-order) cell range this call processes
     int base_verts, base_faces;      // vertices / triangles produced by earlier ranges
+    int zoff;                        // slab mode: index of the volume's plane 0 in the whole grid (0 = the grid's bottom)
 };
 
 struct Tiling {
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(THREADS) void mc_classify_kernel(const float *__res
         if (cell.index != 0 && cell.index != 255) {
             const Tiling t = select_tiling(cell.v, cell.index);
             int nt, nv;
-            count_cell(t, owned_mask(x, y, z), nt, nv);
+            count_cell(t, owned_mask(x, y, z + d.zoff), nt, nv);
             nt_sum += nt;
             nv_sum += nv;
             na_sum += 1;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
     float lo = 0, hi = 0;
     load_cell(vol, d, x, y, z, level, cell, lo, hi);
     const Tiling t = decode_cell(ac.code);
-    const unsigned own = owned_mask(x, y, z);
+    const unsigned own = owned_mask(x, y, z + d.zoff);
     int vid = ac.vid0;
     unsigned seen = 0;
     for (int i = 0; i < 3 * t.nt; ++i) {
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
                 const double w = 1.0 / (MC_EPS + fabs(cell.v[k]));
                 fx += cx[k] * w; fy += cy[k] * w; fz += cz[k] * w; ff += w;
             }
-            px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)z + fz / ff;
+            px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)(z + d.zoff) + fz / ff;
         } else {
             const int dx1 = MCL_EDGE_DX[2 * e], dx2 = MCL_EDGE_DX[2 * e + 1];
             const int dy1 = MCL_EDGE_DY[2 * e], dy2 = MCL_EDGE_DY[2 * e + 1];
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
             double fx = 0, fy = 0, fz = 0, ff = 0;
             fx += (double)dx1 * w1; fy += (double)dy1 * w1; fz += (double)dz1 * w1; ff += w1;
             fx += (double)dx2 * w2; fy += (double)dy2 * w2; fz += (double)dz2 * w2; ff += w2;
-            px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)z + fz / ff;
+            px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)(z + d.zoff) + fz / ff;
         }
         int axis, vx, vy, vz;
         edge_slot(e, x, y, z, axis, vx, vy, vz);
@@ -689,6 +690,25 @@ __global__ void transform_points_kernel(const float *__restrict__ v, int n, Affi
     for (int r = 0; r < 3; ++r) out[3 * (size_t)i + r] = ((a.m[4 * r] * x + a.m[4 * r + 1] * y) + a.m[4 * r + 2] * z) + a.m[4 * r + 3];
 }
 
+// ---------------------------------------------------------------- slab mode (one volume split along axis 0 over ranks)
+// The cells of a slab's first layer reference the vertices of the x- and y-edges in its plane 0, which the slab below
+// created and numbered.  Until those ids arrive the tables hold a reference to the edge itself: -(2 + slot),
+// slot = axis * ny * nx + y * nx + x; mc_slab_fixup_kernel resolves them once the ranks have exchanged ids and counts.
+__global__ void mc_slab_refs_kernel(int *__restrict__ evid, size_t nvox, int plane) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * plane) return;
+    const int axis = i / plane, r = i - axis * plane;
+    evid[(size_t)axis * nvox + r] = -(2 + i);
+}
+
+__global__ void mc_slab_fixup_kernel(int *__restrict__ faces, long long n, int own_offset, const int *__restrict__ below_ids,
+                                     int below_offset) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = faces[i];
+    faces[i] = v >= 0 ? v + own_offset : below_ids[-v - 2] + below_offset;
+}
+
 }  // namespace mc
 }  // namespace surs
 
@@ -723,8 +743,9 @@ extern "C" size_t surs_mc_workspace_bytes(int n0, int n1, int n2) {
 // needs the counts to size the launches that follow).
 static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_begin, long long cell_end, double level,
                     void *workspace, size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
-                    int32_t *faces, int cap_faces, bool count_only, surs_mc_counts *run, hipStream_t st) {
+                    int32_t *faces, int cap_faces, bool count_only, surs_mc_counts *run, hipStream_t st, int zoff = 0) {
     Dims d;
+    d.zoff = zoff;
     d.nz = n0; d.ny = n1; d.nx = n2;
     d.cz = n0 - 1; d.cy = n1 - 1; d.cx = n2 - 1;
     d.ncells = (long long)d.cz * d.cy * d.cx;
@@ -819,6 +840,52 @@ extern "C" int surs_mc_lewiner_range(const float *vol, int n0, int n1, int n2, i
     const long long per_layer = (long long)(n1 - 1) * (n2 - 1);
     return mc_range(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
                     normals, values, cap_verts, faces, cap_faces, false, run, as_stream(stream));
+}
+
+extern "C" int surs_mc_lewiner_range_slab(const float *vol, int n0, int n1, int n2, int layer_begin, int layer_end, double level,
+                                          void *workspace, size_t workspace_bytes, float *verts, int cap_verts, int32_t *faces,
+                                          int cap_faces, surs_mc_counts *run, int z_offset, void *stream) {
+    SURS_REQUIRE(vol && workspace && run && verts && faces, "null argument");
+    SURS_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "Input array must be at least 2x2x2.");
+    SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
+    SURS_REQUIRE(layer_begin >= 0 && layer_begin <= layer_end && layer_end <= n0 - 1, "bad layer range");
+    SURS_REQUIRE(z_offset >= 0, "negative z_offset");
+    hipStream_t st = as_stream(stream);
+    if (z_offset > 0 && layer_begin == 0) {
+        size_t off[5];
+        mc_ws_layout(n0, n1, n2, off);
+        int *evid = (int *)((char *)workspace + off[4]);
+        const int plane = n1 * n2;
+        hipLaunchKernelGGL(mc_slab_refs_kernel, dim3(ceil_div(2 * plane, 256)), dim3(256), 0, st, evid, (size_t)n0 * n1 * n2, plane);
+        SURS_LAUNCH_CHECK();
+    }
+    const long long per_layer = (long long)(n1 - 1) * (n2 - 1);
+    return mc_range(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
+                    nullptr, nullptr, cap_verts, faces, cap_faces, false, run, st, z_offset);
+}
+
+extern "C" int surs_mc_slab_top_ids(const void *workspace, size_t workspace_bytes, int n0, int n1, int n2, int32_t *ids, void *stream) {
+    SURS_REQUIRE(workspace && ids && n0 >= 2 && n1 >= 2 && n2 >= 2, "bad argument");
+    SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
+    size_t off[5];
+    mc_ws_layout(n0, n1, n2, off);
+    const int *evid = (const int *)((const char *)workspace + off[4]);
+    const size_t nvox = (size_t)n0 * n1 * n2, plane = (size_t)n1 * n2;
+    for (int axis = 0; axis < 2; ++axis)
+        SURS_HIP_CHECK(hipMemcpyAsync(ids + axis * plane, evid + axis * nvox + (size_t)(n0 - 1) * plane, plane * sizeof(int),
+                                      hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
+extern "C" int surs_mc_slab_fixup(int32_t *faces, long long n_faces, int own_offset, const int32_t *below_ids, int below_offset,
+                                  void *stream) {
+    if (n_faces <= 0) return 0;
+    SURS_REQUIRE(faces, "null argument");
+    const long long n = 3 * n_faces;
+    hipLaunchKernelGGL(mc_slab_fixup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), faces, n, own_offset,
+                       below_ids, below_offset);
+    SURS_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int surs_mc_normalize(float *normals, int n_verts, void *stream) {

@@ -1,9 +1,23 @@
-"""Multi-GPU sharding of the dense sweep: one process per GPU, contiguous slabs along array axis 0 (world x, the
-slowest index of create_grid's flattening, /root/reference/lib/sdf.py:14-15,28), so concatenating the slabs in rank
-order reproduces the single-GPU volume bit for bit.  The only exchange step is the gather of the per-rank
-occupancy slabs to the rank that runs marching cubes (RCCL over xGMI when the backend is "nccl"; the same code runs
-on gloo/CPU tensors in the tests).  The reference has no distributed code; this is new.
+"""Multi-GPU sharding of ONE dense reconstruction (BASELINE configs[3]): one process per GPU, contiguous slabs along array
+axis 0 (world x, the slowest index of create_grid's flattening, /root/reference/lib/sdf.py:14-15,28, and the outermost
+loop of Lewiner's sweep).  The reference has no distributed code; this is new.
+
+Every rank sweeps its slab AND extracts its slab's part of both meshes while it sweeps (surs_mc_lewiner_range_slab), so
+rank 0 receives meshes, not volumes.  Exchange steps (RCCL over xGMI when the backend is "nccl"; the same code runs on
+gloo with host staging in the tests):
+
+  1. halo        rank r+1 -> r   the first plane of each field (2 x R^2 fp32), as soon as the first launch has written it:
+                                 the last cell layer of a slab needs the plane above it
+  2. counts      all_gather      (n_verts, n_faces, min, max) per field: exclusive vertex offsets, the level-range check
+  3. boundary    rank r -> r+1   the vertex ids of the x- / y-edges in the slab's top plane (2 x 2 x R^2 int32): the first
+                                 cell layer of slab r+1 references vertices that slab r created
+  4. meshes      rank r -> dst   vertices (world space, float64) and faces (int32, whole-mesh numbering)
+
+Concatenated in rank order the result is bit-identical to the single-GPU extraction (tests/test_gpu_dist.py): vertex
+coordinates are computed in whole-grid coordinates, a slab numbers its vertices in sweep order, and the faces are renumbered
+with the exclusive sums of the vertex counts.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -15,39 +29,248 @@ def slab_range(resolution, rank, world):
     return i0, i0 + base + (1 if rank < rem else 0)
 
 
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _host_staged(t):
+    """gloo moves host memory only: device tensors are staged through the host there (tests); RCCL takes them as they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+class Exchange:
+    """One batch of point-to-point transfers (grouped like ncclGroupStart/End, so a ring of sends and receives cannot
+    deadlock).  start() enqueues them behind the work already on the current stream; wait() makes the current stream
+    (RCCL) or the host (gloo) wait for them."""
+
+    def __init__(self, group=None):
+        self.group, self.ops, self.keep, self.post, self.works = group, [], [], [], []
+
+    def send(self, t, dst):
+        t = t.contiguous()
+        if _host_staged(t):
+            t = t.cpu()     # synchronises: the producer of t has finished
+        self.keep.append(t)
+        self.ops.append(dist.P2POp(dist.isend, t, dst, self.group))
+
+    def recv(self, out, src):
+        assert out.is_contiguous()
+        if _host_staged(out):
+            tmp = torch.empty(out.shape, dtype=out.dtype)
+            self.post.append((out, tmp))
+            out = tmp
+        self.keep.append(out)
+        self.ops.append(dist.P2POp(dist.irecv, out, src, self.group))
+
+    def start(self):
+        self.works = dist.batch_isend_irecv(self.ops) if self.ops else []
+        return self
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for out, tmp in self.post:
+            out.copy_(tmp)
+        self.works, self.post = [], []
+
+
+def all_gather_rows(row, device, group=None):
+    """row: sequence of floats -> float64 array [world, len(row)] (one tiny all_gather; on the device for RCCL)."""
+    world, _ = _world(group)
+    on = device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    mine = torch.tensor([float(v) for v in row], dtype=torch.float64, device=on)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return torch.stack(out).cpu().numpy()
+
+
 def gather_slabs(local, resolution, dst=0, group=None):
-    """local: [n_rank, R, R] tensor of this rank's slab.  Returns the full [R, R, R] tensor on `dst`, None elsewhere."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    """local: [n_rank, R, R] tensor of this rank's slab.  Returns the full [R, R, R] tensor on `dst`, None elsewhere: the
+    volume-level exchange (used when normals are wanted, and by tools that need the whole field on one rank).  The slabs
+    land directly in their place of one preallocated volume - no per-rank buffers, no concatenation copy."""
+    world, rank = _world(group)
+    if world == 1:
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sizes = [slab_range(resolution, r, world) for r in range(world)]
-    nmax = max(b - a for a, b in sizes)
-    plane = local.shape[1:]
-    if local.shape[0] == nmax:
-        send = local.contiguous()
-    else:  # pad to the common size (collectives want equal shapes)
-        send = torch.zeros((nmax,) + tuple(plane), dtype=local.dtype, device=local.device)
-        send[: local.shape[0]] = local
+    ex = Exchange(group)
+    full = None
     if rank == dst:
-        bufs = [torch.empty_like(send) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst, group=group)
-        return torch.cat([bufs[r][: sizes[r][1] - sizes[r][0]] for r in range(world)], 0)
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+        full = torch.empty((resolution,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        for r in range(world):
+            a, b = slab_range(resolution, r, world)
+            if r == rank:
+                full[a:b].copy_(local)
+            elif b > a:
+                ex.recv(full[a:b], r)
+    elif local.shape[0] > 0:
+        ex.send(local, dst)
+    ex.start().wait()
+    return full
 
 
-def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, dst=0, want_mesh=True):
-    """Each rank sweeps its slab of the grid, slabs are gathered on `dst`, which extracts both meshes.
-    Returns the 8-tuple of mesh_util.reconstruction on `dst`, None on the other ranks."""
-    from . import mesh_util
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    i0, i1 = slab_range(resolution, rank, world)
-    vh, vl, mat = mesh_util.eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, i0, i1)
-    full_hr = gather_slabs(vh, resolution, dst)
-    full_lr = gather_slabs(vl, resolution, dst)
-    if rank != dst:
+def offsets_from_counts(counts):
+    """counts [world] -> exclusive prefix sums (int64): where each rank's vertices / faces start in the whole mesh."""
+    c = np.asarray(counts, np.int64)
+    return np.concatenate([[0], np.cumsum(c)[:-1]])
+
+
+def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, dst=0, want_normals=False,
+                           timing=None, group=None):
+    """One reconstruction on all ranks of the group: each rank sweeps the x-slab slab_range(R, rank, world) and extracts its
+    part of the two meshes.  Returns the 8-tuple of mesh_util.reconstruction on `dst` (normals / values None), None on the
+    other ranks.  Every rank raises the same ValueError / RuntimeError as marching_cubes_lewiner when the level is outside
+    the whole volume's range / there is no surface."""
+    from . import mesh_util, native
+    from .sdf import create_grid
+    world, rank = _world(group)
+    R = int(resolution)
+    if world == 1:
+        return mesh_util.reconstruction(opt, net, net._device(), calib_tensor, R, b_min, b_max, use_octree=False,
+                                        want_normals=want_normals)
+    if want_normals:
+        raise NotImplementedError("slab mode returns vertices and faces (what gen_mesh keeps); normals accumulate across slabs")
+    if R < 2 * world:
+        raise ValueError("resolution %d is too small for %d slabs (every rank needs at least two planes)" % (R, world))
+    i0, i1 = slab_range(R, rank, world)
+    nloc, halo = i1 - i0, rank < world - 1
+    _, mat = create_grid(R, R, R, b_min, b_max, transform=transform)
+    m12 = mat[:3].reshape(-1)
+    calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
+    fl, fh = net.features()
+    zmul, zdiv = net._zscale()
+    prec = getattr(opt, "precision", "fp32")
+    blob = net._mlp_blob()
+    ws = net._workspace()
+    dev = blob.device
+    vols = [torch.empty((nloc + (1 if halo else 0), R, R), dtype=torch.float32, device=dev) for _ in range(2)]
+    keys = ("slab", 0), ("slab", 1)
+    first = any(ws.mc_capacity.get(k) is None for k in keys)
+    streams = None if first else [native.MeshStream(ws, k, v, m12, 0.5, False, zoff=i0) for k, v in zip(keys, vols)]
+    # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
+    import os
+    planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
+    sweep = torch.cuda.current_stream(dev)
+    done, ex = [], None
+    for a in range(0, nloc, planes):
+        b = min(nloc, a + planes)
+        try:
+            native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b])
+        except native._lib.SursError as e:
+            if e.code != -3:
+                raise
+            prec = "fp32"   # general calibration / grid transform: the column kernel does not apply
+            native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b])
+        ev = torch.cuda.Event()
+        ev.record(sweep)
+        done.append((b, ev))
+        if ex is None:
+            ex = Exchange(group)
+            for v in vols:
+                if rank > 0:
+                    ex.send(v[0], rank - 1)
+                if halo:
+                    ex.recv(v[nloc], rank + 1)
+            ex.start()
+    ex.wait()                      # the sweep's stream (RCCL) / the host (gloo) has the halo planes from here on
+    halo_ev = torch.cuda.Event()
+    halo_ev.record(sweep)
+    if timing is not None:
+        timing.record()
+    # ---- extraction: layer by layer behind the sweep's launches (from the second reconstruction on), or in one piece
+    res = None
+    if streams is not None:
+        for b, ev in done[:-1]:
+            for s in streams:
+                s.advance(b - 1, after=ev)
+        res = [s.finish(after=halo_ev) for s in streams]
+        if any(r is None for r in res):
+            res = None
+        else:
+            runs = [s.run for s in streams]
+            tables = [s.w for s in streams]
+    if res is None:
+        torch.cuda.current_stream(dev).synchronize()
+        res, runs, tables = [], [], []
+        for k, v in zip(keys, vols):
+            world_v, faces, run, w = native.slab_mesh_one_piece(ws, k, v, m12, 0.5, i0)
+            res.append((world_v, faces))
+            runs.append(run)
+            tables.append(w)
+    n0 = vols[0].shape[0]
+
+    def top_ids(f):
+        top = torch.empty((2, R, R), dtype=torch.int32, device=dev)
+        native.check(native.lib().surs_mc_slab_top_ids(native._ptr(tables[f]), tables[f].numel(), n0, R, R, native._ptr(top),
+                                                       native._stream()))
+        return top
+
+    def fixup(f, faces, own_off, below, below_off):
+        native.check(native.lib().surs_mc_slab_fixup(native._ptr(faces), faces.shape[0], own_off, native._ptr(below), below_off,
+                                                     native._stream()))
+
+    out = assemble_slab_meshes(res, [(r.n_verts, r.n_faces, r.vmin, r.vmax) for r in runs], top_ids, fixup, R, dev, dst, group)
+    if out is None:
+        torch.cuda.current_stream(dev).synchronize()   # the sends have left before the buffers go back to the allocator
         return None
-    if not want_mesh:
-        return full_hr, full_lr, mat
-    return mesh_util.meshes_from_volumes(net, [full_hr, full_lr], mat)
+    host = ws.to_host([out[0][0], out[0][1], out[1][0], out[1][1]])
+    return host[0], host[1], None, None, host[2], host[3], None, None
+
+
+def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None, level=0.5):
+    """Steps 2-4 of the module docstring.  res[f] = (verts [V,3], faces int32 [F,3]) of this rank's slab of field f in local
+    numbering (references to the slab below as -(2 + slot)); counts[f] = (n_verts, n_faces, vmin, vmax); top_ids(f) -> int32
+    [2,R,R] ids of the x- / y-edge vertices in the slab's top plane; fixup(f, faces, own_offset, below_ids, below_offset)
+    renumbers `faces` in place.  Returns [(verts, faces)] per field of the whole mesh on `dst`, None on the other ranks.
+    (The kernels behind top_ids / fixup are the product's on the GPU; the gloo test passes numpy stand-ins.)"""
+    world, rank = _world(group)
+    nfields = len(res)
+    row = []
+    for c in counts:
+        row += list(c)
+    allc = all_gather_rows(row, dev, group)          # [world, 4 * nfields]
+    for f in range(nfields):
+        lo, hi = allc[:, 4 * f + 2].min(), allc[:, 4 * f + 3].max()
+        if level < lo or level > hi:
+            raise ValueError("Surface level must be within volume data range.")
+        if allc[:, 4 * f].sum() == 0:
+            raise RuntimeError("No surface found at the given iso value.")
+    voff = [offsets_from_counts(allc[:, 4 * f]) for f in range(nfields)]
+    # ---- boundary vertex ids to the slab above, faces to the whole mesh's numbering
+    ex = Exchange(group)
+    below = [torch.empty((2, R, R), dtype=torch.int32, device=dev) if rank > 0 else None for _ in range(nfields)]
+    for f in range(nfields):
+        if rank < world - 1:
+            ex.send(top_ids(f), rank + 1)
+        if rank > 0:
+            ex.recv(below[f], rank - 1)
+    ex.start().wait()
+    for f in range(nfields):
+        fixup(f, res[f][1], int(voff[f][rank]), below[f], int(voff[f][rank - 1]) if rank > 0 else 0)
+    # ---- meshes to dst
+    ex = Exchange(group)
+    out = []
+    for f in range(nfields):
+        nv, nf = allc[:, 4 * f].astype(np.int64), allc[:, 4 * f + 1].astype(np.int64)
+        foff = offsets_from_counts(nf)
+        if rank == dst:
+            V = torch.empty((int(nv.sum()), 3), dtype=res[f][0].dtype, device=dev)
+            F = torch.empty((int(nf.sum()), 3), dtype=torch.int32, device=dev)
+            for r in range(world):
+                va, fa = int(voff[f][r]), int(foff[r])
+                if r == rank:
+                    V[va:va + int(nv[r])].copy_(res[f][0])
+                    F[fa:fa + int(nf[r])].copy_(res[f][1])
+                else:
+                    if nv[r]:
+                        ex.recv(V[va:va + int(nv[r])], r)
+                    if nf[r]:
+                        ex.recv(F[fa:fa + int(nf[r])], r)
+            out.append((V, F))
+        else:
+            if nv[rank]:
+                ex.send(res[f][0], dst)
+            if nf[rank]:
+                ex.send(res[f][1], dst)
+    ex.start().wait()
+    return out if rank == dst else None

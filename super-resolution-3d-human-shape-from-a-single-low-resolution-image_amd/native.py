@@ -403,8 +403,15 @@ class MeshStream:
     field's previous extraction (ws.mc_capacity[key]); `overflow` is set if that turns out too small - the caller then
     extracts the finished volume in one piece."""
 
-    def __init__(self, ws, key, vol, mat, level=0.5, want_normals=True):
+    def __init__(self, ws, key, vol, mat, level=0.5, want_normals=True, zoff=None):
+        """zoff (slab mode, dist.reconstruction_sharded): `vol` is one axis-0 slab of a larger grid whose plane 0 is the grid's
+        plane zoff and whose last plane is the next slab's first (halo); vertices and faces stay on the device, numbered
+        locally, faces of the first cell layer referring to the slab below as surs_mc_lewiner_range_slab describes;
+        finish() then returns device tensors and leaves the level-range / no-surface checks to the caller."""
         self.ws, self.key, self.vol, self.level, self.want = ws, key, vol, float(level), want_normals
+        self.zoff = zoff
+        if zoff is not None and want_normals:
+            raise NotImplementedError("slab mode extracts vertices and faces only (normals accumulate across slabs)")
         self.n0, self.n1, self.n2 = vol.shape
         dev = vol.device
         self.cap_v, self.cap_f = ws.mc_capacity[key]
@@ -418,8 +425,9 @@ class MeshStream:
         self.faces = torch.empty((self.cap_f, 3), dtype=torch.int32, device=dev)
         self.normals = torch.empty((self.cap_v, 3), dtype=torch.float32, device=dev) if want_normals else None
         self.values = torch.empty((self.cap_v,), dtype=torch.float32, device=dev) if want_normals else None
-        self.h_world = torch.empty((self.cap_v, 3), dtype=torch.float64, pin_memory=True)
-        self.h_faces = torch.empty((self.cap_f, 3), dtype=torch.int32, pin_memory=True)
+        if zoff is None:
+            self.h_world = torch.empty((self.cap_v, 3), dtype=torch.float64, pin_memory=True)
+            self.h_faces = torch.empty((self.cap_f, 3), dtype=torch.int32, pin_memory=True)
         self.mat = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
         self.run = _lib.McCounts(0, 0, 3.4028234663852886e38, -3.4028234663852886e38)
         self.layers = 0          # cell layers (axis 0) extracted so far
@@ -455,9 +463,14 @@ class MeshStream:
         layer_end = min(int(layer_end), self.n0 - 1)
         if self.overflow or layer_end <= self.layers:
             return
-        rc = lib().surs_mc_lewiner_range(_ptr(self.vol), self.n0, self.n1, self.n2, self.layers, layer_end, self.level,
-                                         _ptr(self.w), self.w.numel(), _ptr(self.verts), _ptr(self.normals), _ptr(self.values),
-                                         self.cap_v, _ptr(self.faces), self.cap_f, C.byref(self.run), _stream())
+        if self.zoff is not None:
+            rc = lib().surs_mc_lewiner_range_slab(_ptr(self.vol), self.n0, self.n1, self.n2, self.layers, layer_end, self.level,
+                                                  _ptr(self.w), self.w.numel(), _ptr(self.verts), self.cap_v, _ptr(self.faces),
+                                                  self.cap_f, C.byref(self.run), int(self.zoff), _stream())
+        else:
+            rc = lib().surs_mc_lewiner_range(_ptr(self.vol), self.n0, self.n1, self.n2, self.layers, layer_end, self.level,
+                                             _ptr(self.w), self.w.numel(), _ptr(self.verts), _ptr(self.normals), _ptr(self.values),
+                                             self.cap_v, _ptr(self.faces), self.cap_f, C.byref(self.run), _stream())
         if rc == -6:
             self.overflow = True
             return
@@ -467,7 +480,7 @@ class MeshStream:
         if nv > self.sent_v:
             check(lib().surs_transform_points(self.verts[self.sent_v:].data_ptr(), nv - self.sent_v, self.mat,
                                               self.world[self.sent_v:].data_ptr(), _stream()))
-        if nv > self.sent_v or nf > self.sent_f:
+        if self.zoff is None and (nv > self.sent_v or nf > self.sent_f):
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             self.side.wait_event(ready)
@@ -476,7 +489,7 @@ class MeshStream:
                     self.h_world[self.sent_v:nv].copy_(self.world[self.sent_v:nv], non_blocking=True)
                 if nf > self.sent_f:
                     self.h_faces[self.sent_f:nf].copy_(self.faces[self.sent_f:nf], non_blocking=True)
-            self.sent_v, self.sent_f = nv, nf
+        self.sent_v, self.sent_f = nv, nf
 
     def finish(self, after=None):
         """Last layers, the checks of marching_cubes_lewiner, normals; -> (verts_world, faces, normals, values) numpy."""
@@ -489,6 +502,11 @@ class MeshStream:
         self._advance(self.n0 - 1)
         if self.overflow:
             return None
+        if self.zoff is not None:   # slab mode: device results, local numbering; the caller checks the whole grid's range
+            nv, nf = self.run.n_verts, self.run.n_faces
+            self.ws.mc_capacity[self.key] = mesh_capacity(nv, nf)
+            torch.cuda.current_stream().synchronize()
+            return self.world[:nv], self.faces[:nf]
         if self.level < self.run.vmin or self.level > self.run.vmax:
             raise ValueError("Surface level must be within volume data range.")
         nv, nf = self.run.n_verts, self.run.n_faces
@@ -501,6 +519,39 @@ class MeshStream:
             extra = self.ws.to_host([self.normals[:nv], self.values[:nv]])
         self.side.synchronize()
         return self.h_world[:nv].numpy(), self.h_faces[:nf].numpy(), extra[0], extra[1]
+
+
+def slab_mesh_one_piece(ws, key, vol, mat, level, zoff):
+    """Slab-mode extraction of a finished slab in one piece (the first reconstruction of a workspace, or after a streamed
+    extraction ran out of buffer): a counting call sizes the buffers.  Returns device tensors (verts_world float64 [V,3],
+    faces int32 [F,3] in the slab's local numbering), the counts and the workspace that holds the edge tables."""
+    n0, n1, n2 = vol.shape
+    dev = vol.device
+    need = lib().surs_mc_workspace_bytes(n0, n1, n2)
+    w = ws.mesh_ws.get(key)
+    if w is None or w.numel() < need:
+        w = ws.mesh_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+
+    def run(cap_v, cap_f):
+        verts = torch.empty((max(cap_v, 1), 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((max(cap_f, 1), 3), dtype=torch.int32, device=dev)
+        counts = _lib.McCounts(0, 0, 3.4028234663852886e38, -3.4028234663852886e38)
+        rc = lib().surs_mc_lewiner_range_slab(_ptr(vol), n0, n1, n2, 0, n0 - 1, float(level), _ptr(w), w.numel(), _ptr(verts), cap_v,
+                                              _ptr(faces), cap_f, C.byref(counts), int(zoff), _stream())
+        return rc, verts, faces, counts
+
+    cap = ws.mc_capacity.get(key) or (0, 0)
+    rc, verts, faces, counts = run(*cap)
+    if rc == -6:
+        rc, verts, faces, counts = run(counts.n_verts, counts.n_faces)
+    check(rc)
+    nv, nf = counts.n_verts, counts.n_faces
+    ws.mc_capacity[key] = mesh_capacity(nv, nf)
+    world = torch.empty((nv, 3), dtype=torch.float64, device=dev)
+    if nv:
+        check(lib().surs_transform_points(_ptr(verts), nv, m, _ptr(world), _stream()))
+    return world, faces[:nf], counts, w
 
 
 def transform_points(verts, mat):

@@ -211,3 +211,58 @@ def smooth_image(h, w=None, seed=1, waves=6):
 def synthetic_points(n, seed=2, lo=-0.55, hi=0.55):
     """[3,N] float32 points; about 17 % fall outside the image for +-0.55."""
     return prng.uniform("synthetic_points", seed, (3, n), lo, hi)
+
+
+# ------------------------------------------------------------------ a smooth, closed, body-sized occupancy field
+# The seeded random weights above give a noise-like field (a level crossing in nearly every voxel column: ~100x the
+# surface of a body).  Acceptance tests of the reduced-precision sweeps need the other regime too: a smooth field whose
+# 0.5 level set is ONE closed blob of body-like extent, so that a shift of the level set shows up as a mesh distance.
+# Both MLPs keep seeded random weights (at a reduced gain: a smooth perturbation of about +-1 in the logit) and get a
+# hand-routed path on top:
+#     logit = A * G(x, y)  -  B * |z_feat|  +  (random network)
+# G = 1 - (x/ax)^2 - (y/ay)^2 is channel 0 of the low-resolution feature map and enters through the last layer's skip
+# connection; |z_feat| is built by two layer-0 units, lrelu(z_feat) and lrelu(-z_feat), and carried to the last layer by
+# one unit in each of layers 1-3.  The level set is a closed double cone over an ellipse, wrinkled by the random part.
+
+BODY_AX, BODY_AY, BODY_Z = 0.30, 0.42, 0.20     # half extents (world units; the grid is [-0.5, 0.5]^3)
+
+
+def body_state_dict(opt, seed=0, gain=0.35, A=8.0):
+    sd = synthetic_state_dict(opt, seed=seed, mlp_gain=gain)
+    zscale = float(opt.loadSize // 2) / float(opt.z_size)       # z_feat = 2 z * zscale
+    B = A / (0.99 * 2.0 * BODY_Z * zscale)                       # logit(0, 0, +-BODY_Z) = 0 without the random part
+    for m, c0 in (("mlp_lr.", 321), ("mlp_hr.", 322)):
+        w = [sd[m + "conv%d.weight" % l] for l in range(5)]
+        b = [sd[m + "conv%d.bias" % l] for l in range(5)]
+        w[0][0:2] = 0.0
+        w[0][0, 320, 0], w[0][1, 320, 0] = 1.0, -1.0             # y0[0] = lrelu(z_feat), y0[1] = lrelu(-z_feat)
+        b[0][0:2] = 0.0
+        for l in (1, 2, 3):                                       # unit 0 of layers 1-3 carries 0.99 |z_feat|
+            w[l][0] = 0.0
+            b[l][0] = 0.0
+        w[1][0, 0, 0] = w[1][0, 1, 0] = 1.0
+        w[2][0, 0, 0] = 1.0
+        w[3][0, 0, 0] = 1.0
+        w[4][0, 0, 0] = -B                                        # ... and enters the logit
+        w[4][0, 128 + 0, 0] = A                                   # skip connection: feature channel 0 = G(x, y)
+        b[4][0] = 0.0
+    return sd
+
+
+def body_features(hl, hh, seed=4, waves=5):
+    """Feature maps for body_state_dict: ([256,hl,hl], [64,hh,hh]) float32, channel 0 of the first = G(x, y), every other
+    channel a band-limited field (a few low-frequency cosines with seeded phases) of amplitude about 1."""
+    def maps(name, c, h):
+        p = prng.uniform(name, seed, (c, waves, 4), 0.0, 1.0).astype(np.float64)
+        v, u = np.mgrid[:h, :h].astype(np.float64) / max(h - 1, 1)       # rows <-> image Y, columns <-> image X, in [0, 1]
+        out = np.zeros((c, h, h))
+        for k in range(waves):
+            fx, fy = (0.5 + 3.5 * p[:, k, 0])[:, None, None], (0.5 + 3.5 * p[:, k, 1])[:, None, None]
+            out += np.cos(2 * np.pi * (fx * u[None] + fy * v[None] + p[:, k, 2][:, None, None])) * (0.3 + 0.4 * p[:, k, 3])[:, None, None]
+        return out
+    fl = maps("body_feat_lr", 256, hl)
+    fh = maps("body_feat_hr", 64, hh)
+    v, u = np.mgrid[:hl, :hl].astype(np.float64) / max(hl - 1, 1)
+    X, Y = 2.0 * u - 1.0, 2.0 * v - 1.0                                   # image coordinates; world x = X/2, y = -Y/2
+    fl[0] = 1.0 - (X / (2.0 * BODY_AX)) ** 2 - (Y / (2.0 * BODY_AY)) ** 2
+    return fl.astype(np.float32), fh.astype(np.float32)

@@ -61,3 +61,101 @@ def test_gather_slabs_world2_even():
 
 def test_gather_slabs_world3_ragged():
     _run(3, 7)
+
+
+# ------------------------------------------------------------------ slab-mode mesh assembly (dist.assemble_slab_meshes)
+# The per-slab extraction is a GPU kernel; here every rank's slab result is DERIVED from the oracle's mesh of the whole
+# volume exactly as surs_mc_lewiner_range_slab defines it (a slab owns the vertices / faces its cell layers create, numbers
+# them from 0 and refers to the slab below as -(2 + slot)), and the protocol - counts all_gather, boundary-id exchange,
+# renumbering, mesh gather - must give the whole mesh back.  tests/test_gpu_dist.py runs the real kernels.
+
+def _slab_fixture(R=20, world=3):
+    import mc_volumes
+    import oracle
+    # a smooth blob that reaches into every slab, plus a little seeded noise (centre vertices, ambiguous cells)
+    z, y, x = np.mgrid[:R, :R, :R].astype(np.float64)
+    c = (R - 1) / 2.0
+    vol = 1.0 / (1.0 + np.exp(((x - c) ** 2 / 30.0 + (y - c - 0.7) ** 2 / 50.0 + (z - c + 0.3) ** 2 / 70.0) - 1.0))
+    vol = (vol + 0.08 * (mc_volumes.noise((R, R, R), 5) - 0.5)).astype(np.float32)
+    V, F, _, _ = oracle.marching_cubes_lewiner(vol.astype(np.float64), 0.5)
+
+    def prefix(i1):   # (vertices, faces) created by the cell layers [0, i1)
+        if i1 < 1:
+            return 0, 0
+        try:
+            v, f, _, _ = oracle.marching_cubes_lewiner(vol[:i1 + 1].astype(np.float64), 0.5)
+        except (ValueError, RuntimeError):
+            return 0, 0
+        assert np.array_equal(v, V[:len(v)]) and np.array_equal(f, F[:len(f)])   # a prefix of the whole mesh
+        return len(v), len(f)
+
+    slabs = []
+    for r in range(world):
+        i0, i1 = sdist.slab_range(R, r, world)
+        top = i1 if r < world - 1 else R - 1
+        (v0, f0), (v1, f1) = prefix(i0), prefix(top)
+        faces = F[f0:f1].astype(np.int64).copy()
+        ref = faces < v0
+        pos = V[faces[ref]]                       # vertices of the slab below: on plane i0, on an x- or a y-edge
+        assert np.all(pos[:, 0] == i0)
+        on_x = pos[:, 2] != np.floor(pos[:, 2])
+        slot = np.where(on_x, np.floor(pos[:, 1]) * R + np.floor(pos[:, 2]), R * R + np.floor(pos[:, 1]) * R + np.floor(pos[:, 2]))
+        assert np.all(on_x ^ (pos[:, 1] != np.floor(pos[:, 1])))
+        faces[ref] = -(2 + slot.astype(np.int64))
+        faces[~ref] -= v0
+        ids = np.full((2, R, R), -7, np.int32)    # entries of edges the surface does not cross are undefined
+        own = V[v0:v1]
+        for k in np.nonzero(own[:, 0] == i1)[0]:
+            p = own[k]
+            if p[2] != np.floor(p[2]):
+                ids[0, int(p[1]), int(np.floor(p[2]))] = k
+            elif p[1] != np.floor(p[1]):
+                ids[1, int(np.floor(p[1])), int(p[2])] = k
+        mm = vol[i0:top + 1]
+        slabs.append(dict(verts=own.astype(np.float64), faces=faces.astype(np.int32), ids=ids,
+                          counts=(v1 - v0, f1 - f0, float(mm.min()), float(mm.max()))))
+    return V, F, slabs
+
+
+def _assemble_worker(rank, world, port, R, slabs, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = slabs[rank]
+    res = [(torch.from_numpy(s["verts"].copy()), torch.from_numpy(s["faces"].copy())) for _ in range(2)]   # two fields, same data
+
+    def fixup(f, faces, own_off, below, below_off):
+        a = faces.numpy().reshape(-1)
+        neg = a < 0
+        if neg.any():
+            a[neg] = below.numpy().reshape(-1)[-a[neg] - 2] + below_off
+        a[~neg] += own_off
+
+    got = sdist.assemble_slab_meshes(res, [s["counts"], s["counts"]], lambda f: torch.from_numpy(s["ids"].copy()), fixup, R,
+                                     torch.device("cpu"), dst=0)
+    out[rank] = None if got is None else [(v.numpy(), f.numpy()) for v, f in got]
+    dist.destroy_process_group()
+
+
+def _run_assemble(world, R=20):
+    V, F, slabs = _slab_fixture(R, world)
+    assert len(V) > 100 and sum(s["counts"][0] for s in slabs) == len(V)
+    assert all((s["faces"] < 0).any() for s in slabs[1:])       # every upper slab refers to the slab below
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_assemble_worker, args=(world, _free_port(), R, slabs, out), nprocs=world, join=True)
+    assert all(out[r] is None for r in range(1, world))
+    for v, f in out[0]:
+        assert np.array_equal(v, V.astype(np.float64)) and np.array_equal(f, F)
+
+
+def test_slab_mesh_assembly_world2():
+    _run_assemble(2)
+
+
+def test_slab_mesh_assembly_world3_ragged():
+    _run_assemble(3)
+
+
+def test_offsets_and_small_grids():
+    assert list(sdist.offsets_from_counts([3, 0, 5])) == [0, 3, 3]

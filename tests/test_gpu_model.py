@@ -236,10 +236,13 @@ def test_bench_contract_small():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "queries/s" and d["dtype"] == "bf16"
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert abs(d["value"] - 64 ** 3 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "mfma"
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "achieved_executed", "frac_executed"}
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["frac_executed"] < d["roofline"]["frac"]
+    f32 = d["config"]["fp32_mode"]
+    assert f32["dtype"] == "fp32" and f32["roofline"]["mfma_products_per_mac"] == 3 and f32["ms_per_step"] > 0
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     # (no ordering between the stage times here: at this size the mesh tail and the sweep are both ~1-3 ms)
-    assert "workload" in d["config"] and set(d["config"]["stage_ms_rank0"]) == {"encoder", "query", "gather", "mesh"}
+    assert "workload" in d["config"] and set(d["config"]["stage_ms_rank0"]) == {"encoder", "query", "exchange", "mesh"}
 
 
 def test_streamed_reconstruction_full_size():

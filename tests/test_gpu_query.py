@@ -92,36 +92,80 @@ def test_grid_column_kernel_vs_fp32(setup, dtype, tol):
     assert np.array_equal(a, vh[8:24])
 
 
-def test_full_size_sweep_properties(setup):
-    """BASELINE's full grid (512^3 = 134 217 728 queries, bf16 column kernel) through properties that do not need a CPU pass
-    over the grid: (1) four flat ranges of 65 536 voxels - a plane boundary, a slab boundary of the sweep and two interior
-    ones - against the fp32 point evaluator on the oracle's coordinates for those voxels (the fp32 evaluator is itself
-    held to the reference's goldens at 1e-4); (2) the same bits on a second run; (3) slab consistency: planes [200, 296)
-    evaluated on their own equal those planes of the full sweep."""
+@pytest.fixture(scope="module")
+def setup_full():
+    """BASELINE's feature-map sizes (512 x 512 input): im_feat_lr 256 x 256^2, im_feat_hr 64 x 1024^2, PRNG values."""
+    import gpu_common as g
+    from surs_amd import native
+    fl, fh = common.synth_features(seed=7, hl=256, hh=1024)
+    s = dict(g=g, native=native, Fl=g.upload_nhwc(fl), Fh=g.upload_nhwc(fh), ws=native.Workspace(g.dev()))
+    del fl, fh
+    return s
+
+
+@pytest.mark.parametrize("dtype,tol,tol_logit", [("fp32", 2e-5, 1e-4), ("bf16", 3e-2, None), ("fp16", 4e-3, None)])
+def test_full_size_sweep_properties(setup_full, dtype, tol, tol_logit):
+    """BASELINE's full grid (512^3 = 134 217 728 queries) over full-size feature maps, every precision of the column
+    kernels (fp32 = v5, split-f16 operands), through properties that do not need a CPU pass over the grid: (1) four flat
+    ranges of 65 536 voxels - a plane boundary, a slab boundary of the sweep and two interior ones - against the fp32 point
+    evaluator on the oracle's coordinates for those voxels (the point evaluator is itself held to the reference's goldens
+    at 1e-4); for fp32 also in logit space, at the north star's 1e-4; (2) the same bits on a second run; (3) slab
+    consistency: planes [200, 296) evaluated on their own equal those planes of the full sweep."""
     import oracle
     R = 512
-    s, nat = setup, setup["native"]
+    s, nat = setup_full, setup_full["native"]
     mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
     cal = common.CALIB.reshape(-1)[:12]
     dev = s["g"].dev()
-    blob = s["g"].blob("bf16")
+    blob = s["g"].blob("f16" if dtype == "fp16" else "bf16")
     vh = torch.empty((R, R, R), dtype=torch.float32, device=dev)
     vl = torch.empty_like(vh)
-    nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, "bf16", s["ws"], vh, vl)
+    nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, dtype, s["ws"], vh, vl)
     n = 65536
+    lg = lambda p: torch.log(p.double() / (1.0 - p.double()))
     for start in (0, 31 * R * R + 509 * R - 7, 32 * R * R - n // 2, R ** 3 - n):
         pts = torch.from_numpy(oracle.grid_points(R, [-0.5] * 3, [0.5] * 3, start, start + n)).to(dev)
-        phr, plr = nat.query_points(pts, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, s["ws"])
-        eh = (vh.view(-1)[start:start + n] - phr).abs().max().item()
-        el = (vl.view(-1)[start:start + n] - plr).abs().max().item()
-        assert eh < 3e-2 and el < 3e-2, (start, eh, el)
+        phr, plr, lhr, llr = nat.query_points(pts, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, s["ws"], want_logits=True)
+        a, b = vh.view(-1)[start:start + n], vl.view(-1)[start:start + n]
+        eh, el = (a - phr).abs().max().item(), (b - plr).abs().max().item()
+        assert eh < tol and el < tol, (start, eh, el)
+        if tol_logit is not None:
+            ok = (a > 1e-4) & (a < 1 - 1e-4) & (b > 1e-4) & (b < 1 - 1e-4)
+            dh, dl = (lg(a) - lhr.double()).abs()[ok].max().item(), (lg(b) - llr.double()).abs()[ok].max().item()
+            assert dh < tol_logit and dl < tol_logit, (start, dh, dl)
     vh2 = torch.empty_like(vh)
     vl2 = torch.empty_like(vl)
-    nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, "bf16", s["ws"], vh2, vl2)
+    nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, dtype, s["ws"], vh2, vl2)
     assert torch.equal(vh, vh2) and torch.equal(vl, vl2)
-    nat.query_grid(200, 296, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, "bf16", s["ws"], vh2[200:296].zero_(), vl2[200:296].zero_())
+    nat.query_grid(200, 296, R, R, mat, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], blob, dtype, s["ws"], vh2[200:296].zero_(), vl2[200:296].zero_())
     assert torch.equal(vh[200:296], vh2[200:296]) and torch.equal(vl[200:296], vl2[200:296])
     assert float(vh.min()) >= 0.0 and float(vh.max()) <= 1.0 and bool(torch.isfinite(vh).all())
+
+
+def test_grid_fp32_column_kernel_vs_layer_kernels(setup):
+    """surs_query_grid(SURS_F32) on an axis-aligned sweep runs the fp32-grade column kernel (v5: split-f16 operands, three
+    MFMA products per MAC); on a general calibration it runs the per-point layer kernels (split-bf16, six products).  Both
+    are fp32-grade: the same grid through both, occupancies within 2e-6 and logits within 2e-5 of each other (ragged R)."""
+    import oracle
+    nat = setup["native"]
+    R = 40
+    vh, vl = _grid(setup, R, "fp32")
+    pts = torch.from_numpy(oracle.grid_points(R, [-0.5] * 3, [0.5] * 3)).to(setup["g"].dev())
+    phr, plr, lhr, llr = nat.query_points(pts, common.CALIB.reshape(-1)[:12], ZMUL, ZDIV, setup["Fl"], setup["Fh"],
+                                          setup["g"].blob("bf16"), setup["ws"], want_logits=True)
+    a, b = torch.from_numpy(vh.reshape(-1)).to(pts.device), torch.from_numpy(vl.reshape(-1)).to(pts.device)
+    lg = lambda p: torch.log(p.double() / (1.0 - p.double()))
+    assert (a - phr).abs().max().item() < 2e-6 and (b - plr).abs().max().item() < 2e-6
+    assert (lg(a) - lhr.double()).abs().max().item() < 2e-5 and (lg(b) - llr.double()).abs().max().item() < 2e-5
+    # a general calibration (rotated about x: the projected Y depends on k) takes the layer kernels and agrees with the
+    # point path bit for bit (same kernels, same batches of 65 536)
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    calib = (np.array([[1, 0, 0, 0], [0, c, -s_, 0], [0, s_, c, 0], [0, 0, 0, 1]], np.float32) @ common.CALIB).astype(np.float32)
+    mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)
+    gh, gl = nat.query_grid(0, R, R, R, mat[:3].reshape(-1), calib.reshape(-1)[:12], ZMUL, ZDIV, setup["Fl"], setup["Fh"],
+                            setup["g"].blob("bf16"), "fp32", setup["ws"])
+    phr, plr = nat.query_points(pts, calib.reshape(-1)[:12], ZMUL, ZDIV, setup["Fl"], setup["Fh"], setup["g"].blob("bf16"), setup["ws"])
+    assert torch.equal(gh.view(-1)[:65536], phr[:65536]) and torch.equal(gl.view(-1)[:65536], plr[:65536])
 
 
 def test_pipelined_kernel_bitwise_equals_simple_kernel():
