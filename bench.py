@@ -191,6 +191,48 @@ def main():
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
                                "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
+    if world == 1 and not args.no_extras:
+        # a run of subjects (apps/eval_SuRS.py:74-80) - per subject: decoded 8-bit pixels -> img_LR -> encoder ->
+        # reconstruction (no OBJ files).  sequential = host normalise + upload + gen_mesh's order; pipelined = device input stage,
+        # next subject's decode / upload / encoder under the current sweep (train_util.gen_mesh_pipelined)
+        try:
+            from surs_amd import data
+            K = 4
+            ds = data.SyntheticDataset(opt, n=K, size=IMG)
+            raws = [ds.get_raw_item(i) for i in range(K)]
+
+            def sequential():
+                for raw in raws:
+                    m = raw["mask"].astype(np.float32) / np.float32(255.0)
+                    x = (raw["rgb"].astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)
+                    img = torch.from_numpy(np.ascontiguousarray((m[None] * x.transpose(2, 0, 1))[None])).to(dev)
+                    _, f_lr, f_hr = net.super_res(img)
+                    net.filter_hr(f_hr)
+                    net.filter_lr(f_lr)
+                    mesh_util.reconstruction(opt, net, dev, calib, R, b_min, b_max, use_octree=False, want_normals=False)
+
+            class Raws:
+                def get_raw_item(self, i):
+                    return ds.get_raw_item(i)     # decoded again per subject, like reading the files
+
+            def pipelined():
+                train_util.gen_mesh_pipelined(opt, net, dev, Raws(), range(K), None, use_octree=False, write=False)
+
+            times = {}
+            for name, fn in (("sequential", sequential), ("pipelined", pipelined)):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                times[name] = time.perf_counter() - t0
+            extras["subject_pipeline"] = {"subjects": K, "resolution": R, "precision": args.precision,
+                                          "sequential_subjects_per_s": K / times["sequential"],
+                                          "pipelined_subjects_per_s": K / times["pipelined"],
+                                          "note": "8-bit pixels in host memory -> meshes in host memory; sequential decodes nothing "
+                                                  "(pixels held in memory), pipelined regenerates them per subject on a host thread"}
+        except Exception as e:
+            extras["subject_pipeline"] = {"error": repr(e)}
     if world == 1 and not args.no_extras and R == RES:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -98,6 +98,10 @@ int surs_pixel_shuffle2(const float *x, int h, int w, int c4, int x_ld, float sl
 /* y = a + b (+ c, nullable) */
 int surs_add3(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch, float *y,
               int y_ld, void *stream);
+/* Input stage of the test path (lib/data/EvalDataset_LR_v2.py:227-243): rgb uint8 [h][w][3], mask uint8 [h][w] (device) ->
+ * y[h][w][0:3] (pitch y_ld) = (mask / 255) * ((rgb / 255 - 0.5) / 0.5), float32, the reference's operations in its order
+ * (ToTensor, Normalize(0.5, 0.5), mask multiply): bit-identical to its img_LR, already in the encoder's NHWC layout. */
+int surs_image_prepare(const unsigned char *rgb, const unsigned char *mask, int h, int w, float *y, int y_ld, void *stream);
 /* NCHW <-> NHWC(pitch ld) copies for the boundary tensors */
 int surs_nchw_to_nhwc(const float *x, int c, int h, int w, float *y, int y_ld, void *stream);
 int surs_nhwc_to_nchw(const float *x, int c, int h, int w, int x_ld, float *y, void *stream);

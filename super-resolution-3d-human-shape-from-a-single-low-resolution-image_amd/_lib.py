@@ -45,6 +45,7 @@ _SIGS = {
     "surs_bicubic_up2": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "surs_pixel_shuffle2": (C.c_int, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
     "surs_add3": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "surs_image_prepare": (C.c_int, [_vp, _vp, _i, _i, _vp, _i, _vp]),
     "surs_nchw_to_nhwc": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "surs_nhwc_to_nchw": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "surs_conv2d_nhwc_x3": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),

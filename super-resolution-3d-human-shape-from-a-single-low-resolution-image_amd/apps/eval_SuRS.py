@@ -5,7 +5,8 @@
         --load_netG_checkpoint_path W/netG_epoch_12 --b_min -0.5 -0.5 -0.5 --b_max 0.5 0.5 0.5 [--precision bf16] [--no_octree]
 
 Extensions: --precision {fp32,bf16,fp16}; --no_octree (dense sweep instead of the reference's default octree);
---synthetic (seeded image + weights when no dataset / checkpoint is at hand).
+--synthetic (seeded image + weights when no dataset / checkpoint is at hand); --pipeline (the subjects as a pipeline:
+next subject's decode, upload and encoder under the current sweep, OBJ files written in the background - same files).
 """
 import os
 import sys
@@ -16,7 +17,7 @@ import torch
 from ..data import EvalDataset, SyntheticDataset
 from ..model import SuRSNet
 from ..options import BaseOptions
-from ..train_util import gen_mesh
+from ..train_util import gen_mesh, gen_mesh_pipelined
 
 
 def eval(opt):
@@ -35,6 +36,13 @@ def eval(opt):
     netG.eval()
     if not opt.no_gen_mesh:
         print("generate mesh (test) ...")
+        if opt.pipeline and opt.num_views == 1:
+            # same files; decode / upload / encoder of the next subject and the OBJ writing of the previous one overlap the sweep
+            t = time.time()
+            gen_mesh_pipelined(opt, netG, cuda, test_dataset, range(len(test_dataset)),
+                               lambda raw: "%s/%s/%s.obj" % (opt.results_path, opt.name, raw["name"][0]), use_octree=not opt.no_octree)
+            print("%d subjects: %.3f s" % (len(test_dataset), time.time() - t))
+            return
         for gen_idx in range(len(test_dataset)):
             t = time.time()
             test_data = test_dataset[gen_idx]

@@ -40,6 +40,20 @@ inline int fail(int code, const char *fmt, ...) {
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// "has this kernel's attribute been set on the current device?" - hipFuncSetAttribute belongs to the (function, device)
+// pair, so a process-wide flag would leave a second device without its > 64 KB dynamic-LDS limit.  One DeviceOnce per
+// kernel instantiation (a function-local static); first() is true exactly once per device.
+struct DeviceOnce {
+    unsigned long long mask = 0;   // bit d: done on device d (d < 64)
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;   // set it again: cheap and harmless
+        const unsigned long long bit = 1ull << dev;
+        const unsigned long long old = __atomic_fetch_or(&mask, bit, __ATOMIC_ACQ_REL);
+        return !(old & bit);
+    }
+};
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace surs

@@ -17,6 +17,9 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "surs_common.h"
 
@@ -154,11 +157,9 @@ template <int KS, int STRIDE, int TR, int NT>
 static int launch_conv_cfg(const ConvArgs &a, hipStream_t st) {
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
     const size_t lds = (size_t)(PR * PC * PS + KS * KS * CK * NT) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.first())
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_kernel<KS, STRIDE, TR, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
     dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), ceil_div(a.cout_pad, NT));
     hipLaunchKernelGGL((conv_kernel<KS, STRIDE, TR, NT>), grid, dim3(256), lds, st, a);
     SURS_LAUNCH_CHECK();
@@ -423,11 +424,9 @@ static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, h
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
     SURS_REQUIRE(a.cin_pad <= 1024, "split-bf16 convolution: at most 1024 input channels");
     const size_t lds = (size_t)(3 * PR * PC * XS + 3 * KS * KS * NT3 * XS) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce attr;
+    if (attr.first())
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
     dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), ceil_div(a.cout_pad, NT3));
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3>), grid, dim3(256), lds, st, a, wsplit);
     SURS_LAUNCH_CHECK();
@@ -675,18 +674,49 @@ extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, in
                                      const float *beta, float *scale, float *shift, void *stream) {
     SURS_REQUIRE(x && gamma && beta && scale && shift, "null argument");
     SURS_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0 && hw > 0, "bad GroupNorm shape");
-    // partial sums live in a small per-device scratch buffer owned by the library (calls on one stream are ordered;
-    // concurrent calls from several streams would race on it)
-    static double *scratch[16] = {nullptr};
+    // the partial sums live in a small scratch buffer owned by the library, one per (device, stream): calls on one stream
+    // are ordered, calls on different streams (two subjects' encoders side by side) get different buffers.  A few KB each,
+    // kept for the life of the process.
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, double *> scratch;
     int dev = 0;
     SURS_HIP_CHECK(hipGetDevice(&dev));
-    SURS_REQUIRE(dev >= 0 && dev < 16, "device index out of range");
-    if (!scratch[dev]) SURS_HIP_CHECK(hipMalloc((void **)&scratch[dev], sizeof(double) * 64 * GN_SPLIT * 2));
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(groups, GN_SPLIT), dim3(256), 0, st, x, hw, c, x_ld, groups, scratch[dev]);
+    double *buf = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        double *&slot = scratch[std::make_pair(dev, st)];
+        if (!slot) SURS_HIP_CHECK(hipMalloc((void **)&slot, sizeof(double) * 64 * GN_SPLIT * 2));
+        buf = slot;
+    }
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(groups, GN_SPLIT), dim3(256), 0, st, x, hw, c, x_ld, groups, buf);
     SURS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, scratch[dev], hw, c, groups, eps, gamma, beta,
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, buf, hw, c, groups, eps, gamma, beta,
                        scale, shift);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+// Input stage (lib/data/EvalDataset_LR_v2.py:227-243): ToTensor (uint8 / 255), Normalize(0.5, 0.5), mask multiply - the same
+// three float32 operations in the same order, so the bytes equal the reference's tensor; output NHWC for the encoder.
+namespace surs {
+__global__ void image_prepare_kernel(const unsigned char *__restrict__ rgb, const unsigned char *__restrict__ mask, int npix,
+                                     float *__restrict__ y, int y_ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float m = (float)mask[i] / 255.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = (float)rgb[3 * (size_t)i + c] / 255.0f;
+        v = (v - 0.5f) / 0.5f;
+        y[(size_t)i * y_ld + c] = m * v;
+    }
+}
+}  // namespace surs
+
+extern "C" int surs_image_prepare(const unsigned char *rgb, const unsigned char *mask, int h, int w, float *y, int y_ld, void *stream) {
+    SURS_REQUIRE(rgb && mask && y && h > 0 && w > 0 && y_ld >= 3, "bad argument");
+    hipLaunchKernelGGL(surs::image_prepare_kernel, dim3(blocks_for((size_t)h * w)), dim3(256), 0, as_stream(stream), rgb, mask, h * w, y, y_ld);
     SURS_LAUNCH_CHECK();
     return 0;
 }

@@ -384,23 +384,10 @@ static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const v
     return 0;
 }
 
-// kernels that need more than 64 KB of dynamic LDS: the attribute belongs to the (function, device) pair, so the
-// "already set" flags are per device (a second device in the same process gets its own calls)
-static bool attrs_done(int which) {
-    static std::mutex mu;
-    static bool done[2][64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    std::lock_guard<std::mutex> lock(mu);
-    const bool was = done[which][dev];
-    done[which][dev] = true;
-    return was;
-}
-
 // the 256-point layer kernels need more than 64 KB of dynamic LDS
 static int g3_set_attributes() {
-    const bool once = attrs_done(0);
-    if (!once) {
+    static DeviceOnce attr;
+    if (attr.first()) {
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
@@ -1000,7 +987,8 @@ static bool grid_f32_use_columns() {
 }
 
 static int grid_set_attributes() {
-    if (attrs_done(1)) return 0;
+    static DeviceOnce attr;
+    if (!attr.first()) return 0;
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));

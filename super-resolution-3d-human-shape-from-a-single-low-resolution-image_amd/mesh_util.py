@@ -18,12 +18,12 @@ from . import native
 from .sdf import create_grid
 
 
-def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, i0=0, i1=None, precision=None):
+def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, i0=0, i1=None, precision=None, features=None):
     """Dense occupancy volumes of grid slab [i0, i1) as float32 device tensors (vol_hr, vol_lr), and the grid matrix."""
     _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
     i1 = resolution if i1 is None else i1
     calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
-    fl, fh = net.features()
+    fl, fh = features if features is not None else net.features()
     zmul, zdiv = net._zscale()
     prec = precision or getattr(opt, "precision", "fp32")
     blob = net._mlp_blob()
@@ -67,11 +67,11 @@ def eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transfo
     return vh.view(R, R, R), vl.view(R, R, R), mat
 
 
-def eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, init_resolution=64):
+def eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, init_resolution=64, features=None):
     """eval_grid_octree: float64 device volumes (sdf_hr, sdf_lr) and the grid matrix."""
     _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
     calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
-    fl, fh = net.features()
+    fl, fh = features if features is not None else net.features()
     zmul, zdiv = net._zscale()
     vh, vl = native.octree_volumes(resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, net._mlp_blob(), net._workspace(),
                                    opt.threshold, init_resolution)
@@ -107,19 +107,21 @@ def meshes_from_volumes(net, vols, mat, level=0.5, want_normals=True):
 
 
 def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, want_normals=True, timing=None,
-                            planes=None):
+                            planes=None, features=None, after_enqueue=None):
     """Dense reconstruction with the mesh extraction pipelined into the sweep: the sweep writes the volumes 16 384 columns
     (whole axis-0 planes) per launch; after every launch the cell layers that have become final are extracted
     (surs_mc_lewiner_range: Lewiner's sweep has axis 0 outermost, so their vertex / face numbers are final too) and their
     vertices and faces travel to the host under the next launches.  Same outputs as eval_volumes + meshes_from_volumes.
-    Returns None if it cannot run (first extraction of this workspace: no buffer sizes yet; multi-view; octree)."""
+    Returns None if it cannot run (first extraction of this workspace: no buffer sizes yet; multi-view; octree).
+    features: (Img feat_lr, Img feat_hr) instead of the model's current ones; after_enqueue: called once the whole sweep is
+    enqueued and before the host starts driving the extraction (gen_mesh_pipelined enqueues the next subject's encoder there)."""
     ws = net._workspace()
     if ws.mc_capacity.get(0) is None or ws.mc_capacity.get(1) is None or net.num_views != 1:
         return None
     R = int(resolution)
     _, mat = create_grid(R, R, R, b_min, b_max, transform=transform)
     calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
-    fl, fh = net.features()
+    fl, fh = features if features is not None else net.features()
     zmul, zdiv = net._zscale()
     prec = getattr(opt, "precision", "fp32")
     blob = net._mlp_blob()
@@ -149,6 +151,8 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
         done.append((i1, ev))
     if timing is not None:
         timing.record()
+    if after_enqueue is not None:
+        after_enqueue()
     # ... then the extraction follows it slab by slab on the fields' own streams: once planes < i1 are final the cell
     # layers below i1 - 1 are (a cell layer needs the plane above it); the count read-backs of the extraction wait on
     # those streams only, and its kernels run in the gaps and tails of the sweep's launches
@@ -162,18 +166,31 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
 
 
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
-                   transform=None, want_normals=True):
-    """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy)."""
+                   transform=None, want_normals=True, features=None, after_enqueue=None):
+    """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy).
+    features / after_enqueue: see reconstruction_streamed (single view only)."""
     if net.num_views > 1 or getattr(net, "projection_mode", "orthogonal") != "orthogonal":
         # multi-view / perspective: always the dense sweep (the octree walk is only wired to the single-view kernels)
+        if use_octree:
+            import warnings
+            warnings.warn("reconstruction: use_octree is ignored for num_views > 1 / perspective - the grid is swept densely, so "
+                          "the result has neither the octree's interpolated blocks nor its shared-`dirty` artefact "
+                          "(lib/sdf.py:55-120)", stacklevel=2)
         vh, vl, mat = eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     elif use_octree:
-        vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+        vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
+        if after_enqueue is not None:
+            after_enqueue()
     else:
-        out = reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform, want_normals)
+        called = []
+        hook = (lambda: (called.append(1), after_enqueue())) if after_enqueue is not None else None
+        out = reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform, want_normals, features=features,
+                                      after_enqueue=hook)
         if out is not None:
             return out
-        vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+        vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
+        if after_enqueue is not None and not called:
+            after_enqueue()
     return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
 
 

@@ -61,6 +61,7 @@ class SuRSNet:
         self.intermediate_preds_list_lr = []
         self.intermediate_preds_list_hr = []
         self._mr_points = None
+        self._mr_version = 0
 
     # ------------------------------------------------------------------ nn.Module-like plumbing
     def to(self, device=None, **kw):
@@ -156,6 +157,14 @@ class SuRSNet:
         self.im_feat_list_hr = [torch.cat([_as_nchw_view(pv[0]) for pv in per_view], 0) if len(per_view) > 1
                                 else _as_nchw_view(per_view[0][0])]
 
+    def encode_image(self, image):
+        """super_res -> filter_hr -> filter_lr of ONE view without touching the model's state: returns the two feature maps
+        (Img feat_lr, Img feat_hr) the query kernels read.  gen_mesh_pipelined runs it for the next subject on a second
+        stream while the current subject's features are still in use."""
+        W = self._encoder_weights()
+        _, f_lr, f_hr = encoder.super_res(W, _as_img(image[0:1]))
+        return encoder.filter_lr(W, f_lr)[-1], encoder.filter_hr(W, f_hr)[0]
+
     def features(self):
         """(Img feat_lr, Img feat_hr) of view 0, last stack: what the query kernels read."""
         if not self.im_feat_list_lr or not self.im_feat_list_hr:
@@ -199,14 +208,19 @@ class SuRSNet:
     def query_mr(self, points, calibs, transforms=None, labels=None):
         """Evaluates both classifiers in one fused pass; preds_hr is kept for the following query_sr."""
         phr, plr = self._query(points, calibs, transforms)
-        self._mr_points, self._mr_hr = points, phr
+        self._mr_points, self._mr_hr, self._mr_version = points, phr, points._version
         self.intermediate_preds_list_lr = [plr]
         self.preds_lr = plr
 
     def query_sr(self, points, calibs, transforms=None, labels=None):
         if self._mr_points is None:
             raise RuntimeError("query_sr needs the preceding query_mr (it consumes its lr predictions, SuRSNet.py:179)")
-        same = points is self._mr_points or (points.shape == self._mr_points.shape and bool(torch.equal(points, self._mr_points)))
+        # the same points as the preceding query_mr?  Decided without touching the data (a full-tensor compare is a device
+        # synchronisation per call): the same tensor object, or the same storage / view / version
+        ref, ver = self._mr_points, self._mr_version
+        same = (points is ref and points._version == ver) or (
+            points.data_ptr() == ref.data_ptr() and points.shape == ref.shape and points.stride() == ref.stride()
+            and points.dtype == ref.dtype and points._version == ver)
         if not same:
             raise NotImplementedError("query_sr on points other than the preceding query_mr's is not supported: the "
                                       "fused kernel feeds each point its own lr prediction")

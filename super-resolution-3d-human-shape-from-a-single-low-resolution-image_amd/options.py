@@ -69,6 +69,7 @@ _NATIVE = [
     ("precision", str, "fp32"),      # fp32 | bf16 | fp16 : arithmetic of the MLP contractions
     ("no_octree", None, False),      # dense sweep (the parity target)
     ("synthetic", None, False),      # synthetic image + PRNG weights instead of dataroot / checkpoint
+    ("pipeline", None, False),       # eval driver: subjects as a pipeline (train_util.gen_mesh_pipelined) instead of one by one
 ]
 
 
@@ -88,6 +89,8 @@ class BaseOptions:
         for name, typ, default in _NATIVE:
             if typ is None:
                 parser.add_argument("--" + name, action="store_true")
+            elif name == "precision":
+                parser.add_argument("--precision", type=str, default=default, choices=["fp32", "bf16", "fp16"])
             else:
                 parser.add_argument("--" + name, type=typ, default=default)
         self.initialized = True

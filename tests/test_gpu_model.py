@@ -46,6 +46,42 @@ def test_encoder_vs_reference(net, H, golden_dir):
     assert common.rel_err(s4(im_hr), g["im_feat_hr_sub"]) < tol
 
 
+def test_encoder_full_size_vs_reference(net, golden_dir):
+    """BASELINE's image size (512 x 512: feature maps 256 x 256^2 and 64 x 1024^2, GroupNorm groups of 2 M elements) against
+    the reference's own outputs: strided sub-samples of every output and of every stack's output, per-channel means of the
+    whole tensors (tests/golden/encoder_h512.npz, tools/gen_golden.py encoder512).  Relative 1e-4 of each tensor's range."""
+    g = np.load(os.path.join(golden_dir, "encoder_h512.npz"))
+    H = 512
+    img = torch.from_numpy(weights.synthetic_image(H, seed=1)).to("cuda:0")
+    img_sr, f_lr, f_hr = net.super_res(img)
+    assert tuple(f_lr.shape) == (1, 256, 256, 256) and tuple(f_hr.shape) == (1, 64, 1024, 1024)
+    net.filter_hr(f_hr)
+    was = net.training
+    net.train(True)           # training mode keeps every stack's output
+    net.filter_lr(f_lr)
+    net.train(was)
+    assert len(net.im_feat_list_lr) == 3
+    got = dict(img_sr=img_sr[0], feature_lr=f_lr[0], feature_hr=f_hr[0], im_feat_lr=net.im_feat_list_lr[2][0],
+               im_feat_hr=net.im_feat_list_hr[0][0])
+    step = dict(img_sr=8, feature_lr=8, feature_hr=16, im_feat_lr=8, im_feat_hr=16)
+    tol = 1e-4
+    for k, t in got.items():
+        scale = float(g[k + "_absmax"].max())
+        sub = t[:, ::step[k], ::step[k]].cpu().numpy()
+        assert np.abs(sub - g[k + "_sub"]).max() < tol * scale, (k, np.abs(sub - g[k + "_sub"]).max(), scale)
+        mean = t.double().mean((1, 2)).cpu().numpy()
+        assert np.abs(mean - g[k + "_mean"]).max() < tol * scale, (k, "mean")
+        amax = t.abs().amax((1, 2)).cpu().numpy()
+        assert np.abs(amax - g[k + "_absmax"]).max() < tol * scale, (k, "absmax")
+    for i in range(3):
+        t = net.im_feat_list_lr[i][0]
+        ref = g["tap_out%d_sub" % i]
+        assert np.abs(t[:, ::16, ::16].cpu().numpy() - ref).max() < tol * np.abs(ref).max(), i
+        assert np.abs(t.double().mean((1, 2)).cpu().numpy() - g["tap_out%d_mean" % i]).max() < tol * np.abs(ref).max(), i
+    net.eval()
+    net.filter_lr(f_lr)
+
+
 def test_encoder_taps_vs_oracle(net):
     """Bisecting aid: every stack's hourglass / output against the oracle at H=64."""
     import oracle
@@ -105,7 +141,20 @@ def test_reconstruction_vs_reference(net, R, golden_dir):
         assert np.array_equal(v, g["verts_" + tag])
     out = mesh_util.reconstruction(common.opt(), net, torch.device("cuda:0"), calib, R, b_min, b_max, use_octree=False)
     assert len(out) == 8
-    assert abs(len(out[0]) - len(g["verts_hr"])) <= max(8, len(g["verts_hr"]) // 100)
+    # end to end (the product's own field, within 1e-4 of the reference's): same surface - vertex counts within 0.3 %, and
+    # every vertex has a vertex of the reference's mesh within a small fraction of a voxel (and vice versa)
+    sys_path_tools = os.path.join(os.path.dirname(__file__), "..", "tools")
+    import sys
+    sys.path.insert(0, os.path.abspath(sys_path_tools))
+    import precision_report as pr
+    for mine, ref in ((out[0], g["verts_hr"]), (out[4], g["verts_lr"])):
+        assert abs(len(mine) - len(ref)) <= max(4, len(ref) * 3 // 1000)
+        a = torch.from_numpy(((mine - b_min) * R).astype(np.float32)).to("cuda:0")
+        b = torch.from_numpy(((ref - b_min) * R).astype(np.float32)).to("cuda:0")
+        for x, y in ((a, b), (b, a)):
+            d = pr.nearest_vertex_distance(x, y, R)
+            ok = torch.isfinite(d)
+            assert int((~ok).sum()) <= 2 and float(d[ok].mean()) < 2e-3, (int((~ok).sum()), float(d[ok].mean()))
     # OBJ writer: same bytes as the reference's writer for the reference's mesh
     txt = mesh_util._obj_text(g["verts_hr"], g["faces_hr"])
     assert hashlib.sha256(txt.encode()).hexdigest() == str(g["obj_hr_sha256"])
@@ -118,31 +167,45 @@ def test_gen_mesh_writes_both_objs(net, tmp_path):
     #                       volume -> "Surface level must be within volume data range", in the reference too)
     data = {"img_LR": torch.from_numpy(weights.synthetic_image(64, seed=1)), "b_min": np.array([-0.5] * 3),
             "b_max": np.array([0.5] * 3), "name": ("subject", ".png")}
-    train_util.gen_mesh(opt, net, torch.device("cuda:0"), data, str(tmp_path / "subject.obj"))
-    for tag in ("HR", "LR"):
-        lines = open(tmp_path / ("subject_%s.obj" % tag)).read().splitlines()
-        assert lines[0].startswith("v ") and lines[-1].startswith("f ")
+    vh, fh, vl, fl_ = train_util.gen_mesh(opt, net, torch.device("cuda:0"), data, str(tmp_path / "subject.obj"))
+    from surs_amd import mesh_util
+    for tag, v, f in (("HR", vh, fh), ("LR", vl, fl_)):
+        # the file holds the returned mesh in the reference writer's format, byte for byte (the format itself is pinned to
+        # the reference writer's output by the digest in test_reconstruction_vs_reference)
+        assert open(tmp_path / ("subject_%s.obj" % tag)).read() == mesh_util._obj_text(v, f)
+        assert f.dtype == np.int32 and v.dtype == np.float64 and f.min() == 0 and f.max() == len(v) - 1
     opt.resolution = 24
     with pytest.raises(ValueError, match="within volume data range"):
         train_util.gen_mesh(opt, net, torch.device("cuda:0"), data, str(tmp_path / "tiny.obj"))
 
 
 def test_eval_driver_end_to_end(tmp_path):
-    """python -m surs_amd.apps.eval_SuRS with reference-style flags (synthetic image + weights), octree and dense."""
+    """BASELINE configs[0]'s workload through the driver: python -m surs_amd.apps.eval_SuRS with the reference's flags, one
+    512 x 512 synthetic image + mask (--loadSize 1024), resolution 128 - octree (the reference's default) and dense bf16.
+    The OBJ files must hold exactly the bytes of the reference writer's format for the meshes that gen_mesh returns
+    in-process on the same inputs (the kernels are deterministic), with consistent indices."""
     import subprocess
     import sys
+    from surs_amd import data, mesh_util, model, options, train_util
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    flags = ["--synthetic", "--residual", "--loadSize", "1024", "--resolution", "128", "--name", "exp", "--b_min", "-0.5", "-0.5", "-0.5",
+             "--b_max", "0.5", "0.5", "0.5", "--num_samples", "50000", "--threshold", "0.05"]
     for extra in ([], ["--no_octree", "--precision", "bf16"]):
         out = tmp_path / ("run%d" % len(extra))
-        r = subprocess.run([sys.executable, "-m", "surs_amd.apps.eval_SuRS", "--synthetic", "--residual", "--loadSize", "128",
-                            "--resolution", "128", "--results_path", str(out), "--name", "exp", "--b_min", "-0.5", "-0.5", "-0.5",
-                            "--b_max", "0.5", "0.5", "0.5", "--num_samples", "50000", "--threshold", "0.05"] + extra,
+        r = subprocess.run([sys.executable, "-m", "surs_amd.apps.eval_SuRS", "--results_path", str(out)] + flags + extra,
                            cwd=root, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
-        for tag in ("HR", "LR"):
-            path = out / "exp" / ("synthetic_0000_%s.obj" % tag)
-            lines = open(path).read().splitlines()
-            assert lines[0].startswith("v ") and lines[-1].startswith("f ") and len(lines) > 100
+        opt = options.BaseOptions().parse(flags + extra + ["--results_path", str(out)])
+        n = model.SuRSNet(opt).to(device=torch.device("cuda:0"))
+        n.eval()
+        item = data.SyntheticDataset(opt)[0]
+        assert tuple(item["img_LR"].shape) == (1, 3, 512, 512)
+        vh, fh, vl, fl_ = train_util.gen_mesh(opt, n, torch.device("cuda:0"), item, str(tmp_path / "inproc.obj"),
+                                              use_octree=not opt.no_octree)
+        for tag, v, f in (("HR", vh, fh), ("LR", vl, fl_)):
+            txt = open(out / "exp" / ("synthetic_0000_%s.obj" % tag)).read()
+            assert txt == mesh_util._obj_text(v, f), (extra, tag)
+            assert len(v) > 1000 and f.min() == 0 and f.max() == len(v) - 1
 
 
 def test_multiview_facade_and_reconstruction(golden_dir):

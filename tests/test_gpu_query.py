@@ -41,6 +41,17 @@ def test_query_50k_vs_reference(setup, golden_dir):
     assert ((phr == 0) == (g["a_pred_hr"] == 0)).all()
 
 
+def test_query_50k_full_size_features_vs_reference(setup_full, golden_dir):
+    """BASELINE configs[1] as stated: 50 000 random points, fp32, feature maps of the 512 x 512 input's sizes (256 x 256^2,
+    64 x 1024^2), against the reference's outputs (tests/golden/query_h512.npz): 1e-4 on occupancies and logits."""
+    from surs_amd import weights
+    g = np.load(os.path.join(golden_dir, "query_h512.npz"))
+    phr, plr, lhr, llr = _q(setup_full, weights.synthetic_points(50000, seed=2), common.CALIB)
+    assert np.abs(phr - g["pred_hr"]).max() < 1e-4 and np.abs(plr - g["pred_lr"]).max() < 1e-4
+    assert np.abs(lhr - g["logit_hr"]).max() < 1e-4 and np.abs(llr - g["logit_lr"]).max() < 1e-4
+    assert ((phr == 0) == (g["pred_hr"] == 0)).all()
+
+
 def test_query_general_calib_ragged_and_edges(setup, golden_dir):
     from surs_amd import weights
     g = np.load(os.path.join(golden_dir, "query.npz"))

@@ -31,6 +31,17 @@ def test_query_random_points(golden_dir):
     assert ((phr == 0) == (g["a_pred_hr"] == 0)).all()  # the in-image mask
 
 
+def test_query_full_size_features(golden_dir):
+    """The same 50 000 points over feature maps of BASELINE's sizes (256 x 256^2 / 64 x 1024^2): tests/golden/query_h512.npz."""
+    g = np.load(os.path.join(golden_dir, "query_h512.npz"))
+    fl, fh = common.synth_features(seed=7, hl=256, hh=1024)
+    pts = weights.synthetic_points(50000, seed=2)
+    phr, plr, lhr, llr = oracle.query(common.state_dict(), pts, common.CALIB, fl, fh, 1024, 200.0, want_logits=True)
+    assert np.abs(phr - g["pred_hr"]).max() < 1e-5 and np.abs(plr - g["pred_lr"]).max() < 1e-5
+    assert np.abs(lhr - g["logit_hr"]).max() < 2e-5 and np.abs(llr - g["logit_lr"]).max() < 2e-5
+    assert ((phr == 0) == (g["pred_hr"] == 0)).all()
+
+
 def test_query_general_calib_and_edges(golden_dir):
     g = np.load(os.path.join(golden_dir, "query.npz"))
     fl, fh = common.synth_features()

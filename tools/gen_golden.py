@@ -182,6 +182,59 @@ def gen_encoder():
             torch.save({"im_lr": im_lr, "im_hr": im_hr}, "/tmp/enc64_feats.pt")
 
 
+def gen_encoder512():
+    """BASELINE's image size: the reference encoder on the 512 x 512 synthetic image.  The tensors are 67 - 268 MB each, so
+    the fixture holds strided sub-samples (every 8th / 16th pixel of every channel) plus per-channel means (float64 sums)
+    and abs-maxima of the whole tensors."""
+    net, opt_ref, sd = make_net()
+    H = 512
+    img = weights.synthetic_image(H, seed=1)
+    taps, hooks = {}, []
+
+    def tap(name, mod):
+        hooks.append(mod.register_forward_hook(lambda m, i, o, name=name: taps.__setitem__(name, o.detach()[0].numpy().copy())))
+
+    tap("conv2", net.image_filter_lr.conv2)
+    for i in range(3):
+        tap("hg%d" % i, getattr(net.image_filter_lr, "m%d" % i))
+        tap("out%d" % i, getattr(net.image_filter_lr, "l%d" % i))
+    t = time.time()
+    with torch.no_grad(), rh.quiet():
+        img_sr, f_lr, f_hr = net.super_res(torch.from_numpy(img.copy()))
+        net.filter_hr(f_hr)
+        net.filter_lr(f_lr)
+    for h in hooks:
+        h.remove()
+    print("encoder H=512: %.1fs" % (time.time() - t))
+    full = dict(img_sr=img_sr[0].numpy(), feature_lr=f_lr[0].numpy(), feature_hr=f_hr[0].numpy(),
+                im_feat_lr=net.im_feat_list_lr[0][0].numpy(), im_feat_hr=net.im_feat_list_hr[0][0].numpy())
+    step = dict(img_sr=8, feature_lr=8, feature_hr=16, im_feat_lr=8, im_feat_hr=16)
+    out = {}
+    for k, v in full.items():
+        out[k + "_sub"] = _sub(v, step[k])
+        out[k + "_mean"] = v.astype(np.float64).mean((1, 2))
+        out[k + "_absmax"] = np.abs(v).max((1, 2))
+    for k, v in taps.items():
+        out["tap_" + k + "_sub"] = _sub(v, 16)
+        out["tap_" + k + "_mean"] = v.astype(np.float64).mean((1, 2))
+    np.savez_compressed(os.path.join(GOLD, "encoder_h512.npz"), **out)
+    for k, v in out.items():
+        print("  ", k, v.shape, float(np.abs(v).max()))
+
+
+def gen_query512():
+    """The 50 000-point query of BASELINE configs[1] on feature maps of BASELINE's sizes (256 x 256^2 and 64 x 1024^2, PRNG
+    values, seed 7 = tests/common.synth_features(seed=7, hl=256, hh=1024))."""
+    net, opt_ref, sd = make_net()
+    fl, fh = synth_features(seed=7, hl=256, hh=1024)
+    net.im_feat_list_lr = [torch.from_numpy(fl[None].copy())]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None].copy())]
+    pts = weights.synthetic_points(50000, seed=2)
+    phr, plr, lhr, llr = run_query(net, pts, CALIB)
+    np.savez_compressed(os.path.join(GOLD, "query_h512.npz"), pred_hr=phr, pred_lr=plr, logit_hr=lhr, logit_lr=llr)
+    print("query512: pred_hr range", phr.min(), phr.max(), "outside frac", float((phr == 0).mean()))
+
+
 def gen_recon():
     net, opt_ref, sd = make_net()
     ns = rh.load_reference()
