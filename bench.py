@@ -213,24 +213,24 @@ def main():
 
             class Raws:
                 def get_raw_item(self, i):
-                    return ds.get_raw_item(i)     # decoded again per subject, like reading the files
+                    return raws[i]                # decoded pixels held in memory on both sides
 
             def pipelined():
                 train_util.gen_mesh_pipelined(opt, net, dev, Raws(), range(K), None, use_octree=False, write=False)
 
             times = {}
-            for name, fn in (("sequential", sequential), ("pipelined", pipelined)):
+            for name, fn in (("sequential", sequential), ("pipelined", pipelined), ("sequential", sequential), ("pipelined", pipelined)):
                 fn()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 fn()
                 torch.cuda.synchronize()
-                times[name] = time.perf_counter() - t0
+                times[name] = min(times.get(name, 1e9), time.perf_counter() - t0)
             extras["subject_pipeline"] = {"subjects": K, "resolution": R, "precision": args.precision,
                                           "sequential_subjects_per_s": K / times["sequential"],
                                           "pipelined_subjects_per_s": K / times["pipelined"],
-                                          "note": "8-bit pixels in host memory -> meshes in host memory; sequential decodes nothing "
-                                                  "(pixels held in memory), pipelined regenerates them per subject on a host thread"}
+                                          "note": "decoded 8-bit pixels in host memory -> meshes in host memory, no OBJ files; the sweep keeps "
+                                                  "the GPU busy in both, the pipeline hides the input stage and the host gaps"}
         except Exception as e:
             extras["subject_pipeline"] = {"error": repr(e)}
     if world == 1 and not args.no_extras and R == RES:

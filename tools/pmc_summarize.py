@@ -1,12 +1,17 @@
 """Reduces the rocprofv3 --pmc CSVs that tools/profile_round.sh collected (gpurun_out/prof/) to profiles/pmc_summary.json
-and copies the per-kernel rows of the column kernel next to it.  HBM bytes per launch of the column kernel =
+and copies the per-kernel rows of the column kernels next to it.  HBM bytes per launch of a column kernel =
 2 x FETCH_SIZE (the gfx950 correction of MI355X_MICROARCH.md: the counter reports half the bytes of wide coalesced reads)
-+ WRITE_SIZE, both in KiB, each from its own pass, averaged over the launches of that kernel."""
++ WRITE_SIZE, both in KiB, each from its own pass, averaged over the launches of that kernel.  The summary records the
+sha256 of the library the counters were collected on: bench.py reports them only for that library.
+
+    python tools/pmc_summarize.py r02
+"""
 import csv, glob, json, os, sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+PRODUCTS = {"bf16": 1, "fp32": 3}
 
 
 def rows(sub, counter):
@@ -38,31 +43,39 @@ def keep(sub, counter, name):
     return rs
 
 
-fetch = keep("pmc_fetch", "FETCH_SIZE", "%s_pmc_fetch_size.csv" % TAG)
-write = keep("pmc_write", "WRITE_SIZE", "%s_pmc_write_size.csv" % TAG)
-hit, miss = rows("pmc_l2", "TCC_HIT_sum"), rows("pmc_l2", "TCC_MISS_sum")
-gui = rows("pmc_clk", "GRBM_GUI_ACTIVE")
-mfma = keep("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES", "%s_pmc_mfma_busy.csv" % TAG)
-f_kb, w_kb = mean(fetch), mean(write)
-s = {
-    "kernel": fetch[0]["Kernel_Name"] if fetch else None,
-    "launch": "16384 columns x 512 voxels = 8388608 queries (bf16, R=512), tools/gpu_grid_once.py 512 bf16",
-    "fetch_size_kb_raw_per_launch": f_kb,
-    "write_size_kb_per_launch": w_kb,
-    "grid_mlp_kernel_hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0 if f_kb is not None and w_kb is not None else None,
-    "l2_hit_rate": (mean(hit) / (mean(hit) + mean(miss))) if hit and miss else None,
-    "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
-    "effective_clock_ghz": (mean(gui) / 8.0 / (dur_ms(gui) * 1e-3) * 1e-9) if gui else None,
-    "avg_launch_ms_under_pmc": dur_ms(fetch),
-    # SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipes were busy, summed over the chip's 1024 SIMDs (32 per
-    # v_mfma_f32_32x32x16_bf16); the denominator is the launch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs
-    "mfma_busy_cycles_per_launch": mean(mfma) if mfma else None,
-    "mfma_busy_fraction": (mean(mfma) / (mean(gui) / 8.0 * 1024.0)) if mfma and gui else None,
-    "mfma_busy_cycles_expected": 8388608 * 2752512 / 32768 * 32,   # executed FLOP / FLOP per MFMA x 32 cycles
-    # algorithmic bytes of one launch: the per-column constants (CC_PAD floats per column), the column masks, the two
-    # output fields (2 x 4 B per voxel) and the packed weight stream once (2 x 42 slabs x 32 KiB)
-    "algorithmic_bytes_per_launch": 16384 * 2944 * 4 + 16384 * 4 + 8388608 * 8 + 2 * 42 * 32768,
-    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); separate --pmc passes; GRBM_GUI_ACTIVE is summed over the 8 XCDs",
-}
+def one(prec):
+    fetch = keep("pmc_fetch_" + prec, "FETCH_SIZE", "%s_pmc_fetch_size_%s.csv" % (TAG, prec))
+    write = keep("pmc_write_" + prec, "WRITE_SIZE", "%s_pmc_write_size_%s.csv" % (TAG, prec))
+    hit, miss = rows("pmc_l2_" + prec, "TCC_HIT_sum"), rows("pmc_l2_" + prec, "TCC_MISS_sum")
+    gui = rows("pmc_clk_" + prec, "GRBM_GUI_ACTIVE")
+    mfma = keep("pmc_mfma_" + prec, "SQ_VALU_MFMA_BUSY_CYCLES", "%s_pmc_mfma_busy_%s.csv" % (TAG, prec))
+    f_kb, w_kb = mean(fetch), mean(write)
+    n = PRODUCTS[prec]
+    weights = 2 * 42 * 32768 * (2 if prec == "fp32" else 1)     # the packed weight stream once (fp32: hi + lo parts)
+    return {
+        "kernel": fetch[0]["Kernel_Name"] if fetch else None,
+        "launch": "16384 columns x 512 voxels = 8388608 queries (R=512), tools/gpu_grid_once.py 512 " + prec,
+        "fetch_size_kb_raw_per_launch": f_kb,
+        "write_size_kb_per_launch": w_kb,
+        "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0 if f_kb is not None and w_kb is not None else None,
+        "l2_hit_rate": (mean(hit) / (mean(hit) + mean(miss))) if hit and miss else None,
+        "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
+        "effective_clock_ghz": (mean(gui) / 8.0 / (dur_ms(gui) * 1e-3) * 1e-9) if gui else None,
+        "avg_launch_ms_under_pmc": dur_ms(fetch),
+        # SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipes were busy, summed over the chip's 1024 SIMDs (32 per
+        # v_mfma_f32_32x32x16_*); the denominator is the launch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs
+        "mfma_busy_cycles_per_launch": mean(mfma) if mfma else None,
+        "mfma_busy_fraction": (mean(mfma) / (mean(gui) / 8.0 * 1024.0)) if mfma and gui else None,
+        "mfma_busy_cycles_expected": 8388608 * 2752512 * n / 32768 * 32,   # executed FLOP / FLOP per MFMA x 32 cycles
+        # compulsory bytes of one launch: the two output fields (2 x 4 B per voxel) and the weight stream once; the
+        # per-column constants (CC_PAD floats per column) and masks are the sweep's own intermediate, listed separately
+        "algorithmic_bytes_per_launch": 8388608 * 8 + weights,
+        "column_constant_bytes_per_launch": 16384 * 2944 * 4 + 16384 * 4,
+    }
+
+
+s = {"lib_sha256": open(os.path.join(SRC, "lib_sha256.txt")).read().split()[0] if os.path.exists(os.path.join(SRC, "lib_sha256.txt")) else None,
+     "round": TAG, "kernels": {p: one(p) for p in ("bf16", "fp32")},
+     "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); separate --pmc passes; GRBM_GUI_ACTIVE is summed over the 8 XCDs"}
 json.dump(s, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(s, indent=1))
