@@ -10,23 +10,27 @@
 //     own only the three edges meeting at their far corner (5, 6, 10) and their centre vertex (12);
 //   * inside the owning cell vertices are numbered in order of first appearance in its triangle list;
 //   * faces are emitted cell by cell in sweep order, triangles in LUT order.
-// So:  pass 1  classify: MC33 tests on every cell that the surface crosses; the chosen triangle list is stored as a 32-bit
-//              cell code (table, offset, triangle count, vertices created; 0 = empty cell), and vertices / triangles /
-//              active cells are summed per block of 1024 sweep-consecutive cells
-//      pass 2  exclusive scan of the block sums
-//      pass 3  compaction: the active cells in sweep order, found with wavefront ballots over the cell codes; the
-//              in-block prefixes of their vertex and triangle counts are sums of popcounts of per-bit ballots.
-//              One 16-byte entry per active cell: (cell, code, first vertex id, first triangle id)
+// So:  pass 1  count: every thread streams the corner rows of four consecutive cells (aligned 16-byte loads), decides
+//              inside / outside per voxel with one float compare and lists the cells the surface crosses in LDS (wavefront
+//              ballots for the ranks); the listed cells are classified (MC33 tests in double; a 256-entry table for the
+//              cube indices that need no test) and vertices / triangles / active cells are summed per block of 1024
+//              sweep-consecutive cells, with the volume's min / max.  Nothing is written per cell.
+//      pass 2  exclusive scan of the block sums, two levels (1024 blocks per group, then the groups)
+//      pass 3  emit: the same classification again, only in blocks that have active cells; one 16-byte entry per active
+//              cell in sweep order: (cell, code = table / offset / counts, first vertex id, first triangle id)
 //      pass 4a vertices, one thread per ACTIVE cell: positions; ids stored in 4 dense per-voxel tables
 //              (x-edge, y-edge, z-edge starting at the voxel, centre of the cell whose corner 0 it is)
 //      pass 4b faces (+ values by atomic max, normals by atomic add): vertex ids looked up in the tables
 //      pass 5  normalise normals.
-// HBM-bound: the volume is read once (pass 1; corner re-reads hit L1/L2), then 4 bytes per cell (pass 3) and the
-// active cells only; the ambiguity tests run in double, once, on the active cells.  All arithmetic that decides topology or positions is double, written exactly
-// as the Cython core evaluates it (compiled with -ffp-contract=off).
+// HBM-bound by design: the volume is read once (pass 1) plus the blocks with a surface once more (pass 3: a few per cent
+// for a body-sized surface), then the active cells only.  Measured at 512^3 on a body-sized blob (4.3 x 10^5 vertices):
+// 0.67 ms of kernels (count 0.37, emit 0.19, vertices + faces 0.09), pass 1 being bound by its ~100 integer / compare
+// instructions per cell, not by the 537 MB it reads.  All arithmetic that decides topology or positions is double, written
+// exactly as the Cython core evaluates it (compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 
 #include "surs_common.h"
 
@@ -47,7 +51,9 @@ struct Dims {
     int nz, ny, nx;     // volume dims (axis 0, 1, 2)
     int cz, cy, cx;     // cells per axis
     long long ncells;
-    long long cell_begin, cell_end;   // the flat (sweep-order) cell range this call processes
+    long long cell_begin, cell_end;   // the flat (sweep-order) cell range this call processes (whole layers)
+    int prow;                         // padded row length of the classification passes: cx rounded up to a multiple of 4
+    long long q_begin, q_end;         // the same range as padded indices q = (z * cy + y) * prow + x
     int base_verts, base_faces;      // vertices / triangles produced by earlier ranges
     int zoff;                        // slab mode: index of the volume's plane 0 in the whole grid (0 = the grid's bottom)
 };
@@ -341,39 +347,204 @@ __device__ __forceinline__ void count_cell(const Tiling &t, unsigned own, int &n
     nv = __popc(seen & own);
 }
 
-// ---------------------------------------------------------------- pass 1: classify
+// ---------------------------------------------------------------- passes 1 and 3: classify (count) and classify again (emit)
+// A block = 1024 sweep-consecutive cells, a thread = 4 consecutive cells.  Inside one grid row (the common case) the four
+// cells share their corner rows: 4 rows x 5 consecutive floats instead of 4 x 8 scattered loads, each voxel compared with
+// the level once.  Pass 1 (count) only sums vertices / triangles / active cells and min / max per block: nothing is written
+// per cell.  After the scan, pass 3 (emit) runs the same classification again - but only in blocks that have active cells
+// (for a body-sized surface a few per cent of the blocks: the volume is read once plus that) - and writes the active cells
+// in sweep order with their first vertex / triangle numbers.  The cell code (table, offset, counts) lives in registers.
 struct BlockSums {
     int nv, nt, na, pad;
 };
 
-__global__ __launch_bounds__(THREADS) void mc_classify_kernel(const float *__restrict__ vol, Dims d, double level,
-                                                              unsigned *__restrict__ codes, BlockSums *__restrict__ block_counts,
-                                                              float2 *__restrict__ block_minmax) {
+struct ActiveCell {
+    unsigned cell, code;
+    int vid0, tri0;
+};
+
+constexpr int CELLS_PER_THREAD = CELLS_PER_BLOCK / THREADS;
+static_assert(CELLS_PER_THREAD == 4, "mc_scan_block handles four cells per thread");
+
+// Cube indices whose MC33 case needs no face / interior test (cases 1, 2, 5, 8, 9, 11, 14: every cell of a smooth surface)
+// resolve through a 256-entry table filled once per device: the cell code without its vertex count, and the set of edges
+// its triangles use (the vertex count is the popcount of that set masked with the edges the cell owns).  The general path -
+// select_tiling and a walk over the triangle list, a chain of dependent look-ups - remains for the ambiguous cases.
+__device__ unsigned g_fast_code[256];
+__device__ unsigned g_fast_seen[256];
+
+__global__ void mc_fast_init_kernel() {
+    const int index = threadIdx.x;
+    const int mccase = MCL_CASES[2 * index];
+    unsigned code = 0, seen = 0;
+    if (mccase == 1 || mccase == 2 || mccase == 5 || mccase == 8 || mccase == 9 || mccase == 11 || mccase == 14) {
+        const double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // not read for these cases
+        const Tiling t = select_tiling(v, index);
+        for (int i = 0; i < 3 * t.nt; ++i) seen |= 1u << t.row[i];
+        code = encode_cell(t, 0);
+    }
+    g_fast_code[index] = code;
+    g_fast_seen[index] = seen;
+}
+
+__device__ __forceinline__ unsigned classify_cell(const double *v, int index, unsigned own) {
+    const unsigned fast = g_fast_code[index];
+    if (fast != 0u) return fast | ((unsigned)__popc(g_fast_seen[index] & own) << 4);
+    const Tiling t = select_tiling(v, index);
+    int nt, nv;
+    count_cell(t, own, nt, nv);
+    return encode_cell(t, nv);
+}
+
+// Threads walk a PADDED cell index q = row * prow + x (row = z * cy + y, prow = cx rounded up to a multiple of 4; cells with
+// x >= cx do not exist): monotone in the sweep order, a thread's four cells q .. q+3 lie in one row and start at x % 4 == 0,
+// so with nx % 4 == 0 each corner row is one aligned 16-byte load plus one float.
+//
+// Both passes run in two phases.  Phase 1 streams: every thread reads the corner rows of its four cells, decides
+// inside / outside per voxel with one float compare (levelf = the largest float <= level: for a float f, f > levelf is
+// exactly (double)f - level > 0), forms the four cube indices and appends the cells the surface crosses, in sweep order,
+// to a list in LDS (wavefront ballots for the ranks).  Phase 2 works on that list with all lanes busy: thread t takes the
+// entries 4t .. 4t+3, re-reads their corners (L1 / L2 hits) and classifies them (MC33 tests in double).  A block without
+// surface - nearly every block of a body-sized field - ends after phase 1.
+struct CellList {
+    unsigned short x[CELLS_PER_BLOCK];     // position of the cell in the block (padded index - block start)
+    unsigned char index[CELLS_PER_BLOCK];  // its cube index
+    int wave_count[4];
+    int n;
+};
+
+__device__ __forceinline__ void decode_q(const Dims &d, long long q, int &x, int &y, int &z) {
+    const unsigned q32 = (unsigned)q, pr = (unsigned)d.prow, cy = (unsigned)d.cy;
+    const unsigned row = q32 / pr;
+    x = (int)(q32 - row * pr);
+    const unsigned zz = row / cy;
+    y = (int)(row - zz * cy);
+    z = (int)zz;
+}
+
+// phase 1 for the block starting at padded index q0: fills `list` (sweep order) and widens lo / hi by the block's voxels
+__device__ __forceinline__ void mc_scan_block(const float *__restrict__ vol, const Dims &d, float levelf, long long q0,
+                                              CellList &list, float &lo, float &hi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long q = q0 + (long long)threadIdx.x * CELLS_PER_THREAD;
+    unsigned idx[4] = {0, 0, 0, 0};
+    int ncell = 0;
+    if (q < d.q_end) {
+        int x, y, z;
+        decode_q(d, q, x, y, z);
+        ncell = max(0, min(4, d.cx - x));
+        if (ncell > 0) {
+            const size_t sy = (size_t)d.nx, sz = (size_t)d.nx * d.ny;
+            const float *p = vol + (size_t)z * sz + (size_t)y * sy + x;
+            float r[4][5];   // rows (y, z), (y+1, z), (y, z+1), (y+1, z+1)
+            if ((d.nx & 3) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 v = *reinterpret_cast<const float4 *>(p + (k & 1) * sy + (k >> 1) * sz);
+                    r[k][0] = v.x; r[k][1] = v.y; r[k][2] = v.z; r[k][3] = v.w;
+                    r[k][4] = ncell == 4 ? p[(k & 1) * sy + (k >> 1) * sz + 4] : v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) r[k][j] = p[(k & 1) * sy + (k >> 1) * sz + min(j, ncell)];
+            }
+            // min / max: every voxel is covered by row 0 of some thread, except the last plane of axis 1 (row 1 when y is the
+            // last cell row) and of axis 0 (rows 2, 3 when z is the last cell layer of the volume)
+            const bool ylast = y == d.cy - 1, zlast = z == d.cz - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool use = k == 0 || (k == 1 && ylast) || (k == 2 && zlast) || (k == 3 && ylast && zlast);
+                if (use) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        lo = fminf(lo, r[k][j]);
+                        hi = fmaxf(hi, r[k][j]);
+                    }
+                }
+            }
+            unsigned in[4];   // bit j of in[k]: voxel j of row k is inside
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                in[k] = 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) in[k] |= (r[k][j] > levelf ? 1u : 0u) << j;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // corners v0..v7 = (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z) (x,y,z+1) (x+1,y,z+1) (x+1,y+1,z+1) (x,y+1,z+1)
+                const unsigned a0 = in[0] >> i, a1 = in[1] >> i, a2 = in[2] >> i, a3 = in[3] >> i;
+                idx[i] = (a0 & 1) | (a0 & 2) | ((a1 & 2) << 1) | ((a1 & 1) << 3) | ((a2 & 1) << 4) | ((a2 & 2) << 4) |
+                         ((a3 & 2) << 5) | ((a3 & 1) << 7);
+                if (i >= ncell) idx[i] = 0;
+            }
+        }
+    }
+    // ranks in sweep order: lanes below (ballots over the bits of the per-thread count), waves below (LDS)
+    bool act[4];
+    int ta = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        act[i] = idx[i] != 0u && idx[i] != 255u;
+        ta += act[i];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int pa = 0, wa = 0;
+#pragma unroll
+    for (int bit = 0; bit < 3; ++bit) {
+        const unsigned long long m = __ballot((ta >> bit) & 1);
+        pa += __popcll(m & below) << bit;
+        wa += __popcll(m) << bit;
+    }
+    __syncthreads();   // the previous block's list has been consumed
+    if (lane == 0) list.wave_count[wave] = wa;
+    __syncthreads();
+    int base = pa;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) base += list.wave_count[w];
+    if (threadIdx.x == 0) list.n = list.wave_count[0] + list.wave_count[1] + list.wave_count[2] + list.wave_count[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (act[i]) {
+            list.x[base] = (unsigned short)(threadIdx.x * CELLS_PER_THREAD + i);
+            list.index[base] = (unsigned char)idx[i];
+            ++base;
+        }
+    __syncthreads();
+}
+
+// phase 2: list entry e -> its cell code and flat cell number (one entry per thread and round: the corner re-read and the
+// table look-ups are a chain of two memory latencies, so a block's entries go side by side, not one after the other)
+__device__ __forceinline__ unsigned mc_classify_entry(const float *__restrict__ vol, const Dims &d, double level, long long q0,
+                                                      const CellList &list, int e, unsigned &cell) {
+    int x, y, z;
+    decode_q(d, q0 + list.x[e], x, y, z);
+    Cell c;
+    float lo = 0.f, hi = 0.f;
+    load_cell(vol, d, x, y, z, level, c, lo, hi);
+    cell = (unsigned)(((long long)z * d.cy + y) * d.cx + x);
+    return classify_cell(c.v, (int)list.index[e], owned_mask(x, y, z + d.zoff));
+}
+
+__global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
+                                                           BlockSums *__restrict__ block_counts,
+                                                           float2 *__restrict__ block_minmax) {
+    __shared__ CellList list;
     __shared__ int red[3][4];
     __shared__ float redf[2][4];
-    const long long c0 = d.cell_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
-    int nt_sum = 0, nv_sum = 0, na_sum = 0;
+    const long long q0 = d.q_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
     float lo = FLT_MAX, hi = -FLT_MAX;
-    for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
-        const long long c = c0 + r * THREADS + threadIdx.x;
-        if (c >= d.cell_end) break;
-        int x, y, z;
-        cell_xyz(d, c, x, y, z);
-        Cell cell;
-        load_cell(vol, d, x, y, z, level, cell, lo, hi);
-        unsigned code = 0;
-        if (cell.index != 0 && cell.index != 255) {
-            const Tiling t = select_tiling(cell.v, cell.index);
-            int nt, nv;
-            count_cell(t, owned_mask(x, y, z + d.zoff), nt, nv);
-            nt_sum += nt;
-            nv_sum += nv;
-            na_sum += 1;
-            code = encode_cell(t, nv);
-        }
-        if (codes) codes[c] = code;
+    mc_scan_block(vol, d, levelf, q0, list, lo, hi);
+    int nt_sum = 0, nv_sum = 0, na_sum = 0;
+    for (int e = threadIdx.x; e < list.n; e += THREADS) {
+        unsigned cell;
+        const unsigned code = mc_classify_entry(vol, d, level, q0, list, e, cell);
+        nt_sum += code_nt(code);
+        nv_sum += code_nv(code);
+        na_sum += 1;
     }
-    // block reduce
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -392,14 +563,63 @@ __global__ __launch_bounds__(THREADS) void mc_classify_kernel(const float *__res
         bs.na = red[2][0] + red[2][1] + red[2][2] + red[2][3];
         bs.pad = 0;
         block_counts[blockIdx.x] = bs;
-        // the volume's min / max: per block here, reduced by the scan kernel (131 072 same-address atomics at 512^3 cost
-        // 2.7 of this kernel's 3.0 ms)
         block_minmax[blockIdx.x] = make_float2(fminf(fminf(redf[0][0], redf[0][1]), fminf(redf[0][2], redf[0][3])),
                                                fmaxf(fmaxf(redf[1][0], redf[1][1]), fmaxf(redf[1][2], redf[1][3])));
     }
 }
 
-// ---------------------------------------------------------------- pass 2: exclusive scan of the block sums (one workgroup)
+// ---------------------------------------------------------------- pass 2: exclusive scan of the block sums, two levels
+// Level 1: one workgroup per 1024 blocks scans its entries (offsets local to the group) and leaves the group's totals and
+// min / max; level 2 (mc_scan_kernel, one workgroup) scans the group totals.  Offset of block b = group[b >> 10] + local[b].
+constexpr int SCAN_GROUP = 1024;
+
+__global__ __launch_bounds__(1024) void mc_scan1_kernel(const BlockSums *__restrict__ counts, BlockSums *__restrict__ local,
+                                                        int nblocks, BlockSums *__restrict__ group_counts,
+                                                        const float2 *__restrict__ block_minmax, float2 *__restrict__ group_minmax) {
+    __shared__ int wsum[3][16];
+    __shared__ float wmm[2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * SCAN_GROUP + threadIdx.x;
+    BlockSums v = {0, 0, 0, 0};
+    float lo = FLT_MAX, hi = -FLT_MAX;
+    if (i < nblocks) {
+        v = counts[i];
+        const float2 mm = block_minmax[i];
+        lo = mm.x;
+        hi = mm.y;
+    }
+    int a = v.nv, b = v.nt, c = v.na;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int na = __shfl_up(a, o), nb = __shfl_up(b, o), nc = __shfl_up(c, o);
+        if (lane >= o) { a += na; b += nb; c += nc; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if (lane == 63) { wsum[0][wave] = a; wsum[1][wave] = b; wsum[2][wave] = c; }
+    if (lane == 0) { wmm[0][wave] = lo; wmm[1][wave] = hi; }
+    __syncthreads();
+    int pa = 0, pb = 0, pc = 0;
+    for (int w = 0; w < wave; ++w) { pa += wsum[0][w]; pb += wsum[1][w]; pc += wsum[2][w]; }
+    if (i < nblocks) {
+        BlockSums o;
+        o.nv = pa + a - v.nv; o.nt = pb + b - v.nt; o.na = pc + c - v.na; o.pad = 0;
+        local[i] = o;
+    }
+    if (threadIdx.x == 1023) {
+        BlockSums t;
+        t.nv = pa + a; t.nt = pb + b; t.na = pc + c; t.pad = 0;
+        group_counts[blockIdx.x] = t;
+    }
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) { lo = fminf(lo, wmm[0][w]); hi = fmaxf(hi, wmm[1][w]); }
+        group_minmax[blockIdx.x] = make_float2(lo, hi);
+    }
+}
+
 __global__ __launch_bounds__(1024) void mc_scan_kernel(const BlockSums *__restrict__ counts, BlockSums *__restrict__ offsets,
                                                        int nblocks, int *__restrict__ totals,
                                                        const float2 *__restrict__ block_minmax, float *__restrict__ minmax) {
@@ -453,61 +673,66 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const BlockSums *__restri
     }
 }
 
-// ---------------------------------------------------------------- pass 3: active-cell compaction with wavefront ballots
-// One wave per 64 sweep-consecutive cells.  The rank of an active cell among the wave's active cells is the popcount of
-// the ballot below its lane; the in-wave prefixes of the vertex count and triangle count (4 bits each) are
-// sum_b 2^b * popc(ballot(bit b of the count) & lanes_below).  Waves of a block combine through LDS.
-struct ActiveCell {
-    unsigned cell, code;
-    int vid0, tri0;
-};
-
-__global__ __launch_bounds__(THREADS) void mc_compact_kernel(const unsigned *__restrict__ codes, Dims d,
-                                                             const BlockSums *__restrict__ block_offsets,
-                                                             ActiveCell *__restrict__ alist) {
-    __shared__ int wsum[3][4];
+// ---------------------------------------------------------------- pass 3: emit the active cells in sweep order
+// Only blocks with active cells do any work.  A thread's four cells are consecutive in sweep order, so the rank of an
+// active cell is (active cells of the lanes below, by wavefront ballots over the per-thread counts) + (its rank inside the
+// thread); the running vertex / triangle numbers likewise, as sums of popcounts of per-bit ballots (no shuffles).
+__global__ __launch_bounds__(THREADS) void mc_emit_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
+                                                          int nblocks, const BlockSums *__restrict__ block_counts,
+                                                          const BlockSums *__restrict__ local_offsets,
+                                                          const BlockSums *__restrict__ group_offsets,
+                                                          ActiveCell *__restrict__ alist) {
+    __shared__ CellList list;
+    __shared__ int wsum[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long c0 = d.cell_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
-    const BlockSums bo = block_offsets[blockIdx.x];
-    int run_v = d.base_verts + bo.nv, run_t = d.base_faces + bo.nt, run_a = bo.na;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int r = 0; r < CELLS_PER_BLOCK / THREADS; ++r) {
-        const long long c = c0 + r * THREADS + threadIdx.x;
-        const unsigned code = (c < d.cell_end) ? codes[c] : 0u;
-        const bool active = code != 0u;
-        const unsigned long long am = __ballot(active);
-        const int nt = code_nt(code), nv = code_nv(code);
-        int pa = __popcll(am & below), pv = 0, pt = 0, wv = 0, wt = 0;
+    // a workgroup walks a contiguous run of blocks and skips the empty ones (launching one workgroup per block costs more
+    // than the whole pass when a few per cent of the blocks have a surface)
+    const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b_end = min(nblocks, ((int)blockIdx.x + 1) * per);
+    for (int blk = (int)blockIdx.x * per; blk < b_end; ++blk) {
+        if (block_counts[blk].na == 0) continue;   // uniform over the workgroup
+        const long long q0 = d.q_begin + (long long)blk * CELLS_PER_BLOCK;
+        float lo = 0.f, hi = 0.f;
+        mc_scan_block(vol, d, levelf, q0, list, lo, hi);
+        const BlockSums lo_ = local_offsets[blk], go = group_offsets[blk / SCAN_GROUP];
+        int carry_v = d.base_verts + go.nv + lo_.nv, carry_t = d.base_faces + go.nt + lo_.nt;
+        const int a0 = go.na + lo_.na;   // list entries are the block's active cells, in order
+        const int n = list.n;
+        for (int e0 = 0; e0 < n; e0 += THREADS) {   // rounds of 256 entries, one per thread
+            const int e = e0 + (int)threadIdx.x;
+            unsigned code = 0u, cell = 0u;
+            if (e < n) code = mc_classify_entry(vol, d, level, q0, list, e, cell);
+            const int tv = code_nv(code), tt = code_nt(code);
+            int pv = 0, pt = 0, wv = 0, wt = 0;   // prefixes inside the wave, the wave's totals
 #pragma unroll
-        for (int bit = 0; bit < 4; ++bit) {
-            const unsigned long long m = __ballot((nv >> bit) & 1);
-            pv += __popcll(m & below) << bit;
-            wv += __popcll(m) << bit;
-        }
+            for (int bit = 0; bit < 4; ++bit) {   // a cell creates at most 13 vertices, 12 triangles
+                const unsigned long long mv = __ballot((tv >> bit) & 1), mt = __ballot((tt >> bit) & 1);
+                pv += __popcll(mv & below) << bit;
+                wv += __popcll(mv) << bit;
+                pt += __popcll(mt & below) << bit;
+                wt += __popcll(mt) << bit;
+            }
+            __syncthreads();   // wsum of the previous round has been read
+            if (lane == 0) { wsum[0][wave] = wv; wsum[1][wave] = wt; }
+            __syncthreads();
+            int run_v = carry_v + pv, run_t = carry_t + pt;
 #pragma unroll
-        for (int bit = 0; bit < 4; ++bit) {
-            const unsigned long long m = __ballot((nt >> bit) & 1);
-            pt += __popcll(m & below) << bit;
-            wt += __popcll(m) << bit;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) { run_v += wsum[0][w]; run_t += wsum[1][w]; }
+                carry_v += wsum[0][w];
+                carry_t += wsum[1][w];
+            }
+            if (code != 0u) {
+                ActiveCell ac;
+                ac.cell = cell;
+                ac.code = code;
+                ac.vid0 = run_v;
+                ac.tri0 = run_t;
+                alist[(size_t)(a0 + e)] = ac;
+            }
         }
-        __syncthreads();   // wsum of the previous round has been read by everyone
-        if (lane == 0) { wsum[0][wave] = wv; wsum[1][wave] = wt; wsum[2][wave] = __popcll(am); }
-        __syncthreads();
-        int bv = 0, bt = 0, ba = 0, tv = 0, tt = 0, ta = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wave) { bv += wsum[0][w]; bt += wsum[1][w]; ba += wsum[2][w]; }
-            tv += wsum[0][w]; tt += wsum[1][w]; ta += wsum[2][w];
-        }
-        if (active) {
-            ActiveCell e;
-            e.cell = (unsigned)c;
-            e.code = code;
-            e.vid0 = run_v + bv + pv;
-            e.tri0 = run_t + bt + pt;
-            alist[(size_t)(run_a + ba + pa)] = e;
-        }
-        run_v += tv; run_t += tt; run_a += ta;
+        // (the next block's mc_scan_block starts with a barrier: wsum and the list are free by then)
     }
 }
 
@@ -718,14 +943,14 @@ using namespace surs::mc;
 static int mc_nblocks(long long ncells) { return (int)((ncells + CELLS_PER_BLOCK - 1) / CELLS_PER_BLOCK); }
 
 static size_t mc_ws_layout(int n0, int n1, int n2, size_t off[5]) {
-    const long long ncells = (long long)(n0 - 1) * (n1 - 1) * (n2 - 1);
-    const size_t nb = (size_t)mc_nblocks(ncells);
+    const size_t nb = (size_t)mc_nblocks((long long)(n0 - 1) * (n1 - 1) * ((n2 - 1 + 3) / 4 * 4));   // padded rows (mc_scan_block)
     const size_t nvox = (size_t)n0 * n1 * n2;
     size_t o = 0;
+    const size_t ng = (nb + SCAN_GROUP - 1) / SCAN_GROUP;
     off[0] = o; o += align_up(nb * sizeof(BlockSums), 256);         // block sums
-    off[1] = o; o += align_up(nb * sizeof(BlockSums), 256);         // block offsets
+    off[1] = o; o += align_up(nb * sizeof(BlockSums), 256);         // block offsets (local to their scan group)
     off[2] = o; o += 256 + align_up(nb * sizeof(float2), 256);      // min/max, totals; per-block min/max
-    off[3] = o; o += align_up((size_t)ncells * sizeof(unsigned), 256);   // cell codes
+    off[3] = o; o += 3 * align_up(ng * sizeof(BlockSums), 256);     // scan groups: totals, offsets, min/max
     off[4] = o; o += align_up(4 * nvox * sizeof(int), 256);         // edge -> vertex id tables
     return o;   // the active-cell list follows; its size is known after pass 2 (worst case: every cell)
 }
@@ -756,7 +981,20 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     d.cell_end = cell_end;
     d.base_verts = run->n_verts;
     d.base_faces = run->n_faces;
-    const int nb = mc_nblocks(cell_end - cell_begin);
+    // the classification passes walk padded rows (see mc_scan_block); ranges are whole layers, so they map to whole rows
+    d.prow = (d.cx + 3) / 4 * 4;
+    const long long per_layer = (long long)d.cy * d.cx;
+    SURS_REQUIRE(cell_begin % per_layer == 0 && cell_end % per_layer == 0, "cell range must consist of whole layers");
+    d.q_begin = cell_begin / d.cx * d.prow;
+    d.q_end = cell_end / d.cx * d.prow;
+    SURS_REQUIRE((long long)d.cz * d.cy * d.prow < (1ll << 32), "volume too large");
+    const int nb = mc_nblocks(d.q_end - d.q_begin);
+    static DeviceOnce fast_table;
+    if (fast_table.first()) {   // (host calls are sequential: the table is complete before any other stream can need it)
+        hipLaunchKernelGGL(mc_fast_init_kernel, dim3(1), dim3(256), 0, st);
+        SURS_LAUNCH_CHECK();
+        SURS_HIP_CHECK(hipStreamSynchronize(st));
+    }
     size_t off[5];
     const size_t fixed = mc_ws_layout(n0, n1, n2, off);
     char *ws = (char *)workspace;
@@ -765,14 +1003,22 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     float *minmax = (float *)(ws + off[2]);
     int *totals = (int *)(ws + off[2] + 16);
     float2 *bminmax = (float2 *)(ws + off[2] + 256);
-    unsigned *codes = (unsigned *)(ws + off[3]);
+    const int ng = (nb + SCAN_GROUP - 1) / SCAN_GROUP;
+    const size_t gstride = align_up((size_t)ng * sizeof(BlockSums), 256);
+    BlockSums *gcounts = (BlockSums *)(ws + off[3]);
+    BlockSums *goffs = (BlockSums *)(ws + off[3] + gstride);
+    float2 *gminmax = (float2 *)(ws + off[3] + 2 * gstride);
     int *evid = (int *)(ws + off[4]);
     ActiveCell *alist = (ActiveCell *)(ws + fixed);
 
-    hipLaunchKernelGGL(mc_classify_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, count_only ? (unsigned *)nullptr : codes,
-                       bcounts, bminmax);
+    // largest float <= level: for a float f, f > levelf  <=>  (double)f - level > 0 (how the core decides "inside")
+    float levelf = (float)level;
+    if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
+    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, levelf, bcounts, bminmax);
     SURS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, bcounts, boffs, nb, totals, bminmax, minmax);
+    hipLaunchKernelGGL(mc_scan1_kernel, dim3(ng), dim3(1024), 0, st, bcounts, boffs, nb, gcounts, bminmax, gminmax);
+    SURS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, gcounts, goffs, ng, totals, gminmax, minmax);
     SURS_LAUNCH_CHECK();
     struct { float mm[2]; unsigned pad[2]; int tot[3]; } host;
     SURS_HIP_CHECK(hipMemcpyAsync(&host, minmax, sizeof(host), hipMemcpyDeviceToHost, st));
@@ -785,7 +1031,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     if (count_only || nactive == 0) return 0;
     if (run->n_verts > cap_verts || run->n_faces > cap_faces)
         return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
-    hipLaunchKernelGGL(mc_compact_kernel, dim3(nb), dim3(THREADS), 0, st, codes, d, boffs, alist);
+    hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 4096 ? nb : 4096), dim3(THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs, goffs, alist);
     SURS_LAUNCH_CHECK();
     const int ab = ceil_div(nactive, THREADS);
     hipLaunchKernelGGL(mc_vertex_kernel, dim3(ab), dim3(THREADS), 0, st, vol, d, level, alist, nactive, evid, verts, normals,
