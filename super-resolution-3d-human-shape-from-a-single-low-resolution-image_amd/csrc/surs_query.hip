@@ -1145,7 +1145,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         SURS_LAUNCH_CHECK();
 #ifdef SURS_V3_TRACE
-        if (dtype != SURS_F32 && kver >= 3 && c0 == 0 && getenv("SURS_V3_TRACE")) {
+        if ((dtype == SURS_F32 || kver == 3 || kver == 4) && c0 == 0 && getenv("SURS_V3_TRACE")) {
             unsigned long long t[64];
             SURS_HIP_CHECK(hipStreamSynchronize(st));
             SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
@@ -1156,8 +1156,9 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             }
             fprintf(stderr, "v3 trace between MLPs: %llu\n", t[16] - t[9]);
             const double cyc = (double)(t[42] - t[40]), us = (double)(t[43] - t[41]) / 100.0;
-            fprintf(stderr, "v3 workgroup 0: %.0f cycles in %.1f us = %.3f GHz; %.0f cycles per 128-point tile\n", cyc, us,
-                    cyc / us * 1e-3, cyc / ((double)((nc + grid - 1) / grid) * ((rz + 127) / 128)));
+            const int tile = dtype == SURS_F32 ? 64 : 128;
+            fprintf(stderr, "workgroup 0: %.0f cycles in %.1f us = %.3f GHz; %.0f cycles per %d-point tile\n", cyc, us,
+                    cyc / us * 1e-3, cyc / ((double)((nc + grid - 1) / grid) * ((rz + tile - 1) / tile)), tile);
         }
 #endif
         if (prof) {
