@@ -56,15 +56,42 @@ def eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transfo
     calib = calib_tensor.to(dev)
     for s in range(0, total, num_samples):
         f = torch.arange(s, min(total, s + num_samples), device=dev, dtype=torch.int64)
-        i, j, k = (f // (R * R)).double(), ((f // R) % R).double(), (f % R).double()
-        pts = torch.stack([(((M[r, 0] * i + M[r, 1] * j) + M[r, 2] * k) + M[r, 3]) for r in range(3)]).float()
-        samples = pts.unsqueeze(0).repeat(net.num_views, 1, 1)
+        samples = _grid_points(M, f, R).unsqueeze(0).repeat(net.num_views, 1, 1)
         net.query_mr(samples, calib)
         net.query_sr(samples, calib)
         phr, plr = net.get_preds()
         vh[s:s + f.numel()] = phr[0, 0]
         vl[s:s + f.numel()] = plr[0, 0]
     return vh.view(R, R, R), vl.view(R, R, R), mat
+
+
+def _grid_points(M, f, R):
+    """float32 [3,n] world positions of the flat voxel indices f (int64 device tensor): np.matmul(coords_matrix, idx) in
+    float64, then .float(), exactly as create_grid + eval_func do (lib/sdf.py:22-26, lib/mesh_util.py:24)."""
+    i, j, k = (f // (R * R)).double(), ((f // R) % R).double(), (f % R).double()
+    return torch.stack([(((M[r, 0] * i + M[r, 1] * j) + M[r, 2] * k) + M[r, 3]) for r in range(3)]).float()
+
+
+def eval_volumes_octree_views(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, init_resolution=64):
+    """eval_grid_octree for num_views > 1 / the perspective projection: the same level walk on the device (selection,
+    scatter and cell pass are the single-view kernels - they only see the two fields), the lattice points evaluated by
+    eval_func's multi-view recipe (lib/mesh_util.py:20-28: points repeated per view, query_mr + query_sr, view 0 kept)."""
+    R = int(resolution)
+    _, mat = create_grid(R, R, R, b_min, b_max, transform=transform)
+    dev = net._device()
+    M = torch.from_numpy(np.asarray(mat, np.float64)).to(dev)
+    calib = calib_tensor.to(dev)
+
+    def evaluate(idx):
+        samples = _grid_points(M, idx, R).unsqueeze(0).repeat(net.num_views, 1, 1)
+        net.query_mr(samples, calib)
+        net.query_sr(samples, calib)
+        phr, plr = net.get_preds()
+        return phr[0, 0], plr[0, 0]
+
+    vh, vl = native.octree_volumes(R, mat[:3].reshape(-1), None, 0.0, 1.0, None, None, None, net._workspace(), opt.threshold,
+                                   init_resolution, evaluate=evaluate, device=dev)
+    return vh, vl, mat
 
 
 def eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, init_resolution=64, features=None):
@@ -170,13 +197,11 @@ def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_o
     """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy).
     features / after_enqueue: see reconstruction_streamed (single view only)."""
     if net.num_views > 1 or getattr(net, "projection_mode", "orthogonal") != "orthogonal":
-        # multi-view / perspective: always the dense sweep (the octree walk is only wired to the single-view kernels)
+        # multi-view / perspective: the per-point layer kernels (surs_query_points_views) behind the same two sweeps
         if use_octree:
-            import warnings
-            warnings.warn("reconstruction: use_octree is ignored for num_views > 1 / perspective - the grid is swept densely, so "
-                          "the result has neither the octree's interpolated blocks nor its shared-`dirty` artefact "
-                          "(lib/sdf.py:55-120)", stacklevel=2)
-        vh, vl, mat = eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+            vh, vl, mat = eval_volumes_octree_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+        else:
+            vh, vl, mat = eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
     elif use_octree:
         vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
         if after_enqueue is not None:

@@ -564,17 +564,20 @@ def transform_points(verts, mat):
 
 # ------------------------------------------------------------------ octree sweep (lib/sdf.py:55-120)
 
-def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, threshold, init_resolution=64, num_samples=None):
+def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, threshold, init_resolution=64, num_samples=None,
+                   evaluate=None, device=None):
     """eval_grid_octree on the device: float64 volumes (sdf_hr, sdf_lr) [R,R,R] like the reference's arrays.
-    Host code only walks the levels; selection, evaluation (fp32 kernels), scatter and the cell pass are kernels."""
-    dev = blob.device
+    Host code only walks the levels; selection, evaluation (fp32 kernels), scatter and the cell pass are kernels.
+    evaluate(idx int64 device tensor [n]) -> (pred_hr, pred_lr) float32 [n] replaces the single-view evaluator
+    (surs_query_grid_indexed): mesh_util passes the multi-view / perspective query there."""
+    dev = device if device is not None else blob.device
     n3 = R * R * R
     sdf_hr = torch.zeros(n3, dtype=torch.float64, device=dev)
     sdf_lr = torch.zeros(n3, dtype=torch.float64, device=dev)
     dirty = torch.ones(n3, dtype=torch.uint8, device=dev)
     cnt_dev = torch.zeros(1, dtype=torch.int32, device=dev)
     m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
-    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    cal = (C.c_float * 12)(*[float(v) for v in calib]) if evaluate is None else None
     reso = R // init_resolution
     batch = 262144
     while reso > 0:
@@ -586,9 +589,14 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
         n = cnt.value
         phr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
         plr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        w = ws.get(lib().surs_query_workspace_bytes(min(n, batch)))
+        w = ws.get(lib().surs_query_workspace_bytes(min(n, batch))) if evaluate is None else None
         for b0 in range(0, n, batch):
             nb = min(batch, n - b0)
+            if evaluate is not None:
+                a, b = evaluate(idx[b0:b0 + nb])
+                phr[b0:b0 + nb] = a
+                plr[b0:b0 + nb] = b
+                continue
             check(lib().surs_query_grid_indexed(C.c_void_p(idx.data_ptr() + 8 * b0), nb, R, R, m, cal, float(zmul), float(zdiv),
                                                 feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
                                                 _ptr(blob), _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * b0),

@@ -235,7 +235,7 @@ def test_multiview_facade_and_reconstruction(golden_dir):
     assert np.abs(plr[:, 0].cpu().numpy() - g["o2_pred_lr"]).max() < 1e-4
     # reconstruction: dense, fp32, view 0 kept
     R, b_min, b_max = 12, np.array([-0.5] * 3), np.array([0.5] * 3)
-    out = mesh_util.reconstruction(opt, net, torch.device("cuda:0"), calibs, R, b_min, b_max, use_octree=True)
+    out = mesh_util.reconstruction(opt, net, torch.device("cuda:0"), calibs, R, b_min, b_max, use_octree=False)
     gp = oracle.grid_points(R, b_min, b_max)
     o_hr, o_lr, _, _ = oracle.query_views(common.state_dict(), np.repeat(gp[None], V, 0), g["o2_calibs"], fl, fh)
     vh, vl, _ = mesh_util.eval_volumes_views(opt, net, calibs, R, b_min, b_max)
@@ -246,6 +246,40 @@ def test_multiview_facade_and_reconstruction(golden_dir):
         v, f, _, _ = oracle.marching_cubes_lewiner(field.cpu().numpy().astype(np.float64), 0.5)
         assert np.array_equal(f, f_got)
         assert np.allclose((np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T, v_got, atol=1e-6)
+
+
+def test_multiview_octree_vs_oracle(golden_dir):
+    """use_octree=True with num_views = 2: the reference's eval_grid_octree (lib/sdf.py:55-120) over eval_func's multi-view
+    recipe - the device level walk with the multi-view evaluator behind it - against the oracle's octree restatement
+    (bit-pinned to the reference's loop) over the oracle's multi-view query.  A flat / not-flat decision can flip where a
+    corner range is within 1e-6 of the threshold: allow 0.2 % of the voxels."""
+    import oracle
+    from surs_amd import mesh_util, model, options
+    V = 2
+    opt = options.BaseOptions().parse(common.FLAGS + ["--num_views", str(V), "--threshold", "0.05"])
+    net = model.SuRSNet(opt, "orthogonal").to(device=torch.device("cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    g = np.load(os.path.join(golden_dir, "query_views.npz"))
+    fl = np.stack([common.synth_features(seed=10 + v)[0] for v in range(V)])
+    fh = np.stack([common.synth_features(seed=10 + v)[1] for v in range(V)])
+    net.im_feat_list_lr = [torch.from_numpy(fl).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(fh).to("cuda:0")]
+    calibs = torch.from_numpy(g["o2_calibs"].copy())
+    R, init, b_min, b_max = 32, 8, np.array([-0.5] * 3), np.array([0.5] * 3)
+
+    def eval_func(pts):
+        hr, lr, _, _ = oracle.query_views(common.state_dict(), np.repeat(pts.astype(np.float32)[None], V, 0), g["o2_calibs"], fl, fh)
+        return hr[0], lr[0]
+
+    want_hr, want_lr = oracle.eval_grid_octree(R, b_min, b_max, eval_func, opt.threshold, init)
+    vh, vl, mat = mesh_util.eval_volumes_octree_views(opt, net, calibs, R, b_min, b_max, init_resolution=init)
+    for got, want in ((vh.cpu().numpy(), want_hr), (vl.cpu().numpy(), want_lr)):
+        assert got.dtype == np.float64 and got.shape == (R, R, R)
+        assert (np.abs(got - want) > 1e-4).mean() < 2e-3
+    # and through reconstruction(): use_octree is honoured for multi-view (it used to sweep densely)
+    out = mesh_util.reconstruction(opt, net, torch.device("cuda:0"), calibs, 64, b_min, b_max, use_octree=True)
+    assert len(out[0]) > 0 and out[1].dtype == np.int32
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
