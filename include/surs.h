@@ -49,10 +49,14 @@ enum {
     SURS_E_UNSUPPORTED = -3,
     SURS_E_LEVEL_RANGE = -4, /* marching cubes: level outside [min,max]  (skimage ValueError) */
     SURS_E_NO_SURFACE = -5,  /* marching cubes: no surface              (skimage RuntimeError) */
-    SURS_E_CAPACITY = -6     /* marching cubes: output buffers too small; counts are reported */
+    SURS_E_CAPACITY = -6,    /* marching cubes: output buffers too small; counts are reported */
+    SURS_E_NONFINITE = -7    /* marching cubes: the volume contains NaN (counts->vmin / vmax are NaN).  skimage would go on
+                                silently; here it is how an overflow of the fp32-grade sweep's f16 range surfaces */
 };
 
-enum { SURS_F32 = 0, SURS_BF16 = 1, SURS_F16 = 2 }; /* arithmetic of the dense MLP contractions */
+enum { SURS_F32 = 0, SURS_BF16 = 1, SURS_F16 = 2,  /* arithmetic of the dense MLP contractions */
+       SURS_F32_GEMM = 3 };  /* surs_query_grid only: fp32 on the per-point layer kernels (bf16 x 3 split operands: fp32's exponent
+                                range) even where the fp32-grade column kernel (f16 x 2 split: |activation| < 65504) applies */
 
 int surs_abi_version(void);
 const char *surs_last_error(void);
@@ -146,8 +150,10 @@ size_t surs_query_views_workspace_bytes(int max_points, int num_views);
  * p = float32( mat[:,0]*i + mat[:,1]*j + mat[:,2]*k + mat[:,3] )  (mat HOST [12] doubles = create_grid's
  * coords_matrix rows 0..2, evaluated in double like np.matmul on the float64 grid, then cast as eval_func does).
  * vol_hr / vol_lr: [(i1-i0)][ry][rz] fp32, z fastest (the flattening of lib/sdf.py:14-15,28).
- * dtype SURS_F32: same arithmetic as surs_query_points.  SURS_BF16 / SURS_F16: fused column kernel (requires the
- * projected X,Y not to depend on k, true for gen_mesh's calib; otherwise returns SURS_E_UNSUPPORTED). */
+ * dtype SURS_F32: fp32-grade results (logits within 1e-4 of the reference): on an axis-aligned orthographic sweep (the projected
+ * X, Y do not depend on k: true for gen_mesh's calib) the fused column kernel with split-f16 operands, otherwise - and for
+ * SURS_F32_GEMM - the arithmetic of surs_query_points.  SURS_BF16 / SURS_F16: the reduced-precision column kernel (axis-aligned
+ * sweeps only; otherwise returns SURS_E_UNSUPPORTED). */
 int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul, float zdiv,
                     const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,
                     int dtype, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr, void *stream);

@@ -10,8 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SURS_LIB_PATH") or os.path.join(_HERE, "libsurs_hip.so")   # override: timing experiments only
 _lib = None
 
-F32, BF16, F16 = 0, 1, 2
-DTYPES = {"fp32": F32, "bf16": BF16, "fp16": F16, "f16": F16}
+F32, BF16, F16, F32_GEMM = 0, 1, 2, 3
+DTYPES = {"fp32": F32, "bf16": BF16, "fp16": F16, "f16": F16, "fp32x": F32_GEMM}
 
 
 class SursError(RuntimeError):
@@ -26,6 +26,12 @@ class LevelRangeError(ValueError):
 
 class NoSurfaceError(RuntimeError):
     pass
+
+
+class NonFiniteVolumeError(FloatingPointError):
+    """The occupancy volume holds NaN values (marching cubes saw them).  With `--precision fp32` that is how an activation
+    beyond the f16 range of the fp32-grade column kernel surfaces; reconstruction() then repeats the sweep on the layer
+    kernels (fp32's exponent range)."""
 
 
 class McCounts(C.Structure):
@@ -106,4 +112,6 @@ def check(code):
         raise LevelRangeError("Surface level must be within volume data range.")
     if code == -5:
         raise NoSurfaceError("No surface found at the given iso value.")
+    if code == -7:
+        raise NonFiniteVolumeError("the occupancy volume contains NaN values")
     raise SursError(code, msg)

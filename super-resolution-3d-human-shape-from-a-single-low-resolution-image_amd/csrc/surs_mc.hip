@@ -424,7 +424,7 @@ __device__ __forceinline__ void decode_q(const Dims &d, long long q, int &x, int
 
 // phase 1 for the block starting at padded index q0: fills `list` (sweep order) and widens lo / hi by the block's voxels
 __device__ __forceinline__ void mc_scan_block(const float *__restrict__ vol, const Dims &d, float levelf, long long q0,
-                                              CellList &list, float &lo, float &hi) {
+                                              CellList &list, float &lo, float &hi, int *__restrict__ nan_flag = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long q = q0 + (long long)threadIdx.x * CELLS_PER_THREAD;
     unsigned idx[4] = {0, 0, 0, 0};
@@ -457,11 +457,15 @@ __device__ __forceinline__ void mc_scan_block(const float *__restrict__ vol, con
             for (int k = 0; k < 4; ++k) {
                 const bool use = k == 0 || (k == 1 && ylast) || (k == 2 && zlast) || (k == 3 && ylast && zlast);
                 if (use) {
+                    bool bad = false;
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
                         lo = fminf(lo, r[k][j]);
                         hi = fmaxf(hi, r[k][j]);
+                        bad |= r[k][j] != r[k][j];
                     }
+                    // fminf / fmaxf skip NaNs: report them (an overflowed f16 activation of the fp32-grade sweep shows up so)
+                    if (bad && nan_flag) atomicOr(nan_flag, 1);
                 }
             }
             unsigned in[4];   // bit j of in[k]: voxel j of row k is inside
@@ -530,13 +534,13 @@ __device__ __forceinline__ unsigned mc_classify_entry(const float *__restrict__ 
 
 __global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
                                                            BlockSums *__restrict__ block_counts,
-                                                           float2 *__restrict__ block_minmax) {
+                                                           float2 *__restrict__ block_minmax, int *__restrict__ nan_flag) {
     __shared__ CellList list;
     __shared__ int red[3][4];
     __shared__ float redf[2][4];
     const long long q0 = d.q_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
     float lo = FLT_MAX, hi = -FLT_MAX;
-    mc_scan_block(vol, d, levelf, q0, list, lo, hi);
+    mc_scan_block(vol, d, levelf, q0, list, lo, hi, nan_flag);
     int nt_sum = 0, nv_sum = 0, na_sum = 0;
     for (int e = threadIdx.x; e < list.n; e += THREADS) {
         unsigned cell;
@@ -1014,15 +1018,23 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     // largest float <= level: for a float f, f > levelf  <=>  (double)f - level > 0 (how the core decides "inside")
     float levelf = (float)level;
     if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
-    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, levelf, bcounts, bminmax);
+    int *nan_flag = totals + 3;
+    SURS_HIP_CHECK(hipMemsetAsync(nan_flag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, levelf, bcounts, bminmax, nan_flag);
     SURS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(ng), dim3(1024), 0, st, bcounts, boffs, nb, gcounts, bminmax, gminmax);
     SURS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, st, gcounts, goffs, ng, totals, gminmax, minmax);
     SURS_LAUNCH_CHECK();
-    struct { float mm[2]; unsigned pad[2]; int tot[3]; } host;
+    struct { float mm[2]; unsigned pad[2]; int tot[3]; int nan; } host;
     SURS_HIP_CHECK(hipMemcpyAsync(&host, minmax, sizeof(host), hipMemcpyDeviceToHost, st));
     SURS_HIP_CHECK(hipStreamSynchronize(st));
+    if (host.nan) {   // reported through the range: vmin = NaN (sticky: fminf(NaN, x) below would drop it)
+        run->vmin = NAN;
+        run->vmax = NAN;
+        return fail(SURS_E_NONFINITE, "the volume contains NaN values");
+    }
+    if (run->vmin != run->vmin) return fail(SURS_E_NONFINITE, "the volume contains NaN values");
     run->vmin = fminf(run->vmin, host.mm[0]);
     run->vmax = fmaxf(run->vmax, host.mm[1]);
     const int nactive = host.tot[2];

@@ -969,7 +969,7 @@ static size_t col_ws_bytes(long long ncb) {
 extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
     (void)ry; (void)rz;
     const size_t col = col_ws_bytes(COL_BATCH);
-    if (dtype == SURS_F32) {   // column kernel v5 where the sweep allows it, the layer kernels otherwise
+    if (dtype == SURS_F32 || dtype == SURS_F32_GEMM) {   // column kernel v5 where the sweep allows it, the layer kernels otherwise
         const size_t gen = fp32_ws_bytes(GRID_BATCH);
         return gen > col ? gen : col;
     }
@@ -1007,7 +1007,9 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                                float *vol_lr, void *stream) {
     SURS_REQUIRE(mat && calib && feat_lr && feat_hr && mlp_blob && workspace && vol_hr && vol_lr, "null argument");
     SURS_REQUIRE(i1 >= i0 && ry > 0 && rz > 0, "bad grid range");
-    SURS_REQUIRE(dtype == SURS_F32 || dtype == SURS_BF16 || dtype == SURS_F16, "unknown dtype %d", dtype);
+    SURS_REQUIRE(dtype == SURS_F32 || dtype == SURS_BF16 || dtype == SURS_F16 || dtype == SURS_F32_GEMM, "unknown dtype %d", dtype);
+    const bool force_gemm = dtype == SURS_F32_GEMM;
+    if (force_gemm) dtype = SURS_F32;
     SURS_REQUIRE(workspace_bytes >= surs_query_grid_workspace_bytes(ry, rz, dtype), "workspace too small");
     if (i1 == i0) return 0;
     hipStream_t st = as_stream(stream);
@@ -1026,7 +1028,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
     const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
     const bool columns = !(cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f);
 
-    if (dtype == SURS_F32 && !(columns && grid_f32_use_columns())) {
+    if (dtype == SURS_F32 && !(columns && grid_f32_use_columns() && !force_gemm)) {
         // general calibration: every voxel is its own point, the five layers are GEMMs on the split-bf16 layer kernels
         const long long total = (long long)(i1 - i0) * ry * rz;
         Fp32Workspace w = carve_fp32(workspace, GRID_BATCH);

@@ -178,25 +178,35 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
     if timing is not None:
         timing.record()
     # ---- extraction: layer by layer behind the sweep's launches (from the second reconstruction on), or in one piece
-    res = None
-    if streams is not None:
-        for b, ev in done[:-1]:
-            for s in streams:
-                s.advance(b - 1, after=ev)
-        res = [s.finish(after=halo_ev) for s in streams]
-        if any(r is None for r in res):
-            res = None
-        else:
-            runs = [s.run for s in streams]
-            tables = [s.w for s in streams]
-    if res is None:
-        torch.cuda.current_stream(dev).synchronize()
-        res, runs, tables = [], [], []
-        for k, v in zip(keys, vols):
-            world_v, faces, run, w = native.slab_mesh_one_piece(ws, k, v, m12, 0.5, i0)
-            res.append((world_v, faces))
-            runs.append(run)
-            tables.append(w)
+    res, nonfinite = None, False
+    try:
+        if streams is not None:
+            for b, ev in done[:-1]:
+                for s in streams:
+                    s.advance(b - 1, after=ev)
+            res = [s.finish(after=halo_ev) for s in streams]
+            if any(r is None for r in res):
+                res = None
+            else:
+                runs = [s.run for s in streams]
+                tables = [s.w for s in streams]
+        if res is None:
+            torch.cuda.current_stream(dev).synchronize()
+            res, runs, tables = [], [], []
+            for k, v in zip(keys, vols):
+                world_v, faces, run, w = native.slab_mesh_one_piece(ws, k, v, m12, 0.5, i0)
+                res.append((world_v, faces))
+                runs.append(run)
+                tables.append(w)
+    except native._lib.NonFiniteVolumeError:
+        nonfinite = True   # this rank's slab holds NaN: tell everybody through the counts (a lone raise would hang the others)
+    if nonfinite:
+        nan = float("nan")
+        counts = [(0, 0, nan, nan)] * 2
+        res = [(torch.empty((0, 3), dtype=torch.float64, device=dev), torch.empty((0, 3), dtype=torch.int32, device=dev))] * 2
+        tables = [None, None]
+    else:
+        counts = [(r.n_verts, r.n_faces, r.vmin, r.vmax) for r in runs]
     n0 = vols[0].shape[0]
 
     def top_ids(f):
@@ -209,7 +219,7 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
         native.check(native.lib().surs_mc_slab_fixup(native._ptr(faces), faces.shape[0], own_off, native._ptr(below), below_off,
                                                      native._stream()))
 
-    out = assemble_slab_meshes(res, [(r.n_verts, r.n_faces, r.vmin, r.vmax) for r in runs], top_ids, fixup, R, dev, dst, group)
+    out = assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst, group)
     if out is None:
         torch.cuda.current_stream(dev).synchronize()   # the sends have left before the buffers go back to the allocator
         return None
@@ -229,6 +239,10 @@ def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None,
     for c in counts:
         row += list(c)
     allc = all_gather_rows(row, dev, group)          # [world, 4 * nfields]
+    if np.isnan(allc).any():   # some rank's slab holds NaN values: every rank raises
+        from ._lib import NonFiniteVolumeError
+        raise NonFiniteVolumeError("the occupancy volume contains NaN values (rank(s) %s)" %
+                                   sorted(set(np.nonzero(np.isnan(allc))[0].tolist())))
     for f in range(nfields):
         lo, hi = allc[:, 4 * f + 2].min(), allc[:, 4 * f + 3].max()
         if level < lo or level > hi:

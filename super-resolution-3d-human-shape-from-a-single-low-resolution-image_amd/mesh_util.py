@@ -27,7 +27,7 @@ def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=Non
     zmul, zdiv = net._zscale()
     prec = precision or getattr(opt, "precision", "fp32")
     blob = net._mlp_blob()
-    if prec != "fp32" and native.DTYPES[prec] != net._core_dtype:
+    if prec not in ("fp32", "fp32x") and native.DTYPES[prec] != net._core_dtype:
         raise ValueError("network was packed for %s, reconstruction asked for %s: set opt.precision before loading" %
                          (net.precision, prec))
     try:
@@ -209,13 +209,26 @@ def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_o
     else:
         called = []
         hook = (lambda: (called.append(1), after_enqueue())) if after_enqueue is not None else None
-        out = reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform, want_normals, features=features,
-                                      after_enqueue=hook)
-        if out is not None:
-            return out
-        vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
-        if after_enqueue is not None and not called:
-            after_enqueue()
+        try:
+            out = reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform, want_normals, features=features,
+                                          after_enqueue=hook)
+            if out is not None:
+                return out
+            vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
+            if after_enqueue is not None and not called:
+                after_enqueue()
+            return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
+        except native._lib.NonFiniteVolumeError:
+            if getattr(opt, "precision", "fp32") != "fp32":
+                raise
+            # the fp32-grade column kernel carries its operands as two f16 parts: an activation beyond 65504 becomes inf and the
+            # field NaN.  The layer kernels (three bf16 parts: fp32's exponent range) give the same fp32-grade result, 4x slower.
+            import warnings
+            warnings.warn("reconstruction: the fp32-grade column kernel overflowed its f16 range (NaN occupancies); repeating the "
+                          "sweep on the per-point layer kernels", stacklevel=2)
+            if after_enqueue is not None and not called:
+                after_enqueue()
+            vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, precision="fp32x", features=features)
     return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
 
 

@@ -181,7 +181,7 @@ def pack_mlp(sd, dtype, device):
     wl, bl = arrs("mlp_lr.")
     wh, bh = arrs("mlp_hr.")
     code = DTYPES[dtype] if isinstance(dtype, str) else dtype
-    core = BF16 if code == F32 else code
+    core = BF16 if code in (F32, _lib.F32_GEMM) else code
     n = lib().surs_mlp_pack(wl, bl, wh, bh, core, None)
     host = np.zeros(n, np.uint8)
     lib().surs_mlp_pack(wl, bl, wh, bh, core, host.ctypes.data_as(C.c_void_p))

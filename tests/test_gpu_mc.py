@@ -83,3 +83,26 @@ def test_blob_digest_full_size(mc, n, golden_dir):
     assert _sha(f) == meta["faces_sha256"]
     assert _sha(v) == meta["verts_sha256"]
     assert _sha(val) == meta["values_sha256"]
+
+
+def test_nan_in_the_volume_is_reported():
+    """fminf / fmaxf skip NaNs, so a volume with NaN voxels would pass the level-range check and give a garbage mesh; the count
+    pass reports them (SURS_E_NONFINITE -> NonFiniteVolumeError).  That is how an overflow of the fp32-grade sweep's f16 range
+    surfaces; reconstruction() answers it by repeating the sweep on the layer kernels."""
+    import torch
+    from surs_amd import native
+    from surs_amd._lib import NonFiniteVolumeError
+    dev = native.require_gpu()
+    ws = native.Workspace(dev)
+    ax = torch.linspace(-1, 1, 40, device=dev)
+    z, y, x = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vol = (1.0 / (1.0 + torch.exp(8.0 * (torch.sqrt(x * x + y * y + z * z) - 0.6)))).contiguous()
+    v, f, _, _ = native.marching_cubes_lewiner(vol, 0.5, ws)
+    assert len(v) > 100
+    for where in ((0, 0, 0), (39, 39, 39), (17, 5, 39), (20, 20, 20)):
+        bad = vol.clone()
+        bad[where] = float("nan")
+        with pytest.raises(NonFiniteVolumeError):
+            native.marching_cubes_lewiner(bad, 0.5, native.Workspace(dev))
+    v2, f2, _, _ = native.marching_cubes_lewiner(vol, 0.5, ws)     # the workspace is usable afterwards
+    assert torch.equal(v, v2) and torch.equal(f, f2)

@@ -248,6 +248,41 @@ def test_multiview_facade_and_reconstruction(golden_dir):
         assert np.allclose((np.matmul(mat[:3, :3], v.T) + mat[:3, 3:4]).T, v_got, atol=1e-6)
 
 
+def test_fp32_sweep_falls_back_when_f16_range_overflows():
+    """The fp32-grade column kernel carries operands as two f16 parts: activations beyond 65504 overflow.  With weights scaled so
+    that they do, reconstruction() must notice (NaN occupancies reported by marching cubes), warn, and return the result of the
+    layer kernels (bf16 x 3 split: fp32's range) - the same meshes as forcing those kernels from the start."""
+    import warnings
+    from surs_amd import mesh_util, model
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v.copy()) for k, v in common.state_dict().items()}
+    for m in ("mlp_lr.", "mlp_hr."):      # layer-0 outputs x 4e5, compensated in layer 1: same function, huge hidden activations
+        sd[m + "conv0.weight"] *= 4e5
+        sd[m + "conv0.bias"] *= 4e5
+        sd[m + "conv1.weight"] /= 4e5
+    net = model.SuRSNet(common.opt()).to(device=dev)
+    net.load_state_dict(sd)
+    net.eval()
+    fl, fh = common.synth_features()
+    net.im_feat_list_lr = [torch.from_numpy(fl[None]).to(dev)]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None]).to(dev)]
+    calib = torch.from_numpy(common.CALIB[None].copy())
+    R, b_min, b_max = 40, np.array([-0.5] * 3), np.array([0.5] * 3)
+    vh, vl, mat = mesh_util.eval_volumes(common.opt(), net, calib, R, b_min, b_max, precision="fp32x")
+    want = mesh_util.meshes_from_volumes(net, [vh, vl], mat, want_normals=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = mesh_util.reconstruction(common.opt(), net, dev, calib, R, b_min, b_max, use_octree=False, want_normals=False)
+    assert any("f16 range" in str(x.message) for x in w)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[5], want[5])
+    # the second reconstruction of a workspace takes the streamed path (extraction beside the sweep): same answer
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = mesh_util.reconstruction(common.opt(), net, dev, calib, R, b_min, b_max, use_octree=False, want_normals=False)
+    assert any("f16 range" in str(x.message) for x in w)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[5], want[5])
+
+
 def test_multiview_octree_vs_oracle(golden_dir):
     """use_octree=True with num_views = 2: the reference's eval_grid_octree (lib/sdf.py:55-120) over eval_func's multi-view
     recipe - the device level walk with the multi-view evaluator behind it - against the oracle's octree restatement
