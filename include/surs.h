@@ -119,6 +119,12 @@ int surs_nhwc_to_nchw(const float *x, int c, int h, int w, int x_ld, float *y, v
 size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], const float *const w_hr[5],
                      const float *const b_hr[5], int dtype, void *blob);
 
+/* How the fp32 point path (surs_query_points, _views, surs_query_grid_indexed, the general-calibration sweep) carries its fp32
+ * operands through the bf16 / f16 matrix pipe, process-wide: 2 = two f16 parts, three products per MAC (default: 1.6x the
+ * rate, 22 significant bits, |activation| and |feature| < 65504), 3 = three bf16 parts, six products (24 bits, fp32's exponent
+ * range), 0 = back to the default (or the SURS_SPLIT environment variable).  Both meet the 1e-4 logit tolerance. */
+int surs_set_operand_split(int parts);
+
 /* bytes of device workspace the two query entry points need for `max_points` points per call / grid batch */
 size_t surs_query_workspace_bytes(int max_points);
 

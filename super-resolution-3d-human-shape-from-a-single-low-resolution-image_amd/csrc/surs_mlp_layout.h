@@ -68,7 +68,11 @@ struct MlpBlobHeader {
     // fp32-grade column kernel (v5): the dense cores as TWO f16 parts per weight (hi = f16(w), lo = f16(w - hi)), 1 KiB
     // A fragments of the 32x32x16 shape in the order the waves stream them: per MLP, per layer, [k-step][row tile][part][64 lanes][8]
     uint32_t corex;
-    uint32_t pad[1];
+    // fp32 path with TWO f16 parts per operand (hi + lo, three products per MAC): the k-major matrices wt[m][l] and wc once
+    // more, [2 parts][Kpad / 16][M / 32][2][32][8] uint16 (f16) in MFMA A-fragment order
+    uint32_t wt2[2][4];
+    uint32_t wc2;
+    uint32_t pad[4];
 };
 static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 constexpr uint32_t MLP_MAGIC = 0x53525553u;
@@ -104,6 +108,9 @@ inline MlpBlobHeader blob_layout(uint32_t dtype) {
         for (int l = 0; l < 4; ++l) h.wt3[m][l] = take((size_t)kpad[l] * mout[l] * 6);
     h.wc3 = take((size_t)C_G * CC_PAD * 6);
     h.corex = take((size_t)2 * X_F_MLP * 1024);
+    for (int m = 0; m < 2; ++m)
+        for (int l = 0; l < 4; ++l) h.wt2[m][l] = take((size_t)kpad[l] * mout[l] * 4);
+    h.wc2 = take((size_t)C_G * CC_PAD * 4);
     h.total_bytes = (uint32_t)off;
     return h;
 }

@@ -204,6 +204,26 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
                 split_kmajor((const float *)(base + h.wt[m][l]), kpad[l], mout[l], (uint16_t *)(base + h.wt3[m][l]));
         split_kmajor((const float *)(base + h.wc), C_G, CC_PAD, (uint16_t *)(base + h.wc3));
     }
+    // ---- the k-major fp32 matrices as TWO f16 parts in the same A-operand order (the default split of the fp32 point path)
+    {
+        auto split_kmajor2 = [&](const float *wt, int kpad, int M, uint16_t *out) {
+            const size_t per_part = (size_t)kpad * M;
+            for (int k = 0; k < kpad; ++k)
+                for (int o = 0; o < M; ++o) {
+                    const float w = wt[(size_t)k * M + o];
+                    const size_t idx = ((((size_t)(k / 16) * (M / 32) + o / 32) * 2 + ((k >> 3) & 1)) * 32 + (o & 31)) * 8 + (k & 7);
+                    const uint16_t hi = f32_to_f16(w);
+                    out[idx] = hi;
+                    out[per_part + idx] = f32_to_f16(w - f16_to_f32(hi));
+                }
+        };
+        const int mout[4] = {D1, D2, D3, D4};
+        const int kpad[4] = {C0PAD, D1, D2 + C0PAD, D3 + C0PAD};
+        for (int m = 0; m < 2; ++m)
+            for (int l = 0; l < 4; ++l)
+                split_kmajor2((const float *)(base + h.wt[m][l]), kpad[l], mout[l], (uint16_t *)(base + h.wt2[m][l]));
+        split_kmajor2((const float *)(base + h.wc), C_G, CC_PAD, (uint16_t *)(base + h.wc2));
+    }
     // ---- the dense cores as two f16 parts per weight (hi + lo), A fragments [k-step][row tile][part][lane][8]: the
     //      fp32-grade column kernel (v5) multiplies hi*hi + hi*lo + lo*hi.  Same k order inside a k-step as `core`.
     {

@@ -97,18 +97,22 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned short &a, unsigned
     c = __builtin_bit_cast(unsigned short, hc);
 }
 
+#include "surs_gemm.inc"
+
 // ------------------------------------------------------------------------------------------------
 // gather: F[c][n] for c < 320 (bilinear, zeros padding, align_corners=True), F[320][n] = z_feat,
 //         F[321][n] = 0 (p_lr slot), mask[n] = in_img, zproj[n] = projected Z (for the column kernel: Z at k = 0)
 // One workgroup = 64 points; wave w gathers points 16w..16w+15 with lanes = channels (coalesced 256 B per
 // tap), transposes through LDS and stores with lanes = points (coalesced).
 // ------------------------------------------------------------------------------------------------
+template <int NP>
 __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long n, const float *__restrict__ feat_lr,
                                                      int hl, int wl, const float *__restrict__ feat_hr, int hh,
                                                      int wh, float *__restrict__ F, long long ldf,
                                                      float *__restrict__ mask, float *__restrict__ zproj,
                                                      unsigned short *__restrict__ Fs, long long fs_part) {
-    // Fs (optional): the split image of F for the split-bf16 layer kernels, [3][C0PAD/16][ldf][16], fs_part = part stride
+    // Fs (optional): the split image of F for the split-operand layer kernels, [NP][C0PAD/16][ldf][16], fs_part = part stride
+    // (NP = 3: bf16 parts, NP = 2: f16 parts - SplitKind in surs_gemm.inc)
     __shared__ float tile[64][65];
     __shared__ float sx[64], sy[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,10 +137,10 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
             F[(long long)C_G * ldf + t] = Z * src.zmul / src.zdiv;
             F[(long long)(C_G + 1) * ldf + t] = 0.0f;
             if (Fs) {   // k-tile 20 = rows 320..335: z, the p_lr slot (mlp_last_kernel fills it), zero padding
-                unsigned short zp[3];
-                split3_bf16(Z * src.zmul / src.zdiv, zp[0], zp[1], zp[2]);
+                unsigned short zp[NP];
+                SplitKind<NP>::split(Z * src.zmul / src.zdiv, zp);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     u16x8_t v = {zp[p], 0, 0, 0, 0, 0, 0, 0}, z = {0, 0, 0, 0, 0, 0, 0, 0};
                     u16x8_t *dst = reinterpret_cast<u16x8_t *>(Fs + p * fs_part + ((long long)(C_G / 16) * ldf + t) * 16);
                     dst[0] = v;
@@ -200,18 +204,18 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int item = tid + 256 * it, p = item & 63, half = (item >> 6) & 1, ktl = item >> 7;
-                u16x8_t q0, q1, q2;
+                u16x8_t q[NP];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    unsigned short a, b, c;
-                    split3_bf16(tile[ktl * 16 + half * 8 + j][p], a, b, c);
-                    q0[j] = a; q1[j] = b; q2[j] = c;
+                    unsigned short parts[NP];
+                    SplitKind<NP>::split(tile[ktl * 16 + half * 8 + j][p], parts);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) q[k][j] = parts[k];
                 }
                 if (n0 + p < n) {
                     unsigned short *dst = Fs + ((long long)(cbase / 16 + ktl) * ldf + n0 + p) * 16 + half * 8;
-                    *reinterpret_cast<u16x8_t *>(dst) = q0;
-                    *reinterpret_cast<u16x8_t *>(dst + fs_part) = q1;
-                    *reinterpret_cast<u16x8_t *>(dst + 2 * fs_part) = q2;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) *reinterpret_cast<u16x8_t *>(dst + k * fs_part) = q[k];
                 }
             }
         }
@@ -219,10 +223,9 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
     }
 }
 
-#include "surs_gemm.inc"
-
 // last layer (Cout = 1) + sigmoid * mask.  One thread per point, coalesced over points.
 //   logit = b4 + w4[0:128].Y3[:,n] + w4[128:128+336].F[:,n];  pred = mask * sigmoid(logit)
+template <int NP>
 __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__ w4,
                                                        const float *__restrict__ Y3, const float *__restrict__ F,
                                                        long long ld, long long n, const float *__restrict__ mask,
@@ -239,12 +242,11 @@ __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__
     if (logit) logit[t] = acc;
     if (p_slot) p_slot[t] = p;
     if (Fs) {   // row 321 of the split image of F
-        unsigned short a, b, c;
-        split3_bf16(p, a, b, c);
+        unsigned short parts[NP];
+        SplitKind<NP>::split(p, parts);
         unsigned short *dst = Fs + ((long long)(C_G / 16) * ld + t) * 16 + 1;
-        dst[0] = a;
-        dst[fs_part] = b;
-        dst[2 * fs_part] = c;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) dst[k * fs_part] = parts[k];
     }
 }
 
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256) void mean_views_kernel(const float *__restrict
 }
 
 // fp32 k-major X[16 * ktiles][ld] -> its split image [3][ktiles][ld][16] (the view means of the multi-view path)
+template <int NP>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, long long ld, int ktiles,
                                                          unsigned short *__restrict__ Xs, long long part) {
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -266,22 +269,23 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     if (n >= ld) return;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        u16x8_t q0, q1, q2;
+        u16x8_t q[NP];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            unsigned short a, b, c;
-            split3_bf16(X[(long long)(16 * kt + 8 * half + j) * ld + n], a, b, c);
-            q0[j] = a; q1[j] = b; q2[j] = c;
+            unsigned short parts[NP];
+            SplitKind<NP>::split(X[(long long)(16 * kt + 8 * half + j) * ld + n], parts);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) q[k][j] = parts[k];
         }
         unsigned short *dst = Xs + ((long long)kt * ld + n) * 16 + half * 8;
-        *reinterpret_cast<u16x8_t *>(dst) = q0;
-        *reinterpret_cast<u16x8_t *>(dst + part) = q1;
-        *reinterpret_cast<u16x8_t *>(dst + 2 * part) = q2;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<u16x8_t *>(dst + k * part) = q[k];
     }
 }
 
 // multi-view last layer: one logit per point from the view means; every view gets it under its own in-image mask
 // (SuRSNet.py:156,183: `in_img[:, None].float() * mlp(...)` broadcasts the [1,1,N] prediction over the V masks)
+template <int NP>
 __global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__restrict__ w4, const float *__restrict__ Y3,
                                                              const float *__restrict__ Fm, long long ld, long long n,
                                                              int nviews, const float *__restrict__ mask /*[V][ld]*/,
@@ -301,13 +305,12 @@ __global__ __launch_bounds__(256) void mlp_last_views_kernel(const float *__rest
         const float p = mask[(long long)v * ld + t] * y;
         pred[(long long)v * n + t] = p;
         if (p_slot) p_slot[(long long)v * f_view_stride + t] = p;
-        if (Fs) {   // a view's split image follows the previous view's three parts
-            unsigned short a, b, c;
-            split3_bf16(p, a, b, c);
-            unsigned short *dst = Fs + (long long)v * 3 * fs_part + ((long long)(C_G / 16) * ld + t) * 16 + 1;
-            dst[0] = a;
-            dst[fs_part] = b;
-            dst[2 * fs_part] = c;
+        if (Fs) {   // a view's split image follows the previous view's parts
+            unsigned short parts[NP];
+            SplitKind<NP>::split(p, parts);
+            unsigned short *dst = Fs + (long long)v * NP * fs_part + ((long long)(C_G / 16) * ld + t) * 16 + 1;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) dst[k * fs_part] = parts[k];
         }
     }
 }
@@ -384,10 +387,28 @@ static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const v
     return 0;
 }
 
+// Operand split of the 256-point layer kernels (SplitKind): two f16 parts (default: three products per MAC, 4 bytes per value;
+// |x| < 65504) or, with SURS_SPLIT=bf16x3, three bf16 parts (six products, 6 bytes, fp32's exponent range).  The older layer
+// kernels (SURS_GEMM_BIG=0 / SURS_GEMM_X3=0) only know the bf16 form.
+static int g_split_override = 0;   // surs_set_operand_split
+static int split_parts() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SURS_SPLIT");
+        v = (e && e[0] == 'b') ? 3 : 2;
+    }
+    const int want = g_split_override ? g_split_override : v;
+    return (gemm_use_x3() && gemm_use_big()) ? want : 3;
+}
+
 // the 256-point layer kernels need more than 64 KB of dynamic LDS
 static int g3_set_attributes() {
     static DeviceOnce attr;
     if (attr.first()) {
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_SPLIT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 2)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 2)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128, 2)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32_T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128, 2)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<16, 256, G3_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
@@ -398,11 +419,29 @@ static int g3_set_attributes() {
 }
 
 static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned short *X1s, int K1, const unsigned short *X2s,
-                         int K2, const float *bias, float *Y, unsigned short *Ys, long long np) {
+                         int K2, const float *bias, float *Y, unsigned short *Ys, long long np, int parts = 3) {
     SplitSeg s1 = {X1s, (long long)K1 * np, K1 / 16}, s2 = {X2s, (long long)K2 * np, K2 / 16};
     const int nblocks = (int)(np / 128);
     dim3 grid(gemm_grid(M / 128, nblocks));
     const unsigned short *w3 = (const unsigned short *)W3;
+    if (parts == 2) {   // two f16 parts: the 256-point kernels only
+        SURS_REQUIRE(np % 256 == 0 && (M % 256 == 0 || !Ys), "f16 x 2 layer kernels need 256-point tiles");
+        int rca = g3_set_attributes();
+        if (rca) return rca;
+        const int nb256 = (int)(np / 256);
+        const long long yp = (long long)M * np;
+        if (Ys)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_SPLIT, 2>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256, 2), st,
+                               w3, M, K1 + K2, s1, s2, np, bias, (float *)nullptr, 0LL, Ys, yp, nb256);
+        else if (M % 256 == 0)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32, 2>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256, 2), st,
+                               w3, M, K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
+        else
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32, 2>), dim3(gemm_grid(M / 128, nb256)), dim3(512), g3_lds_bytes(128, 2), st,
+                               w3, M, K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
+        SURS_LAUNCH_CHECK();
+        return 0;
+    }
     if (np % 256 == 0 && gemm_use_big() && (M % 256 == 0 || !Ys)) {
         // 256-point tiles: 256 rows per workgroup where M allows, else 128 (fp32 output only: the last hidden layer)
         int rca = g3_set_attributes();
@@ -447,37 +486,49 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
 // runs gather + both MLPs for `n` points described by src; outputs may be offset pointers
 static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, const float *feat_lr, int hl, int wl,
                            const float *feat_hr, int hh, int wh, const char *blob, const MlpBlobHeader &h,
-                           const Fp32Workspace &w, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr) {
+                           const Fp32Workspace &w, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr,
+                           int parts = 0) {
     const long long np = w.np;
     const bool x3 = gemm_use_x3();
+    if (parts == 0) parts = split_parts();
     unsigned short *Fs = x3 ? w.Fs : nullptr;
     const long long fs_part = (long long)C0PAD * np;
     // rows 322..335 of F meet zero weights and must be finite: the caller zeroes them once (zero_pad_rows; the split
     // image gets them from gather_kernel); rows < 322 are fully written for t < n; columns n..np-1 only feed outputs
     // that are never read
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
-                       hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
+    if (parts == 2)
+        hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
+                           hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
+    else
+        hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
+                           hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
     SURS_LAUNCH_CHECK();
     for (int m = 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
-        auto W3 = [&](int l) { return (const void *)(blob + h.wt3[m][l]); };
+        auto W3 = [&](int l) { return (const void *)(blob + (parts == 2 ? h.wt2[m][l] : h.wt3[m][l])); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
         if (x3) {
-            if ((rc = launch_gemm_s(st, W3(0), D1, Fs, C0PAD, nullptr, 0, BI(0), nullptr, w.Y0s, np))) return rc;
-            if ((rc = launch_gemm_s(st, W3(1), D2, w.Y0s, D1, nullptr, 0, BI(1), nullptr, w.Y1s, np))) return rc;
-            if ((rc = launch_gemm_s(st, W3(2), D3, w.Y1s, D2, Fs, C0PAD, BI(2), nullptr, w.Y2s, np))) return rc;
-            if ((rc = launch_gemm_s(st, W3(3), D4, w.Y2s, D3, Fs, C0PAD, BI(3), w.Y3, nullptr, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(0), D1, Fs, C0PAD, nullptr, 0, BI(0), nullptr, w.Y0s, np, parts))) return rc;
+            if ((rc = launch_gemm_s(st, W3(1), D2, w.Y0s, D1, nullptr, 0, BI(1), nullptr, w.Y1s, np, parts))) return rc;
+            if ((rc = launch_gemm_s(st, W3(2), D3, w.Y1s, D2, Fs, C0PAD, BI(2), nullptr, w.Y2s, np, parts))) return rc;
+            if ((rc = launch_gemm_s(st, W3(3), D4, w.Y2s, D3, Fs, C0PAD, BI(3), w.Y3, nullptr, np, parts))) return rc;
         } else {
             if ((rc = launch_gemm(st, false, WT(0), nullptr, D1, w.F, C0PAD, np, nullptr, 0, 0, BI(0), 1, w.Y0, np, np))) return rc;
             if ((rc = launch_gemm(st, false, WT(1), nullptr, D2, w.Y0, D1, np, nullptr, 0, 0, BI(1), 1, w.Y1, np, np))) return rc;
             if ((rc = launch_gemm(st, false, WT(2), nullptr, D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
             if ((rc = launch_gemm(st, false, WT(3), nullptr, D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
         }
-        hipLaunchKernelGGL(mlp_last_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
-                           (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
-                           m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr,
-                           m == 0 ? Fs : (unsigned short *)nullptr, fs_part);
+        if (parts == 2)
+            hipLaunchKernelGGL(mlp_last_kernel<2>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
+                               m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr,
+                               m == 0 ? Fs : (unsigned short *)nullptr, fs_part);
+        else
+            hipLaunchKernelGGL(mlp_last_kernel<3>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
+                               m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr,
+                               m == 0 ? Fs : (unsigned short *)nullptr, fs_part);
         SURS_LAUNCH_CHECK();
     }
     return 0;
@@ -763,6 +814,12 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
     return 0;
 }
 
+extern "C" int surs_set_operand_split(int parts) {
+    SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "parts: 0 (default / SURS_SPLIT), 2 (f16 x 2) or 3 (bf16 x 3)");
+    g_split_override = parts;
+    return 0;
+}
+
 extern "C" size_t surs_query_workspace_bytes(int max_points) {
     long long np = (long long)ceil_div(max_points, 256) * 256;
     return fp32_ws_bytes(np);
@@ -841,8 +898,9 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
     float *Y2m = p;    p += (size_t)D3 * np;
     const long long fstride = (long long)C0PAD * np;
     const bool x3 = gemm_use_x3();
+    const int parts = split_parts();
     unsigned short *q = (unsigned short *)p;
-    unsigned short *Fs = q;   q += (size_t)V * 3 * fstride;   // [V][3][C0PAD/16][np][16]
+    unsigned short *Fs = q;   q += (size_t)V * 3 * fstride;   // [V][parts][C0PAD/16][np][16] (sized for three parts)
     unsigned short *Y0s = q;  q += (size_t)3 * D1 * np;
     unsigned short *Y1s = q;  q += (size_t)3 * D2 * np;
     unsigned short *Y2ms = q; q += (size_t)3 * D3 * np;
@@ -858,22 +916,27 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
         src.ld = n;
         src.persp = projection;
         fill_calib(src, calibs + 12 * v, zmul, zdiv);
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
-                           feat_lr + (size_t)v * hl * wl * C_LR, hl, wl, feat_hr + (size_t)v * hh * wh * C_HR, hh, wh, Fv, np,
-                           mask + (size_t)v * np, (float *)nullptr, x3 ? Fs + (size_t)v * 3 * fstride : (unsigned short *)nullptr,
-                           fstride);
+        unsigned short *Fsv = x3 ? Fs + (size_t)v * parts * fstride : (unsigned short *)nullptr;
+        if (parts == 2)
+            hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
+                               feat_lr + (size_t)v * hl * wl * C_LR, hl, wl, feat_hr + (size_t)v * hh * wh * C_HR, hh, wh, Fv, np,
+                               mask + (size_t)v * np, (float *)nullptr, Fsv, fstride);
+        else
+            hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
+                               feat_lr + (size_t)v * hl * wl * C_LR, hl, wl, feat_hr + (size_t)v * hh * wh * C_HR, hh, wh, Fv, np,
+                               mask + (size_t)v * np, (float *)nullptr, Fsv, fstride);
         SURS_LAUNCH_CHECK();
     }
     for (int m = 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
-        auto W3 = [&](int l) { return (const void *)(blob + h.wt3[m][l]); };
+        auto W3 = [&](int l) { return (const void *)(blob + (parts == 2 ? h.wt2[m][l] : h.wt3[m][l])); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
         for (int v = 0; v < V && x3; ++v) {   // split images between the layers, fp32 out of layer 2 for the mean
-            const unsigned short *Fsv = Fs + (size_t)v * 3 * fstride;
-            if ((rc = launch_gemm_s(st, W3(0), D1, Fsv, C0PAD, nullptr, 0, BI(0), nullptr, Y0s, np))) return rc;
-            if ((rc = launch_gemm_s(st, W3(1), D2, Y0s, D1, nullptr, 0, BI(1), nullptr, Y1s, np))) return rc;
-            if ((rc = launch_gemm_s(st, W3(2), D3, Y1s, D2, Fsv, C0PAD, BI(2), Y2 + (size_t)v * D3 * np, nullptr, np))) return rc;
+            const unsigned short *Fsv = Fs + (size_t)v * parts * fstride;
+            if ((rc = launch_gemm_s(st, W3(0), D1, Fsv, C0PAD, nullptr, 0, BI(0), nullptr, Y0s, np, parts))) return rc;
+            if ((rc = launch_gemm_s(st, W3(1), D2, Y0s, D1, nullptr, 0, BI(1), nullptr, Y1s, np, parts))) return rc;
+            if ((rc = launch_gemm_s(st, W3(2), D3, Y1s, D2, Fsv, C0PAD, BI(2), Y2 + (size_t)v * D3 * np, nullptr, np, parts))) return rc;
         }
         for (int v = 0; v < V && !x3; ++v) {
             const float *Fv = F + (size_t)v * fstride;
@@ -891,19 +954,31 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
                            inv, Fm);
         SURS_LAUNCH_CHECK();
         if (x3) {
-            hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)ceil_div(np, 256), D3 / 16), dim3(256), 0, st, Y2m, np, D3 / 16,
-                               Y2ms, (long long)D3 * np);
+            if (parts == 2) {
+                hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)ceil_div(np, 256), D3 / 16), dim3(256), 0, st, Y2m, np, D3 / 16,
+                                   Y2ms, (long long)D3 * np);
+                hipLaunchKernelGGL(split_rows_kernel<2>, dim3((unsigned)ceil_div(np, 256), C0PAD / 16), dim3(256), 0, st, Fm, np,
+                                   C0PAD / 16, Fms, fstride);
+            } else {
+                hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)ceil_div(np, 256), D3 / 16), dim3(256), 0, st, Y2m, np, D3 / 16,
+                                   Y2ms, (long long)D3 * np);
+                hipLaunchKernelGGL(split_rows_kernel<3>, dim3((unsigned)ceil_div(np, 256), C0PAD / 16), dim3(256), 0, st, Fm, np,
+                                   C0PAD / 16, Fms, fstride);
+            }
             SURS_LAUNCH_CHECK();
-            hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)ceil_div(np, 256), C0PAD / 16), dim3(256), 0, st, Fm, np,
-                               C0PAD / 16, Fms, fstride);
-            SURS_LAUNCH_CHECK();
-            if ((rc = launch_gemm_s(st, W3(3), D4, Y2ms, D3, Fms, C0PAD, BI(3), Y3, nullptr, np))) return rc;
+            if ((rc = launch_gemm_s(st, W3(3), D4, Y2ms, D3, Fms, C0PAD, BI(3), Y3, nullptr, np, parts))) return rc;
         } else if ((rc = launch_gemm(st, false, WT(3), W3(3), D4, Y2m, D3, np, Fm, C0PAD, np, BI(3), 1, Y3, np, np)))
             return rc;
-        hipLaunchKernelGGL(mlp_last_views_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
-                           (const float *)(blob + h.w4[m]), Y3, Fm, np, (long long)n, V, mask, m == 0 ? pred_lr : pred_hr,
-                           m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride,
-                           (m == 0 && x3) ? Fs : (unsigned short *)nullptr, fstride);
+        if (parts == 2)
+            hipLaunchKernelGGL(mlp_last_views_kernel<2>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               (const float *)(blob + h.w4[m]), Y3, Fm, np, (long long)n, V, mask, m == 0 ? pred_lr : pred_hr,
+                               m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride,
+                               (m == 0 && x3) ? Fs : (unsigned short *)nullptr, fstride);
+        else
+            hipLaunchKernelGGL(mlp_last_views_kernel<3>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               (const float *)(blob + h.w4[m]), Y3, Fm, np, (long long)n, V, mask, m == 0 ? pred_lr : pred_hr,
+                               m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride,
+                               (m == 0 && x3) ? Fs : (unsigned short *)nullptr, fstride);
         SURS_LAUNCH_CHECK();
     }
     return 0;
@@ -1037,8 +1112,9 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         for (long long b0 = 0; b0 < total; b0 += GRID_BATCH) {
             const long long nb = (total - b0 < GRID_BATCH) ? total - b0 : GRID_BATCH;
             src.base = (long long)i0 * ry * rz + b0;
+            // SURS_F32_GEMM is asked for when the f16 range does not suffice: three bf16 parts
             rc = run_points_fp32(st, src, nb, feat_lr, hl, wl, feat_hr, hh, wh, blob, h, w, vol_hr + b0, vol_lr + b0,
-                                 nullptr, nullptr);
+                                 nullptr, nullptr, force_gemm ? 3 : 0);
             if (rc) return rc;
         }
         return 0;
@@ -1075,18 +1151,28 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         // column constants CC[col][2944] = Wc^T F[:, col] + bc: the split-bf16 layer kernel in its transposed-output form
         // on the split image of F (SURS_GEMM_X3=0 / SURS_GEMM_BIG=0: the older kernels on the fp32 F)
         const bool split = gemm_use_x3() && gemm_use_big();
+        const int parts = split_parts();
         unsigned short *Fs = (unsigned short *)(cmask + COL_BATCH);
         const long long fs_part = (long long)C0PAD * COL_BATCH;
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
-                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
+        if (parts == 2)
+            hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+                               feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
+        else
+            hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+                               feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
         SURS_LAUNCH_CHECK();
         if (split) {
             if ((rc = g3_set_attributes())) return rc;
             SplitSeg s1 = {Fs, fs_part, C_G / 16}, s2 = {nullptr, 0, 0};
             const int nb256 = (int)(ncp / 256);
-            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128),
-                               st, (const unsigned short *)(blob + h.wc3), CC_PAD, C_G, s1, s2, COL_BATCH,
-                               (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
+            if (parts == 2)
+                hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T, 2>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128, 2),
+                                   st, (const unsigned short *)(blob + h.wc2), CC_PAD, C_G, s1, s2, COL_BATCH,
+                                   (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
+            else
+                hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128),
+                                   st, (const unsigned short *)(blob + h.wc3), CC_PAD, C_G, s1, s2, COL_BATCH,
+                                   (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
             SURS_LAUNCH_CHECK();
         } else {
             rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,

@@ -224,16 +224,19 @@ def test_channel_split_kernels_match_point_split_kernel(tmp_path):
 
 
 def test_layer_kernel_generations_agree(tmp_path):
-    """The fp32 point path has three layer-kernel generations behind environment switches: fp32 MFMA (SURS_GEMM_X3=0),
-    split-bf16 128x128 (SURS_GEMM_BIG=0), split-bf16 256x256 LDS-DMA with 8 (default) or 16 waves.  The split-bf16 kernels
-    accumulate the same six products per k step in the same order, so they agree bit for bit; against the fp32-MFMA kernel
-    the logits differ by summation order and the 24-bit operand split: <= 2e-5."""
+    """The fp32 point path has several layer-kernel generations behind environment switches: the 256x256 LDS-DMA kernel with
+    two f16 parts per operand (default) or three bf16 parts (SURS_SPLIT=bf16x3; 8 or 16 waves), the split-bf16 128x128 kernel
+    (SURS_GEMM_BIG=0) and the fp32-MFMA kernel (SURS_GEMM_X3=0).  The split-bf16 kernels accumulate the same six products per
+    k step in the same order, so they agree bit for bit; across operand splits and against the fp32-MFMA kernel the logits
+    differ by summation order and the 22- / 24-bit operand split: <= 2e-5."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    ref = str(tmp_path / "default.npz")
-    for name, extra, mode in (("default", {}, "save"), ("small", {"SURS_GEMM_BIG": "0"}, "cmp"),
-                              ("waves16", {"SURS_GEMM_WAVES": "16"}, "cmp"), ("f32", {"SURS_GEMM_X3": "0"}, "cmp")):
+    ref = str(tmp_path / "bf16x3.npz")
+    b3 = {"SURS_SPLIT": "bf16x3"}
+    for name, extra, mode in (("bf16x3", b3, "save"), ("small", dict(b3, SURS_GEMM_BIG="0"), "cmp"),
+                              ("waves16", dict(b3, SURS_GEMM_WAVES="16"), "cmp"), ("f32", {"SURS_GEMM_X3": "0"}, "cmp"),
+                              ("f16x2", {}, "cmp")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_points_cmp.py"), mode, ref],
                            env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -245,7 +248,10 @@ def test_layer_kernel_generations_agree(tmp_path):
             d, eq = float(l.split("=")[1].split()[0]), l.rstrip().endswith("equal=1")
             # (the sweep's column constants go through the same kernels; behind them sits the bf16 column kernel, which
             #  rounds the layer-0 activations to bf16: a constant that differs in the last fp32 bit can flip one of those)
-            assert eq if name != "f32" else d <= (2e-5 if not l.startswith("grid_") else 2e-3), (name, l)
+            if name in ("small", "waves16"):
+                assert eq, (name, l)
+            else:
+                assert d <= (2e-5 if not l.startswith("grid_") else 2e-3), (name, l)
 
 
 def test_multiview_and_perspective_vs_reference(setup, golden_dir):
