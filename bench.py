@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip config.fp32_mode and config.precision_acceptance (N=1)")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "slab"],
                     help="N>1 only: one subject per GPU (weak) or one subject split into x-slabs, meshes extracted per slab (strong)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: nccl = RCCL, one rank per GPU (the measured configuration); gloo = host-staged exchange, ranks may share "
+                         "a GPU (LOCAL_RANK modulo the device count) - lets the N>1 code paths run on a single-GPU box (tests)")
     ap.add_argument("--image", default="noise", choices=["smooth", "noise"],
                     help="synthetic input: white noise x mask (SURVEY 8d, default) or band-limited; with random-init weights both give a noise-like field")
     args = ap.parse_args()
@@ -69,11 +72,16 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
                          (args.gpus, world, args.gpus))
+    if args.backend == "gloo":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     R = args.resolution
     flags = ["--loadSize", "1024", "--residual", "--b_min", "-0.5", "-0.5", "-0.5", "--b_max", "0.5", "0.5", "0.5",
@@ -140,7 +148,7 @@ def main():
         lib.surs_profile_read(C.byref(launches), C.byref(kms), C.byref(kpts))
         lib.surs_profile_enable(0)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         k_avg_ms = kms.value / max(launches.value, 1.0)
@@ -273,7 +281,8 @@ def main():
                                     ", x-slab per rank, marching cubes per slab, meshes to rank 0" if slab else ""),
                        "resolution": R, "image": IMG, "image_kind": args.image, "queries_per_step": int(queries),
                        "reconstruction_s": ms_per_step / 1e3, "stage_ms_rank0": stage_ms,
-                       "mesh": last, "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world)},
+                       "mesh": last, "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world),
+                       "backend": None if world == 1 else args.backend},
             "roofline": roofline(args.precision, k_avg_ms, k_pts),
         }
         out["config"].update(extras)
