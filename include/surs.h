@@ -82,6 +82,13 @@ int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_ld, const v
                         float slope, const float *residual, int res_ld, void *stream);
 /* HOST helper for it: [3 parts][k*k][cin_pad/16][cout_pad][16] uint16 (bf16).  Returns bytes (query with out == NULL). */
 size_t surs_conv_pack_weights_x3(const float *w, int cout, int cin, int ksize, void *out);
+/* The same convolution with every operand as TWO f16 parts (hi + lo) and three products per MAC: half the matrix work of the
+ * three-part form, 22 significant bits, operands below 65504 in magnitude; the encoder's default.  wsplit:
+ * surs_conv_pack_weights_x2 layout ([2 parts][k*k][cin_pad/16][cout_pad][16] uint16, f16). */
+int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias, float *y,
+                        int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
+                        float slope, const float *residual, int res_ld, void *stream);
+size_t surs_conv_pack_weights_x2(const float *w, int cout, int cin, int ksize, void *out);
 /* HOST helper: repack a PyTorch [cout][cin][k][k] weight into the kernel layout [k*k][cin_pad][cout_pad] (floats).
  * Returns the number of floats written (query with out == NULL). */
 size_t surs_conv_pack_weights(const float *w, int cout, int cin, int ksize, float *out);

@@ -56,6 +56,8 @@ _SIGS = {
     "surs_nhwc_to_nchw": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "surs_conv2d_nhwc_x3": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),
     "surs_conv_pack_weights_x3": (_sz, [_vp, _i, _i, _i, _vp]),
+    "surs_conv2d_nhwc_x2": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),
+    "surs_conv_pack_weights_x2": (_sz, [_vp, _i, _i, _i, _vp]),
     "surs_mlp_pack": (_sz, [_vp, _vp, _vp, _vp, _i, _vp]),
     "surs_set_operand_split": (C.c_int, [_i]),
     "surs_query_workspace_bytes": (_sz, [_i]),

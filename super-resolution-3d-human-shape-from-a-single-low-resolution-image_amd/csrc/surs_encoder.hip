@@ -207,22 +207,44 @@ __device__ __forceinline__ void split3(float x, unsigned short &a, unsigned shor
     c = __builtin_bit_cast(unsigned short, hc);
 }
 
+// Operand split of the 3x3 kernel: NP = 3 bf16 parts (six products per MAC, fp32's exponent range) or NP = 2 f16 parts
+// (hi = f16(x), lo = f16(x - hi); products hi*hi + hi*lo + lo*hi: half the MFMA work, 22 significant bits, |x| < 65504 - the
+// split of the fp32-grade column kernel).  Both pass the encoder's 1e-4 parity tests; two parts is the default.
+template <int NP> struct ConvSplit;
+template <> struct ConvSplit<3> {
+    typedef bf16x8 vec8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void split(float x, unsigned short (&p)[3]) { split3(x, p[0], p[1], p[2]); }
+};
+template <> struct ConvSplit<2> {
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void split(float x, unsigned short (&p)[2]) {
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);
+        p[0] = __builtin_bit_cast(unsigned short, hi);
+        p[1] = __builtin_bit_cast(unsigned short, lo);
+    }
+};
+
 #ifdef SURS_CONV_TRACE
 __device__ unsigned long long g_conv_trace[8];
 #define CSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); g_conv_trace[i] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
-template <int KS, int STRIDE, int TR, int NT3>
+template <int KS, int STRIDE, int TR, int NT3, int NP>
 __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
+    typedef ConvSplit<NP> CS;
+    typedef typename CS::vec8 vec8;
     constexpr int NJ = NT3 / 32;   // 32-channel MFMA column tiles per wave
     constexpr int PAD = KS / 2, T = KS * KS;
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
     constexpr int RPW = TR / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
-    unsigned short *xs = lds16;                         // [3][PR*PC][XS]
-    unsigned short *wsm = lds16 + 3 * PR * PC * XS;     // [3][T][NT3][XS]
-    float *gn = reinterpret_cast<float *>(wsm + 3 * T * NT3 * XS);   // [2][cin_pad]: GroupNorm scale, shift (if any)
+    unsigned short *xs = lds16;                         // [NP][PR*PC][XS]
+    unsigned short *wsm = lds16 + NP * PR * PC * XS;    // [NP][T][NT3][XS]
+    float *gn = reinterpret_cast<float *>(wsm + NP * T * NT3 * XS);   // [2][cin_pad]: GroupNorm scale, shift (if any)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ox0 = blockIdx.x * TC, oy0 = blockIdx.y * TR, n0 = blockIdx.z * NT3;
     const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD;
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     // A chunk's MFMAs take ~1.7 k cycles, less than a global-memory round trip: the next chunk's patch and weight
     // slices are fetched into registers while the current chunk multiplies, and split / stored to LDS afterwards.
     constexpr int NPI = (PR * PC * (CK / 4) + 255) / 256;   // patch items per thread (4 channels of one pixel each)
-    constexpr int NWI = (3 * T * NT3 * 2 + 255) / 256;      // weight items per thread (16 bytes each)
+    constexpr int NWI = (NP * T * NT3 * 2 + 255) / 256;     // weight items per thread (16 bytes each)
     // chunks in flight: the small tile's MFMAs (1.7 k cycles) are shorter than a memory round trip -> two; the big tile's
     // (7 k cycles) cover it, and a second buffer (80 more registers) would spill
     constexpr int PD = (RPW * NJ >= 4) ? 1 : 2;
@@ -289,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         const int item = tid + k * 256;
         w_src[k] = 0;
         w_dst[k] = -1;
-        if (item < 3 * T * NT3 * 2) {
+        if (item < NP * T * NT3 * 2) {
             const int half = item & 1, row = item >> 1;            // row = (part*T + tap)*NT3 + n
             const int n = row % NT3, pt = row / NT3;               // pt = part*T + tap
             const int part = pt / T, tap = pt - part * T;
@@ -314,19 +336,19 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
         for (int k = 0; k < NPI; ++k) {
             if (px_dst[k] < 0) continue;
-            u16x4 p0, p1, p2;
+            u16x4 pp[NP];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = pre_x[pb][k][q];
                 if (a.in_scale) v = fmaxf(v * sc[q] + sh[q], 0.f);
                 v = px_ok[k] ? v : 0.f;   // zero padding is applied after the norm
-                unsigned short x0, x1, x2;
-                split3(v, x0, x1, x2);
-                p0[q] = x0; p1[q] = x1; p2[q] = x2;
+                unsigned short parts[NP];
+                CS::split(v, parts);
+#pragma unroll
+                for (int e = 0; e < NP; ++e) pp[e][q] = parts[e];
             }
-            *reinterpret_cast<u16x4 *>(xs + 0 * PR * PC * XS + px_dst[k]) = p0;
-            *reinterpret_cast<u16x4 *>(xs + 1 * PR * PC * XS + px_dst[k]) = p1;
-            *reinterpret_cast<u16x4 *>(xs + 2 * PR * PC * XS + px_dst[k]) = p2;
+#pragma unroll
+            for (int e = 0; e < NP; ++e) *reinterpret_cast<u16x4 *>(xs + e * PR * PC * XS + px_dst[k]) = pp[e];
         }
 #pragma unroll
         for (int k = 0; k < NWI; ++k) {
@@ -352,20 +374,20 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         const int kh = lane >> 5, li = lane & 31;
         // operands of tap t + 1 are read from LDS while tap t multiplies (register double buffer): without it every tap
         // starts with an exposed LDS round trip
-        bf16x8 bw[2][NJ][3], ax[2][RPW][3];
+        vec8 bw[2][NJ][NP], ax[2][RPW][NP];
         auto ldtap = [&](int tap, int buf) {
             const int ky = tap / KS, kx = tap - ky * KS;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bw[buf][j][p] = *reinterpret_cast<const bf16x8 *>(wsm + ((size_t)(p * T + tap) * NT3 + j * 32 + li) * XS + 8 * kh);
+                for (int p = 0; p < NP; ++p)
+                    bw[buf][j][p] = *reinterpret_cast<const vec8 *>(wsm + ((size_t)(p * T + tap) * NT3 + j * 32 + li) * XS + 8 * kh);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int prow = (wave * RPW + r) * STRIDE + ky, pcol = li * STRIDE + kx;
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    ax[buf][r][p] = *reinterpret_cast<const bf16x8 *>(xs + ((size_t)p * PR * PC + prow * PC + pcol) * XS + 8 * kh);
+                for (int p = 0; p < NP; ++p)
+                    ax[buf][r][p] = *reinterpret_cast<const vec8 *>(xs + ((size_t)p * PR * PC + prow * PC + pcol) * XS + 8 * kh);
             }
         };
         ldtap(0, 0);
@@ -374,15 +396,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             const int cur = tap & 1;
             if (tap + 1 < T) ldtap(tap + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);   // the next tap's reads are in flight before this tap's MFMAs start
-            // the six partial products, smallest first: (x part, w part)
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            // the partial products that matter, smallest first: (x part, w part); six of three parts, three of two
+            constexpr int NPROD = NP == 3 ? 6 : 3;
+            constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < NPROD; ++t)
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[t % NA][r][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[cur][r][PA[t]], bw[cur][j][PB[t]], acc[t % NA][r][j], 0, 0, 0);
+                        acc[t % NA][r][j] = CS::mfma(ax[cur][r][PA[t]], bw[cur][j][PB[t]], acc[t % NA][r][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
         CSTAMP(3);
@@ -419,16 +442,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     }
 }
 
-template <int KS, int STRIDE, int TR, int NT3>
+template <int KS, int STRIDE, int TR, int NT3, int NP>
 static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
-    SURS_REQUIRE(a.cin_pad <= 1024, "split-bf16 convolution: at most 1024 input channels");
-    const size_t lds = (size_t)(3 * PR * PC * XS + 3 * KS * KS * NT3 * XS) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
+    SURS_REQUIRE(a.cin_pad <= 1024, "split-operand convolution: at most 1024 input channels");
+    const size_t lds = (size_t)(NP * PR * PC * XS + NP * KS * KS * NT3 * XS) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
     static DeviceOnce attr;
     if (attr.first())
-        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), ceil_div(a.cout_pad, NT3));
-    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3>), grid, dim3(256), lds, st, a, wsplit);
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3, NP>), grid, dim3(256), lds, st, a, wsplit);
     SURS_LAUNCH_CHECK();
 #ifdef SURS_CONV_TRACE
     if (getenv("SURS_CONV_TRACE") && a.cin == 256 && a.cout == 128) {
@@ -445,11 +468,11 @@ static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, h
 // 8 rows x 64 channels (140 KB of LDS, one workgroup per CU, 216 MFMAs per wave and chunk: long enough to cover the
 // prefetch, and the input is re-read least) where that still gives every CU two workgroups' worth of tiles; 4 rows x 32
 // channels (79 KB, two workgroups per CU) for the small maps.
-template <int KS, int STRIDE>
+template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     const long long wg_big = (long long)ceil_div(a.wo, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64);
-    if (wg_big >= 512) return launch_conv_x3_cfg<KS, STRIDE, 8, 64>(a, wsplit, st);
-    return launch_conv_x3_cfg<KS, STRIDE, 4, 32>(a, wsplit, st);
+    if (wg_big >= 512) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
+    return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
 // ---------------------------------------------------------------- GroupNorm coefficients
@@ -667,7 +690,29 @@ extern "C" int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.act = act; a.slope = slope;
     a.res = residual; a.res_ld = res_ld;
-    return launch_conv_x3<3, 1>(a, (const unsigned short *)wsplit, as_stream(stream));
+    return launch_conv_x3<3, 1, 3>(a, (const unsigned short *)wsplit, as_stream(stream));
+}
+
+extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                                   float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
+                                   const float *in_shift, int act, float slope, const float *residual, int res_ld,
+                                   void *stream) {
+    SURS_REQUIRE(x && wsplit && y, "null argument");
+    SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
+    SURS_REQUIRE(ksize == 3 && stride == 1, "the split-bf16 kernel is built for 3x3, stride 1");
+    SURS_REQUIRE(cin % 16 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0,
+                 "the split-bf16 kernel needs cin %% 16 == 0 and 16-byte aligned pixels");
+    SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
+    SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
+    ConvArgs a;
+    a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
+    a.wp = nullptr; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
+    a.bias = bias;
+    a.y = y; a.ho = h; a.wo = w; a.cout = cout; a.y_ld = y_ld;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    a.act = act; a.slope = slope;
+    a.res = residual; a.res_ld = res_ld;
+    return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
 extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,

@@ -308,3 +308,24 @@ extern "C" size_t surs_conv_pack_weights_x3(const float *w, int cout, int cin, i
             }
     return bytes;
 }
+
+// The same layout with TWO f16 parts per weight (hi = f16(w), lo = f16(w - hi)) for surs_conv2d_nhwc_x2:
+// [2 parts][k*k taps][cin_pad / 16 chunks][cout_pad][16 channels of the chunk] uint16.
+extern "C" size_t surs_conv_pack_weights_x2(const float *w, int cout, int cin, int ksize, void *out) {
+    const int cin_pad = (cin + 15) / 16 * 16, cout_pad = (cout + 63) / 64 * 64, taps = ksize * ksize, nch = cin_pad / 16;
+    const size_t per_part = (size_t)taps * nch * cout_pad * 16;
+    const size_t bytes = 2 * per_part * sizeof(uint16_t);
+    if (!out) return bytes;
+    uint16_t *o = (uint16_t *)out;
+    memset(o, 0, bytes);
+    for (int oc = 0; oc < cout; ++oc)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < taps; ++t) {
+                const float v = w[((size_t)oc * cin + c) * taps + t];
+                const size_t idx = (((size_t)t * nch + c / 16) * cout_pad + oc) * 16 + (c & 15);
+                const uint16_t hi = f32_to_f16(v);
+                o[idx] = hi;
+                o[per_part + idx] = f32_to_f16(v - f16_to_f32(hi));
+            }
+    return bytes;
+}

@@ -88,11 +88,14 @@ class ConvWeights:
                                      packed.ctypes.data_as(C.c_void_p))
         self.w = torch.from_numpy(packed).to(device)
         self.b = torch.from_numpy(np.ascontiguousarray(b, np.float32)).to(device) if b is not None else None
-        self.w3 = None    # split-bf16 image for the 3x3 / stride-1 kernel (surs_conv2d_nhwc_x3)
+        # split image for the 3x3 / stride-1 kernel: two f16 parts (surs_conv2d_nhwc_x2, default) or, with SURS_CONV_SPLIT=bf16x3,
+        # three bf16 parts (surs_conv2d_nhwc_x3: fp32's exponent range); SURS_CONV_X3=0: neither (fp32 MFMA kernel)
+        self.w3, self.parts = None, 3 if os.environ.get("SURS_CONV_SPLIT", "f16x2").startswith("b") else 2
         if self.k == 3 and os.environ.get("SURS_CONV_X3", "1") != "0":
-            nb = lib().surs_conv_pack_weights_x3(None, self.cout, self.cin, self.k, None)
+            pack = lib().surs_conv_pack_weights_x3 if self.parts == 3 else lib().surs_conv_pack_weights_x2
+            nb = pack(None, self.cout, self.cin, self.k, None)
             buf = np.empty(nb, np.uint8)
-            lib().surs_conv_pack_weights_x3(w.ctypes.data_as(C.c_void_p), self.cout, self.cin, self.k, buf.ctypes.data_as(C.c_void_p))
+            pack(w.ctypes.data_as(C.c_void_p), self.cout, self.cin, self.k, buf.ctypes.data_as(C.c_void_p))
             self.w3 = torch.from_numpy(buf).to(device)
 
 
@@ -104,7 +107,7 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
         out = Img(ho, wo, cw.cout, device=x.buf.device)
     assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
     x3 = cw.w3 is not None and stride == 1 and x.c % 16 == 0 and x.ld % 4 == 0 and (x.buf.data_ptr() + 4 * x.off) % 16 == 0
-    fn, wt = (lib().surs_conv2d_nhwc_x3, cw.w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
+    fn, wt = ((lib().surs_conv2d_nhwc_x3 if cw.parts == 3 else lib().surs_conv2d_nhwc_x2), cw.w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
     check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
              residual.ptr() if residual is not None else None,
