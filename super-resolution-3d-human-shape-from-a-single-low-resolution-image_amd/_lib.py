@@ -96,6 +96,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libsurs_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(or make -C %s/csrc)" % _HERE)
+        # PyTorch first: its wheel carries its own HIP runtime (libamdhip64), and the library must bind to THAT copy - loaded
+        # before torch, it would pull in /opt/rocm's, torch would then run on a second runtime in the same process, and the first
+        # kernel launch fails with "no ROCm-capable device is detected" (seen with build() and smoke() in one process)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the library misses a declared entry point

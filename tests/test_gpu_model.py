@@ -118,6 +118,8 @@ def test_query_facade_vs_reference(net, golden_dir):
     assert np.abs(plr.detach().cpu().numpy()[0, 0] - g["a_pred_lr"]).max() < 1e-4
     with pytest.raises(NotImplementedError):
         net.query_sr(pts + 1.0, calib)
+    net.query_sr(pts.clone(), calib)          # another tensor holding the same points is fine (compared by value)
+    assert np.array_equal(net.get_preds()[0].cpu().numpy(), phr.cpu().numpy())
 
 
 @pytest.mark.parametrize("R", [32, 48])
@@ -388,3 +390,15 @@ def test_streamed_reconstruction_full_size():
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("streamed == one piece") == 2, r.stdout
+
+
+def test_graft_entry_build_and_smoke_in_one_process():
+    """__graft_entry__.build() followed by smoke() in the SAME interpreter (the library gets loaded before anything has
+    initialised the GPU: it must still bind to PyTorch's HIP runtime), and smoke() on its own."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for code in ("import __graft_entry__ as g; g.build(); g.smoke()", "import __graft_entry__ as g; g.smoke()"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "smoke ok" in r.stdout
