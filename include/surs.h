@@ -132,6 +132,10 @@ size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], con
  * range), 0 = back to the default (or the SURS_SPLIT environment variable).  Both meet the 1e-4 logit tolerance. */
 int surs_set_operand_split(int parts);
 
+/* Reduced-precision column kernel of surs_query_grid: 0 = default (or the SURS_GRID_KERNEL environment variable), 1-4, 7
+ * (DESIGN.md section 4.1).  A/B comparisons and regression tests; process-wide. */
+int surs_set_grid_kernel(int version);
+
 /* bytes of device workspace the two query entry points need for `max_points` points per call / grid batch */
 size_t surs_query_workspace_bytes(int max_points);
 

@@ -251,6 +251,14 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
             }
         }
     }
+    // ---- layer-1 weights channel-major (column kernel v7)
+    {
+        uint16_t *wt = (uint16_t *)(base + h.w1t);
+        auto cvt = [&](float f) { return dtype == SURS_F16 ? f32_to_f16(f) : f32_to_bf16(f); };
+        for (int m = 0; m < 2; ++m)
+            for (int c = 0; c < D1; ++c)
+                for (int r = 0; r < D2; ++r) wt[((size_t)m * D1 + c) * D2 + r] = cvt(W[m][1][(size_t)r * D1 + c]);
+    }
     // ---- layer-1 biases as A fragments (three exact 16-bit parts in k-slots 0..2 of lanes 0..31)
     {
         uint16_t *bf = (uint16_t *)(base + h.b1frag);

@@ -563,6 +563,9 @@ struct GridArgs {
     const char *core16;    // the same cores in 16x16x32 fragment order (kernel v4)
     const char *corex;     // the same cores as two f16 parts per weight (kernel v5, fp32-grade)
     const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
+    const char *w1t;       // layer-1 weights channel-major (kernel v7)
+    const float *rr_lr, *rr_hr;   // per column: RA, RB [512] (lr) / RA, RB, RC [512] (hr): kernel v7's affine part of layer 1
+    float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
     int ncols, rz;
@@ -801,6 +804,56 @@ __global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
 #include "surs_grid_v3.inc"
 #include "surs_grid_v4.inc"
 #include "surs_grid_v5.inc"
+#include "surs_grid_v7.inc"
+
+// Column kernel v7's per-column affine part, step 1: the vectors g . a0, g . w0z (lr) and g . a0, g . w0z, g . w0p (hr) of a
+// column batch as the split image [parts][1024 / 16][nvec * ncp][16] that the layer GEMM kernel reads as its point operand
+// (point index = column * nvec + vector).  g_c = 1 or 0.01: the LeakyReLU branch of channel c at mid column (the same
+// expression as in grid_mlp_v7).  Thread = (column, group of 16 channels).
+template <int NP>
+__global__ __launch_bounds__(256) void colsum_prepare_kernel(const float *__restrict__ cc, const float *__restrict__ zvec, int ncp,
+                                                             float zmid, unsigned short *__restrict__ g_lr, long long part_lr,
+                                                             unsigned short *__restrict__ g_hr, long long part_hr) {
+    typedef SplitKind<NP> SK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int c16 = blockIdx.y * 4 + wave;
+    if (col >= ncp) return;
+    const float *row = cc + (size_t)col * CC_PAD + 16 * c16;
+    unsigned o[5][NP][8];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = 16 * c16 + j;
+        const float a0l = row[j], a0h = row[CC_A0_HR + j];
+        const float wzl = zvec[ZV_W0Z_LR + c], wzh = zvec[ZV_W0Z_HR + c], wph = zvec[ZV_W0P_HR + c];
+        const float gl = fmaf(zmid, wzl, a0l) > 0.0f ? 1.0f : 0.01f;
+        const float gh = fmaf(0.5f, wph, fmaf(zmid, wzh, a0h)) > 0.0f ? 1.0f : 0.01f;
+        const float val[5] = {gl * a0l, gl * wzl, gh * a0h, gh * wzh, gh * wph};
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            unsigned short p[NP];
+            SK::split(val[v], p);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (j & 1) o[v][q][j >> 1] |= (unsigned)p[q] << 16;
+                else o[v][q][j >> 1] = p[q];
+            }
+        }
+    }
+    const long long np_lr = 2LL * ncp, np_hr = 3LL * ncp;
+#pragma unroll
+    for (int v = 0; v < 5; ++v) {
+        unsigned short *dst = v < 2 ? g_lr + ((long long)c16 * np_lr + 2LL * col + v) * 16
+                                    : g_hr + ((long long)c16 * np_hr + 3LL * col + (v - 2)) * 16;
+        const long long part = v < 2 ? part_lr : part_hr;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            u32x4 w0 = {o[v][q][0], o[v][q][1], o[v][q][2], o[v][q][3]}, w1 = {o[v][q][4], o[v][q][5], o[v][q][6], o[v][q][7]};
+            *reinterpret_cast<u32x4 *>(dst + q * part) = w0;
+            *reinterpret_cast<u32x4 *>(dst + q * part + 8) = w1;
+        }
+    }
+}
 
 }  // namespace surs
 
@@ -811,6 +864,13 @@ using namespace surs;
 // ------------------------------------------------------------------------------------------------
 static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
     SURS_HIP_CHECK(hipMemsetAsync(w.F + (size_t)(C_G + 2) * w.np, 0, (size_t)(C0PAD - C_G - 2) * w.np * sizeof(float), st));
+    return 0;
+}
+
+static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
+extern "C" int surs_set_grid_kernel(int version) {
+    SURS_REQUIRE(version == 0 || (version >= 1 && version <= 4) || version == 7, "column kernel: 0 (default / SURS_GRID_KERNEL), 1-4 or 7");
+    g_grid_kernel_override = version;
     return 0;
 }
 
@@ -1036,10 +1096,13 @@ static const long long GRID_BATCH = 65536;
 #endif
 static const long long COL_BATCH = SURS_COL_BATCH;
 
-static size_t col_ws_bytes(long long ncb) {
+static size_t col_base_bytes(long long ncb) {
     // F rows 0..335 for the column gather + CC + mask
     return (size_t)ncb * (C0PAD + CC_PAD + 1) * sizeof(float) + (size_t)ncb * C0PAD * 6 + 4096;   // + split image of F
 }
+// column kernel v7: split images of the five g-scaled vectors per column (up to three parts), the five R vectors, a zero bias
+static size_t col_v7_bytes(long long ncb) { return (size_t)ncb * 5 * D1 * 6 + (size_t)ncb * 5 * D2 * 4 + D2 * 4; }
+static size_t col_ws_bytes(long long ncb) { return col_base_bytes(ncb) + col_v7_bytes(ncb); }
 
 extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
     (void)ry; (void)rz;
@@ -1073,6 +1136,8 @@ static int grid_set_attributes() {
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, GRID5_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     return 0;
 }
 
@@ -1137,11 +1202,12 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
     // +1 %); 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.
     // 1 and 2 are bit-identical and kept as the regression reference of 3, which differs from them only in the
     // summation order of the final 128-term dot product.  SURS_F32: kernel v5 (split-f16 operands, fp32-grade).
-    static int kver = -1;
-    if (kver < 0) {
+    static int kver_env = -1;
+    if (kver_env < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
-        kver = (e && e[0] >= '1' && e[0] <= '4') ? (e[0] - '0') : 3;
+        kver_env = (e && ((e[0] >= '1' && e[0] <= '4') || e[0] == '7')) ? (e[0] - '0') : 3;
     }
+    const int kver = g_grid_kernel_override ? g_grid_kernel_override : kver_env;
     if ((rc = grid_set_attributes())) return rc;
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
@@ -1188,6 +1254,49 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.corex = blob + h.corex;
         a.b1frag = blob + h.b1frag;
         a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
+        a.w1t = blob + h.w1t;
+        a.rr_lr = a.rr_hr = nullptr;
+        a.zmid = 0.0f;
+        if (kver == 7 && dtype != SURS_F32) {
+            // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
+            if ((rc = g3_set_attributes())) return rc;
+            char *v7 = (char *)workspace + col_base_bytes(COL_BATCH);
+            unsigned short *g_lr = (unsigned short *)v7, *g_hr = g_lr + (size_t)COL_BATCH * 2 * D1 * 3;
+            float *r_lr = (float *)(g_hr + (size_t)COL_BATCH * 3 * D1 * 3), *r_hr = r_lr + (size_t)COL_BATCH * 2 * D2;
+            float *zero_bias = r_hr + (size_t)COL_BATCH * 3 * D2;
+            SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4, st));
+            {
+                const float zw = (float)(mat[10] * (double)(rz / 2) + mat[11]);
+                a.zmid = (calib[11] + calib[10] * zw) * zmul / zdiv;
+            }
+            const long long part_lr = 2LL * ncp * D1, part_hr = 3LL * ncp * D1;
+            const dim3 pg((unsigned)(ncp / 64), D1 / 64);
+            if (parts == 2)
+                hipLaunchKernelGGL(colsum_prepare_kernel<2>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
+                                   g_lr, part_lr, g_hr, part_hr);
+            else
+                hipLaunchKernelGGL(colsum_prepare_kernel<3>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
+                                   g_lr, part_lr, g_hr, part_hr);
+            SURS_LAUNCH_CHECK();
+            for (int m = 0; m < 2; ++m) {
+                const int nvec = m ? 3 : 2;
+                const long long npm = (long long)nvec * ncp;
+                SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
+                const int nb256 = (int)(npm / 256);
+                float *R = m ? r_hr : r_lr;
+                if (parts == 2)
+                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T, 2>), dim3(gemm_grid(D2 / 128, nb256)), dim3(512), g3_lds_bytes(128, 2),
+                                       st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
+                                       (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
+                else
+                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(D2 / 128, nb256)), dim3(512), g3_lds_bytes(128),
+                                       st, (const unsigned short *)(blob + h.wt3[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
+                                       (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
+                SURS_LAUNCH_CHECK();
+            }
+            a.rr_lr = r_lr;
+            a.rr_hr = r_hr;
+        }
         a.vol_hr = vol_hr + (size_t)c0 * rz;
         a.vol_lr = vol_lr + (size_t)c0 * rz;
         a.ncols = (int)nc;
@@ -1212,6 +1321,11 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         }
         if (dtype == SURS_F32) {
             hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
+        } else if (kver == 7) {
+            if (dtype == SURS_BF16)
+                hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_BF16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_F16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
         } else if (kver == 4) {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v4<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
@@ -1233,7 +1347,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
         SURS_LAUNCH_CHECK();
 #ifdef SURS_V3_TRACE
-        if ((dtype == SURS_F32 || kver == 3 || kver == 4) && c0 == 0 && getenv("SURS_V3_TRACE")) {
+        if ((dtype == SURS_F32 || kver == 3 || kver == 4 || kver == 7) && c0 == 0 && getenv("SURS_V3_TRACE")) {
             unsigned long long t[64];
             SURS_HIP_CHECK(hipStreamSynchronize(st));
             SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
