@@ -33,6 +33,7 @@ namespace surs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------------
@@ -564,7 +565,7 @@ struct GridArgs {
     const char *corex;     // the same cores as two f16 parts per weight (kernel v5, fp32-grade)
     const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
     const char *w1t;       // layer-1 weights channel-major (kernel v7)
-    const float *rr_lr, *rr_hr;   // per column: RA, RB [512] (lr) / RA, RB, RC [512] (hr): kernel v7's affine part of layer 1
+    const char *rfrag;     // per column and MLP: the affine part of layer 1 as A fragments [16 row tiles][64][8] (kernel v7)
     float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
@@ -855,6 +856,32 @@ __global__ __launch_bounds__(256) void colsum_prepare_kernel(const float *__rest
     }
 }
 
+// Step 3 (after the GEMMs R = W1 G): the per-column A operand of the affine k-step, [column][MLP][16 row tiles][64 lanes][8]:
+// lane (r, h) of row tile T holds, for row 32 T + r, the three 16-bit parts a, b, c of (b1 + RA, RB, RC) in the slot order
+// h = 0: a0 a1 a2 b0 b0 b1 b0 b1,  h = 1: b2 c0 c0 c1 c0 c1 c2 0  (the B operand pairs them with 1 1 1 z0 z1 z0 z2 z1 |
+// z0 p0 p1 p0 p2 p1 p0 0: all products of parts down to 2^-24 relative).
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_frag_kernel(const float *__restrict__ r_lr, const float *__restrict__ r_hr,
+                                                          const float *__restrict__ zvec, int ncols, char *__restrict__ frag) {
+    typedef typename HalfT<DT>::elem elem;
+    typedef typename HalfT<DT>::vec8 vec8;
+    const int lane = threadIdx.x & 63;
+    const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // fragment index: (col * 2 + m) * 16 + T
+    if (f >= (long long)ncols * 32) return;
+    const int T = (int)(f & 15), m = (int)((f >> 4) & 1);
+    const long long col = f >> 5;
+    const int r = 32 * T + (lane & 31);
+    const float *base = m ? r_hr + col * (3 * D2) : r_lr + col * (2 * D2);
+    const elem zero = (elem)0.0f;
+    elem a[3], b[3], c[3] = {zero, zero, zero};
+    split3_elem<DT>(base[r] + zvec[(m ? ZV_B1_HR : ZV_B1_LR) + r], a);
+    split3_elem<DT>(base[D2 + r], b);
+    if (m) split3_elem<DT>(base[2 * D2 + r], c);
+    const vec8 lo = {a[0], a[1], a[2], b[0], b[0], b[1], b[0], b[1]};
+    const vec8 hi = {b[2], c[0], c[0], c[1], c[0], c[1], c[2], zero};
+    *reinterpret_cast<vec8 *>(frag + f * 1024 + lane * 16) = (lane >> 5) ? hi : lo;
+}
+
 }  // namespace surs
 
 using namespace surs;
@@ -1101,7 +1128,12 @@ static size_t col_base_bytes(long long ncb) {
     return (size_t)ncb * (C0PAD + CC_PAD + 1) * sizeof(float) + (size_t)ncb * C0PAD * 6 + 4096;   // + split image of F
 }
 // column kernel v7: split images of the five g-scaled vectors per column (up to three parts), the five R vectors, a zero bias
-static size_t col_v7_bytes(long long ncb) { return (size_t)ncb * 5 * D1 * 6 + (size_t)ncb * 5 * D2 * 4 + D2 * 4; }
+// (the A-fragment image of the R vectors, 32 KiB per column, then takes the place of the split images)
+static size_t col_v7_image_bytes(long long ncb) {
+    const size_t g = (size_t)ncb * 5 * D1 * 6, f = (size_t)ncb * 32768;
+    return g > f ? g : f;
+}
+static size_t col_v7_bytes(long long ncb) { return col_v7_image_bytes(ncb) + (size_t)ncb * 5 * D2 * 4 + D2 * 4; }
 static size_t col_ws_bytes(long long ncb) { return col_base_bytes(ncb) + col_v7_bytes(ncb); }
 
 extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
@@ -1255,14 +1287,14 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.b1frag = blob + h.b1frag;
         a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
         a.w1t = blob + h.w1t;
-        a.rr_lr = a.rr_hr = nullptr;
+        a.rfrag = nullptr;
         a.zmid = 0.0f;
         if (kver == 7 && dtype != SURS_F32) {
             // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
             if ((rc = g3_set_attributes())) return rc;
             char *v7 = (char *)workspace + col_base_bytes(COL_BATCH);
             unsigned short *g_lr = (unsigned short *)v7, *g_hr = g_lr + (size_t)COL_BATCH * 2 * D1 * 3;
-            float *r_lr = (float *)(g_hr + (size_t)COL_BATCH * 3 * D1 * 3), *r_hr = r_lr + (size_t)COL_BATCH * 2 * D2;
+            float *r_lr = (float *)(v7 + col_v7_image_bytes(COL_BATCH)), *r_hr = r_lr + (size_t)COL_BATCH * 2 * D2;
             float *zero_bias = r_hr + (size_t)COL_BATCH * 3 * D2;
             SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4, st));
             {
@@ -1294,8 +1326,15 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                                        (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
                 SURS_LAUNCH_CHECK();
             }
-            a.rr_lr = r_lr;
-            a.rr_hr = r_hr;
+            {
+                const unsigned fb = (unsigned)ceil_div(nc * 32, 4);
+                if (dtype == SURS_BF16)
+                    hipLaunchKernelGGL(colsum_frag_kernel<SURS_BF16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
+                else
+                    hipLaunchKernelGGL(colsum_frag_kernel<SURS_F16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
+                SURS_LAUNCH_CHECK();
+            }
+            a.rfrag = v7;
         }
         a.vol_hr = vol_hr + (size_t)c0 * rz;
         a.vol_lr = vol_lr + (size_t)c0 * rz;
@@ -1355,6 +1394,11 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                 fprintf(stderr, "v3 trace MLP %d:", m);
                 for (int i = 1; i < 10; ++i) fprintf(stderr, " %llu", t[16 * m + i] - t[16 * m + i - 1]);
                 fprintf(stderr, "  total %llu\n", t[16 * m + 9] - t[16 * m]);
+                if (kver == 7 && dtype != SURS_F32) {
+                    fprintf(stderr, "   v7 layer 1 (since start): init issued %llu, list %llu, chunk 0: gathered %llu, residuals %llu, barrier %llu, mfma+barrier %llu; listed %llu\n",
+                            t[16 * m + 10] - t[16 * m], t[16 * m + 1] - t[16 * m], t[16 * m + 11] - t[16 * m], t[16 * m + 12] - t[16 * m],
+                            t[16 * m + 13] - t[16 * m], t[16 * m + 14] - t[16 * m], t[48 + m]);
+                }
             }
             fprintf(stderr, "v3 trace between MLPs: %llu\n", t[16] - t[9]);
             const double cyc = (double)(t[42] - t[40]), us = (double)(t[43] - t[41]) / 100.0;
