@@ -144,7 +144,8 @@ def main():
             step(True)
         barrier()
         dt = time.perf_counter() - t0
-        launches, kms, kpts = C.c_double(0), C.c_double(0), C.c_double(0)
+        launches, kms, kpts, ktiles, ksteps = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        lib.surs_profile_read_ksteps(C.byref(ktiles), C.byref(ksteps))   # (column kernel v7: data-dependent layer-1 k-steps)
         lib.surs_profile_read(C.byref(launches), C.byref(kms), C.byref(kpts))
         lib.surs_profile_enable(0)
         if world > 1:
@@ -152,16 +153,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         k_avg_ms = kms.value / max(launches.value, 1.0)
-        return dt, {k: v / steps for k, v in stage_ms.items()}, dict(last), (k_avg_ms, kpts.value / max(launches.value, 1.0))
+        kavg = ksteps.value / ktiles.value if ktiles.value > 0 else None
+        return dt, {k: v / steps for k, v in stage_ms.items()}, dict(last), (k_avg_ms, kpts.value / max(launches.value, 1.0), kavg)
 
-    def roofline(prec, k_avg_ms, k_pts):
+    def roofline(prec, k_avg_ms, k_pts, kavg=None):
         """The column kernel of this precision, timed with HIP events around every launch on its launch stream."""
         nprod = PRODUCTS[prec]
         alg = k_pts * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
-        exe = k_pts * FLOP_EXECUTED * nprod / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
+        # what the matrix pipe executes per query: the dense cores of layers 1-3 (column-constant reduction, A.4); with column
+        # kernel v7 layer 1 is one affine k-step + the measured residual k-steps (16 channels x 512 rows each) instead of 64
+        flop_exec = FLOP_EXECUTED * nprod if kavg is None else 2 * (2 * (512 * 256 + 256 * 128) + (kavg + 1.0) * 16 * 512 * 2)
+        exe = k_pts * flop_exec / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         peak = PEAK_MFMA / 1e12
         r = {"kernel": "grid_mlp_kernel_v5 (split-f16, 3 products per MAC)" if prec == "fp32" else
-                       "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "3")[:1], prec),
+                       "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "7")[:1], prec),
              "bound": "mfma", "unit": "TFLOP/s",
              # contract fields: ALGORITHMIC flops (the reference's un-reduced 4 564 998 FLOP per query, SURVEY 8d) per launch /
              # the launch's duration; peak = the dense f16/bf16 MFMA peak divided by the MFMA products one fp32-grade MAC costs
@@ -170,8 +175,12 @@ def main():
              # what the matrix pipe actually executes (column-constant reduction: 2 752 512 FLOP per query and product)
              "achieved_executed": exe, "frac_executed": exe / peak, "mfma_products_per_mac": nprod,
              "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts,
-             "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": FLOP_EXECUTED * nprod,
+             "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": flop_exec,
              "traffic": None}
+        if kavg is not None:
+            # frac (algorithmic) can exceed 1: the restated layer 1 does not execute the reference's dense product
+            r["layer1_residual_ksteps_per_tile"] = kavg
+            r["layer1_listed_channels_per_tile_upper"] = 16.0 * kavg
         # HBM bytes / MFMA-busy cycles come from separate rocprofv3 --pmc passes (tools/profile_round.sh) and are only valid
         # for the library they were collected on: they are reported when the sha256 of libsurs_hip.so matches, else null
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -189,13 +198,13 @@ def main():
                 pass
         return r
 
-    dt, stage_ms, last, (k_avg_ms, k_pts) = run(opt, args.steps, args.warmup)
+    dt, stage_ms, last, (k_avg_ms, k_pts, k_ks) = run(opt, args.steps, args.warmup)
 
     extras = {}
     if world == 1 and not args.no_extras and args.precision != "fp32":
         # the same step in the parity-grade precision (fp32-grade column kernel; same network object, same blob)
         o32 = options.BaseOptions().parse(flags + ["--precision", "fp32"])
-        d32, st32, last32, (k32, p32) = run(o32, 2, 1)
+        d32, st32, last32, (k32, p32, _) = run(o32, 2, 1)
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
                                "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
@@ -283,7 +292,7 @@ def main():
                        "reconstruction_s": ms_per_step / 1e3, "stage_ms_rank0": stage_ms,
                        "mesh": last, "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world),
                        "backend": None if world == 1 else args.backend},
-            "roofline": roofline(args.precision, k_avg_ms, k_pts),
+            "roofline": roofline(args.precision, k_avg_ms, k_pts, k_ks),
         }
         out["config"].update(extras)
         if world == 1 and not args.no_cpu_baseline:

@@ -209,6 +209,10 @@ int surs_save_obj_mesh(const char *path, const double *verts, long long n_verts,
  * returns the number of timed launches, the sum of their durations (ms) and the voxels they evaluated, and resets. */
 int surs_profile_enable(int on);
 int surs_profile_read(double *launches, double *total_ms, double *points);
+/* Column kernel v7 runs a data-dependent number of layer-1 k-steps.  tile_mlps: (z tile, MLP) pairs the timed launches
+ * processed; ksteps: residual k-steps (16 listed channels each) they ran, not counting the affine k-step of every pair.
+ * Call before surs_profile_read, which resets the counters. */
+int surs_profile_read_ksteps(double *tile_mlps, double *ksteps);
 
 /* ------------------------------------------------------------------ Lewiner marching cubes */
 

@@ -77,6 +77,7 @@ _SIGS = {
     "surs_save_obj_mesh": (C.c_int, [C.c_char_p, _vp, C.c_longlong, _vp, C.c_longlong, _i]),
     "surs_profile_enable": (C.c_int, [_i]),
     "surs_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "surs_profile_read_ksteps": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "surs_mc_workspace_bytes": (_sz, [_i, _i, _i]),
     "surs_transform_points": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
     "surs_mc_lewiner_range": (C.c_int, [_vp, _i, _i, _i, _i, _i, C.c_double, _vp, _sz, _vp, _vp, _vp, _i, _vp, _i,

@@ -567,6 +567,7 @@ struct GridArgs {
     const char *w1t;       // layer-1 weights channel-major (kernel v7)
     const char *rfrag;     // per column and MLP: the affine part of layer 1 as A fragments [16 row tiles][64][8] (kernel v7)
     float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
+    unsigned long long *kstat;   // profiling only: sum of kernel v7's residual k-steps (null otherwise)
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
     int ncols, rz;
@@ -1081,6 +1082,8 @@ struct GridProf {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<double> pts;
+    unsigned long long *kstat = nullptr;   // device counter: residual k-steps of column kernel v7 (executed-FLOP statistic)
+    double tiles = 0;                      // (z tile, MLP) pairs the timed v7 launches processed
 } g_prof;
 }  // namespace
 
@@ -1088,6 +1091,8 @@ static void prof_reset_locked(bool on) {
     for (auto &e : g_prof.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     g_prof.ev.clear();
     g_prof.pts.clear();
+    g_prof.tiles = 0;
+    if (g_prof.kstat) (void)hipMemset(g_prof.kstat, 0, sizeof(unsigned long long));
     g_prof.on = on;
 }
 
@@ -1113,6 +1118,19 @@ extern "C" int surs_profile_read(double *launches, double *total_ms, double *poi
     if (total_ms) *total_ms = ms;
     if (points) *points = p;
     prof_reset_locked(g_prof.on);
+    return 0;
+}
+
+// Column kernel v7 runs a data-dependent number of layer-1 k-steps; while profiling is enabled it adds them up.  Returns the
+// number of (z tile, MLP) pairs the timed launches processed and the residual k-steps (16 listed channels each) they ran -
+// the affine k-step every pair runs is not counted.  Call before surs_profile_read (which resets the counters).
+extern "C" int surs_profile_read_ksteps(double *tile_mlps, double *ksteps) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    for (auto &e : g_prof.ev) SURS_HIP_CHECK(hipEventSynchronize(e.second));
+    unsigned long long v = 0;
+    if (g_prof.kstat) SURS_HIP_CHECK(hipMemcpy(&v, g_prof.kstat, sizeof(v), hipMemcpyDeviceToHost));
+    if (tile_mlps) *tile_mlps = g_prof.tiles;
+    if (ksteps) *ksteps = (double)v;
     return 0;
 }
 
@@ -1229,15 +1247,17 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    // Reduced precision: SURS_GRID_KERNEL selects the column kernel: 3 (default) = waves split the output channels, weights
-    // straight from L2 into registers; 4 = the same on the 16x16x32 MFMA shape (experimental: higher clock, more cycles,
-    // +1 %); 2 = waves split the points, weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.
-    // 1 and 2 are bit-identical and kept as the regression reference of 3, which differs from them only in the
-    // summation order of the final 128-term dot product.  SURS_F32: kernel v5 (split-f16 operands, fp32-grade).
+    // Reduced precision: SURS_GRID_KERNEL / surs_set_grid_kernel select the column kernel: 7 (default) = v3 with layer 1 restated
+    // as a per-column affine part + the residuals of the channels whose LeakyReLU branch changes inside the z tile (1.9x v3,
+    // closer to the fp32 sweep); 3 = waves split the output channels, weights straight from L2 into registers, dense layer 1;
+    // 4 = the same on the 16x16x32 MFMA shape (experimental: higher clock, more cycles, +1 %); 2 = waves split the points,
+    // weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.  1 and 2 are bit-identical and kept as
+    // the regression reference of 3, which differs from them only in the summation order of the final 128-term dot product;
+    // 7 differs from 3 by a few 16-bit roundings of layer 0.  SURS_F32: kernel v5 (split-f16 operands, fp32-grade).
     static int kver_env = -1;
     if (kver_env < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
-        kver_env = (e && ((e[0] >= '1' && e[0] <= '4') || e[0] == '7')) ? (e[0] - '0') : 3;
+        kver_env = (e && ((e[0] >= '1' && e[0] <= '4') || e[0] == '7')) ? (e[0] - '0') : 7;
     }
     const int kver = g_grid_kernel_override ? g_grid_kernel_override : kver_env;
     if ((rc = grid_set_attributes())) return rc;
@@ -1349,9 +1369,18 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         const unsigned grid = (unsigned)((nc < cus) ? nc : cus);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         bool prof;
+        a.kstat = nullptr;
         {
             std::lock_guard<std::mutex> lock(g_prof.mu);
             prof = g_prof.on;
+            if (prof && kver == 7 && dtype != SURS_F32) {
+                if (!g_prof.kstat) {
+                    SURS_HIP_CHECK(hipMalloc((void **)&g_prof.kstat, sizeof(unsigned long long)));
+                    SURS_HIP_CHECK(hipMemset(g_prof.kstat, 0, sizeof(unsigned long long)));
+                }
+                a.kstat = g_prof.kstat;
+                g_prof.tiles += 2.0 * (double)nc * ((rz + 127) / 128);
+            }
         }
         if (prof) {
             SURS_HIP_CHECK(hipEventCreate(&e0));
