@@ -75,7 +75,9 @@ struct MlpBlobHeader {
     // layer-1 weights channel-major, W1t[m][c][r] = W1[r][c] in the blob's 16-bit dtype, [2 MLPs][1024][512]: column kernel v7
     // gathers the rows of the channels whose LeakyReLU branch is not constant over a z tile
     uint32_t w1t;
-    uint32_t pad[3];
+    // the same as two f16 parts per weight, [2 MLPs][1024][2 parts][512]: fp32-grade column kernel v8
+    uint32_t w1tx;
+    uint32_t pad[2];
 };
 static_assert(sizeof(MlpBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 constexpr uint32_t MLP_MAGIC = 0x53525553u;
@@ -115,6 +117,7 @@ inline MlpBlobHeader blob_layout(uint32_t dtype) {
         for (int l = 0; l < 4; ++l) h.wt2[m][l] = take((size_t)kpad[l] * mout[l] * 4);
     h.wc2 = take((size_t)C_G * CC_PAD * 4);
     h.w1t = take((size_t)2 * D1 * D2 * 2);
+    h.w1tx = take((size_t)2 * D1 * 2 * D2 * 2);
     h.total_bytes = (uint32_t)off;
     return h;
 }

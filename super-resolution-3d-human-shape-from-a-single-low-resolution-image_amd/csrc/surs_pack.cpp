@@ -258,6 +258,15 @@ extern "C" size_t surs_mlp_pack(const float *const w_lr[5], const float *const b
         for (int m = 0; m < 2; ++m)
             for (int c = 0; c < D1; ++c)
                 for (int r = 0; r < D2; ++r) wt[((size_t)m * D1 + c) * D2 + r] = cvt(W[m][1][(size_t)r * D1 + c]);
+        uint16_t *wx = (uint16_t *)(base + h.w1tx);
+        for (int m = 0; m < 2; ++m)
+            for (int c = 0; c < D1; ++c)
+                for (int r = 0; r < D2; ++r) {
+                    const float w = W[m][1][(size_t)r * D1 + c];
+                    const uint16_t hi = f32_to_f16(w);
+                    wx[(((size_t)m * D1 + c) * 2) * D2 + r] = hi;
+                    wx[(((size_t)m * D1 + c) * 2 + 1) * D2 + r] = f32_to_f16(w - f16_to_f32(hi));
+                }
     }
     // ---- layer-1 biases as A fragments (three exact 16-bit parts in k-slots 0..2 of lanes 0..31)
     {

@@ -565,6 +565,7 @@ struct GridArgs {
     const char *corex;     // the same cores as two f16 parts per weight (kernel v5, fp32-grade)
     const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
     const char *w1t;       // layer-1 weights channel-major (kernel v7)
+    const char *w1tx;      // the same as two f16 parts (kernel v8)
     const char *rfrag;     // per column and MLP: the affine part of layer 1 as A fragments [16 row tiles][64][8] (kernel v7)
     float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
     unsigned long long *kstat;   // profiling only: sum of kernel v7's residual k-steps (null otherwise)
@@ -807,6 +808,7 @@ __global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
 #include "surs_grid_v4.inc"
 #include "surs_grid_v5.inc"
 #include "surs_grid_v7.inc"
+#include "surs_grid_v8.inc"
 
 // Column kernel v7's per-column affine part, step 1: the vectors g . a0, g . w0z (lr) and g . a0, g . w0z, g . w0p (hr) of a
 // column batch as the split image [parts][1024 / 16][nvec * ncp][16] that the layer GEMM kernel reads as its point operand
@@ -897,7 +899,8 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 
 static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
 extern "C" int surs_set_grid_kernel(int version) {
-    SURS_REQUIRE(version == 0 || (version >= 1 && version <= 4) || version == 7, "column kernel: 0 (default / SURS_GRID_KERNEL), 1-4 or 7");
+    SURS_REQUIRE(version == 0 || (version >= 1 && version <= 5) || version == 7 || version == 8,
+                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 1-4 or 7, fp32-grade 5 or 8");
     g_grid_kernel_override = version;
     return 0;
 }
@@ -1188,6 +1191,7 @@ static int grid_set_attributes() {
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, GRID5_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v8, hipFuncAttributeMaxDynamicSharedMemorySize, GRID8_LDS_BYTES));
     return 0;
 }
 
@@ -1259,7 +1263,15 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         const char *e = getenv("SURS_GRID_KERNEL");
         kver_env = (e && ((e[0] >= '1' && e[0] <= '4') || e[0] == '7')) ? (e[0] - '0') : 7;
     }
-    const int kver = g_grid_kernel_override ? g_grid_kernel_override : kver_env;
+    static int kver32_env = -1;   // fp32-grade column kernel: 8 (default: restated layer 1) or 5 (dense layer 1)
+    if (kver32_env < 0) {
+        const char *e = getenv("SURS_GRID_F32_KERNEL");
+        kver32_env = (e && e[0] == '5') ? 5 : 8;
+    }
+    const bool ov32 = g_grid_kernel_override == 5 || g_grid_kernel_override == 8;
+    const int kver = (g_grid_kernel_override && !ov32) ? g_grid_kernel_override : kver_env;
+    const int kver32 = ov32 ? g_grid_kernel_override : kver32_env;
+    const bool restated = dtype == SURS_F32 ? kver32 == 8 : kver == 7;
     if ((rc = grid_set_attributes())) return rc;
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
@@ -1307,9 +1319,10 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.b1frag = blob + h.b1frag;
         a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
         a.w1t = blob + h.w1t;
+        a.w1tx = blob + h.w1tx;
         a.rfrag = nullptr;
         a.zmid = 0.0f;
-        if (kver == 7 && dtype != SURS_F32) {
+        if (restated) {
             // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
             if ((rc = g3_set_attributes())) return rc;
             char *v7 = (char *)workspace + col_base_bytes(COL_BATCH);
@@ -1348,7 +1361,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             }
             {
                 const unsigned fb = (unsigned)ceil_div(nc * 32, 4);
-                if (dtype == SURS_BF16)
+                if (dtype == SURS_BF16)   // (the fp32-grade kernel's fragments are f16 parts)
                     hipLaunchKernelGGL(colsum_frag_kernel<SURS_BF16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
                 else
                     hipLaunchKernelGGL(colsum_frag_kernel<SURS_F16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
@@ -1373,13 +1386,13 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         {
             std::lock_guard<std::mutex> lock(g_prof.mu);
             prof = g_prof.on;
-            if (prof && kver == 7 && dtype != SURS_F32) {
+            if (prof && restated) {
                 if (!g_prof.kstat) {
                     SURS_HIP_CHECK(hipMalloc((void **)&g_prof.kstat, sizeof(unsigned long long)));
                     SURS_HIP_CHECK(hipMemset(g_prof.kstat, 0, sizeof(unsigned long long)));
                 }
                 a.kstat = g_prof.kstat;
-                g_prof.tiles += 2.0 * (double)nc * ((rz + 127) / 128);
+                g_prof.tiles += 2.0 * (double)nc * (dtype == SURS_F32 ? (rz + 63) / 64 : (rz + 127) / 128);
             }
         }
         if (prof) {
@@ -1388,7 +1401,10 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
         if (dtype == SURS_F32) {
-            hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
+            if (kver32 == 8)
+                hipLaunchKernelGGL(grid_mlp_kernel_v8, dim3(grid), dim3(256), GRID8_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
         } else if (kver == 7) {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_BF16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
@@ -1423,7 +1439,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                 fprintf(stderr, "v3 trace MLP %d:", m);
                 for (int i = 1; i < 10; ++i) fprintf(stderr, " %llu", t[16 * m + i] - t[16 * m + i - 1]);
                 fprintf(stderr, "  total %llu\n", t[16 * m + 9] - t[16 * m]);
-                if (kver == 7 && dtype != SURS_F32) {
+                if (restated) {
                     fprintf(stderr, "   v7 layer 1 (since start): init issued %llu, list %llu, chunk 0: gathered %llu, residuals %llu, barrier %llu, mfma+barrier %llu; listed %llu\n",
                             t[16 * m + 10] - t[16 * m], t[16 * m + 1] - t[16 * m], t[16 * m + 11] - t[16 * m], t[16 * m + 12] - t[16 * m],
                             t[16 * m + 13] - t[16 * m], t[16 * m + 14] - t[16 * m], t[48 + m]);

@@ -28,11 +28,20 @@ def main():
     out = {}
     for kv in (3, 7):
         L.surs_set_grid_kernel(kv)
-        vols, times, ws = pr.sweeps(sd, Fl, Fh, R, ("fp32", "bf16", "fp16") if kv == 3 else ("bf16", "fp16"), dev)
+        vols, times, ws = pr.sweeps(sd, Fl, Fh, R, ("bf16", "fp16"), dev)
         out[kv] = (vols, times)
         print("kernel v%d sweep seconds at R=%d: %s" % (kv, R, {k: round(v, 4) for k, v in times.items()}), flush=True)
+    L.surs_set_grid_kernel(5)
+    v5, t5, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev)
+    L.surs_set_grid_kernel(8)
+    v8, t8, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev)
     L.surs_set_grid_kernel(0)
-    ref = out[3][0]["fp32"]
+    print("fp32-grade sweep seconds at R=%d: v5 %.4f  v8 %.4f" % (R, t5["fp32"], t8["fp32"]))
+    for i, tag in enumerate(("hr", "lr")):
+        st = pr.field_stats(v8["fp32"][i], v5["fp32"][i])
+        print("v8 vs v5 fp32 %s: max|dlogit| %.3e mean %.3e flips %d finite %s" % (
+            tag, st["max_abs_dlogit"], st["mean_abs_dlogit"], st["flipped_voxels"], bool(torch.isfinite(v8["fp32"][i]).all())))
+    ref = v5["fp32"]
     for prec in ("bf16", "fp16"):
         for kv in (3, 7):
             v = out[kv][0][prec]
