@@ -162,10 +162,11 @@ def main():
         alg = k_pts * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         # what the matrix pipe executes per query: the dense cores of layers 1-3 (column-constant reduction, A.4); with column
         # kernel v7 layer 1 is one affine k-step + the measured residual k-steps (16 channels x 512 rows each) instead of 64
-        flop_exec = FLOP_EXECUTED * nprod if kavg is None else 2 * (2 * (512 * 256 + 256 * 128) + (kavg + 1.0) * 16 * 512 * 2)
+        # (the affine k-step is one product per MAC also in the fp32-grade kernel)
+        flop_exec = FLOP_EXECUTED * nprod if kavg is None else 2 * (2 * (512 * 256 + 256 * 128) * nprod + (kavg * nprod + 1.0) * 16 * 512 * 2)
         exe = k_pts * flop_exec / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         peak = PEAK_MFMA / 1e12
-        r = {"kernel": "grid_mlp_kernel_v5 (split-f16, 3 products per MAC)" if prec == "fp32" else
+        r = {"kernel": "grid_mlp_kernel_v%s (split-f16, 3 products per MAC)" % os.environ.get("SURS_GRID_F32_KERNEL", "8")[:1] if prec == "fp32" else
                        "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "7")[:1], prec),
              "bound": "mfma", "unit": "TFLOP/s",
              # contract fields: ALGORITHMIC flops (the reference's un-reduced 4 564 998 FLOP per query) per launch /
@@ -204,9 +205,9 @@ def main():
     if world == 1 and not args.no_extras and args.precision != "fp32":
         # the same step in the parity-grade precision (fp32-grade column kernel; same network object, same blob)
         o32 = options.BaseOptions().parse(flags + ["--precision", "fp32"])
-        d32, st32, last32, (k32, p32, _) = run(o32, 2, 1)
+        d32, st32, last32, (k32, p32, ks32) = run(o32, 2, 1)
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
-                               "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32),
+                               "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
     if world == 1 and not args.no_extras:
         # a run of subjects (apps/eval_SuRS.py:74-80) - per subject: decoded 8-bit pixels -> img_LR -> encoder ->

@@ -415,6 +415,8 @@ static int g3_set_attributes() {
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 2)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
     }
     return 0;
 }
@@ -568,6 +570,7 @@ struct GridArgs {
     const char *w1tx;      // the same as two f16 parts (kernel v8)
     const char *rfrag;     // per column and MLP: the affine part of layer 1 as A fragments [16 row tiles][64][8] (kernel v7)
     float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
+    unsigned *colctr;      // kernels v7 / v8: next column to hand out (zeroed before the launch)
     unsigned long long *kstat;   // profiling only: sum of kernel v7's residual k-steps (null otherwise)
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
@@ -1154,7 +1157,7 @@ static size_t col_v7_image_bytes(long long ncb) {
     const size_t g = (size_t)ncb * 5 * D1 * 6, f = (size_t)ncb * 32768;
     return g > f ? g : f;
 }
-static size_t col_v7_bytes(long long ncb) { return col_v7_image_bytes(ncb) + (size_t)ncb * 5 * D2 * 4 + D2 * 4; }
+static size_t col_v7_bytes(long long ncb) { return col_v7_image_bytes(ncb) + (size_t)ncb * 5 * D2 * 4 + D2 * 4 + 256; }
 static size_t col_ws_bytes(long long ncb) { return col_base_bytes(ncb) + col_v7_bytes(ncb); }
 
 extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
@@ -1321,6 +1324,7 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.w1t = blob + h.w1t;
         a.w1tx = blob + h.w1tx;
         a.rfrag = nullptr;
+        a.colctr = nullptr;
         a.zmid = 0.0f;
         if (restated) {
             // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
@@ -1329,7 +1333,8 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             unsigned short *g_lr = (unsigned short *)v7, *g_hr = g_lr + (size_t)COL_BATCH * 2 * D1 * 3;
             float *r_lr = (float *)(v7 + col_v7_image_bytes(COL_BATCH)), *r_hr = r_lr + (size_t)COL_BATCH * 2 * D2;
             float *zero_bias = r_hr + (size_t)COL_BATCH * 3 * D2;
-            SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4, st));
+            SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4 + 256, st));   // + the column counter behind it
+            a.colctr = (unsigned *)(zero_bias + D2);
             {
                 const float zw = (float)(mat[10] * (double)(rz / 2) + mat[11]);
                 a.zmid = (calib[11] + calib[10] * zw) * zmul / zdiv;
@@ -1350,11 +1355,11 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                 const int nb256 = (int)(npm / 256);
                 float *R = m ? r_hr : r_lr;
                 if (parts == 2)
-                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T, 2>), dim3(gemm_grid(D2 / 128, nb256)), dim3(512), g3_lds_bytes(128, 2),
+                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 2>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 2),
                                        st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
                                        (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
                 else
-                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(D2 / 128, nb256)), dim3(512), g3_lds_bytes(128),
+                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256),
                                        st, (const unsigned short *)(blob + h.wt3[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
                                        (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
                 SURS_LAUNCH_CHECK();
