@@ -323,7 +323,27 @@ def test_restated_layer1_kernel_is_closer_to_fp32_than_dense_kernel(setup):
                     bound = 2e-2 if prec == "bf16" else 2.5e-3
                     assert e7.max().item() < bound and e3.max().item() < bound, (R, prec, i, e3.max().item(), e7.max().item())
                     assert e7.mean().item() < 1.05 * e3.mean().item(), (R, prec, i, e3.mean().item(), e7.mean().item())
+        # the fp32-grade pair (v8 restated, v5 dense) and the bf16 x 3 operand split of the per-column GEMMs
+        R = 48
+        mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+        cal = common.CALIB.reshape(-1)[:12]
+        vols = {}
+        for kv, split in ((5, 0), (8, 0), (8, 3)):
+            L.surs_set_grid_kernel(kv)
+            L.surs_set_operand_split(split)
+            vols[(kv, split)] = [v.clone() for v in nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"],
+                                                                   g.blob("bf16"), "fp32", setup["ws"])]
+        L.surs_set_operand_split(0)
+        for key in ((8, 0), (8, 3)):
+            for x, r in zip(vols[key], vols[(5, 0)]):
+                assert (lg(x) - lg(r)).abs().max().item() < 3e-5, key
         L.surs_set_grid_kernel(7)
+        L.surs_set_operand_split(3)
+        a3 = [v.clone() for v in nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], g.blob("f16"), "fp16", setup["ws"])]
+        L.surs_set_operand_split(0)
+        a2 = nat.query_grid(0, R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], g.blob("f16"), "fp16", setup["ws"])
+        for x, r in zip(a3, a2):
+            assert (lg(x) - lg(r)).abs().max().item() < 1e-3
         L.surs_profile_enable(1)
         R = 96
         mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
@@ -334,3 +354,4 @@ def test_restated_layer1_kernel_is_closer_to_fp32_than_dense_kernel(setup):
     finally:
         L.surs_profile_enable(0)
         L.surs_set_grid_kernel(0)
+        L.surs_set_operand_split(0)

@@ -21,7 +21,14 @@ mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
 b = g.blob("f16" if dt == "fp16" else "bf16")
 vh = torch.empty((R, R, R), dtype=torch.float32, device=g.dev())
 vl = torch.empty_like(vh)
+import ctypes as C  # noqa: E402
+from surs_amd import _lib  # noqa: E402
+L = _lib.lib()
+L.surs_profile_enable(1)
 for _ in range(3):
     native.query_grid(0, R, R, R, mat, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, b, dt, ws, vh, vl)
 torch.cuda.synchronize()
-print("done")
+tiles, ks = C.c_double(0), C.c_double(0)
+L.surs_profile_read_ksteps(C.byref(tiles), C.byref(ks))   # column kernels v7 / v8: residual k-steps of layer 1 (data dependent)
+L.surs_profile_enable(0)
+print("done tile_mlps_per_sweep %.0f residual_ksteps_per_sweep %.0f" % (tiles.value / 3, ks.value / 3))

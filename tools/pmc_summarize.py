@@ -43,6 +43,18 @@ def keep(sub, counter, name):
     return rs
 
 
+def ksteps(prec):
+    """(tile, MLP) pairs and residual layer-1 k-steps of one sweep = 16 launches, printed by tools/gpu_grid_once.py."""
+    for sub in ("pmc_mfma_", "pmc_fetch_", "pmc_clk_"):
+        f = os.path.join(SRC, sub + prec + ".log")
+        if os.path.exists(f):
+            for line in open(f):
+                if line.startswith("done tile_mlps_per_sweep"):
+                    w = line.split()
+                    return float(w[2]), float(w[4])
+    return None, None
+
+
 def one(prec):
     fetch = keep("pmc_fetch_" + prec, "FETCH_SIZE", "%s_pmc_fetch_size_%s.csv" % (TAG, prec))
     write = keep("pmc_write_" + prec, "WRITE_SIZE", "%s_pmc_write_size_%s.csv" % (TAG, prec))
@@ -52,6 +64,14 @@ def one(prec):
     f_kb, w_kb = mean(fetch), mean(write)
     n = PRODUCTS[prec]
     weights = 2 * 42 * 32768 * (2 if prec == "fp32" else 1)     # the packed weight stream once (fp32: hi + lo parts)
+    tiles, ks = ksteps(prec)
+    # MFMAs one wave issues per (tile, MLP): layer 1 = the affine k-step + the residual k-steps, layers 2 and 3 dense.
+    # bf16 (v7, 128-voxel tile): 16 per k-step, 256 + 64; fp32-grade (v8, 64-voxel tile): 8 affine, 24 per k-step, 384 + 96
+    if tiles:
+        per_wave = (16 * tiles + 16 * ks + 320 * tiles) if prec != "fp32" else (8 * tiles + 24 * ks + 480 * tiles)
+        expected = per_wave * 4 * 32 / 16.0      # 4 waves, 32 cycles per MFMA, 16 launches per sweep
+    else:
+        expected = 8388608 * 2752512 * n / 32768 * 32   # dense layer 1 (v3 / v5)
     return {
         "kernel": fetch[0]["Kernel_Name"] if fetch else None,
         "launch": "16384 columns x 512 voxels = 8388608 queries (R=512), tools/gpu_grid_once.py 512 " + prec,
@@ -66,11 +86,13 @@ def one(prec):
         # v_mfma_f32_32x32x16_*); the denominator is the launch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs
         "mfma_busy_cycles_per_launch": mean(mfma) if mfma else None,
         "mfma_busy_fraction": (mean(mfma) / (mean(gui) / 8.0 * 1024.0)) if mfma and gui else None,
-        "mfma_busy_cycles_expected": 8388608 * 2752512 * n / 32768 * 32,   # executed FLOP / FLOP per MFMA x 32 cycles
+        "mfma_busy_cycles_expected": expected,   # MFMAs issued x 32 cycles
+        "layer1_residual_ksteps_per_tile_mlp": (ks / tiles) if tiles else None,
         # compulsory bytes of one launch: the two output fields (2 x 4 B per voxel) and the weight stream once; the
         # per-column constants (CC_PAD floats per column) and masks are the sweep's own intermediate, listed separately
         "algorithmic_bytes_per_launch": 8388608 * 8 + weights,
         "column_constant_bytes_per_launch": 16384 * 2944 * 4 + 16384 * 4,
+        "affine_fragment_bytes_per_launch": 16384 * 32768 if tiles else 0,   # kernels v7 / v8: [column][MLP][16][64][8] 16-bit
     }
 
 
