@@ -135,7 +135,7 @@ def sweeps(sd, Fl, Fh, R, precisions, dev, zmul=512, zdiv=200.0):
 
 def report(sd, Fl, Fh, R, dev, precisions=("bf16", "fp16"), sample=1 << 20):
     vols, times, ws = sweeps(sd, Fl, Fh, R, ("fp32",) + tuple(precisions), dev)
-    rep = {"resolution": R, "reference": "fp32-grade column kernel (v5)", "sweep_s": times}
+    rep = {"resolution": R, "reference": "fp32-grade column kernel (v8)", "sweep_s": times}
     for prec in precisions:
         r = {}
         for i, tag in enumerate(("hr", "lr")):
