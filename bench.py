@@ -8,7 +8,7 @@ seeded random-init weights; `value` is queries per second over the whole job.
         bench.py --gpus N --steps K --warmup W
 
 `--precision bf16` (default: what BASELINE configs[2] names) | `fp16` (configs[4]) | `fp32` (the parity-grade sweep:
-column kernel v5, split-f16 operands, logits within 1e-4 of the reference).  At N=1 the line also carries
+column kernel v8, split-f16 operands, logits within 1e-4 of the reference).  At N=1 the line also carries
 `config.fp32_mode` - the same step timed in fp32 - and `config.precision_acceptance` - what the reduced precisions do to
 the field and the meshes at full size against the fp32 sweep (tools/precision_report.py; asserted in
 tests/test_gpu_precision.py).
@@ -266,7 +266,7 @@ def main():
                                                                for s in ("to_ref", "from_ref")}}
                                  for t in ("hr", "lr")} for p in ("bf16", "fp16")}
                 acc[name]["sweep_s"] = rep["sweep_s"]
-            acc["reference"] = "fp32-grade sweep (column kernel v5) on the same features and weights, 512^3"
+            acc["reference"] = "fp32-grade sweep (column kernel v8) on the same features and weights, 512^3"
             acc["why_bf16"] = ("BASELINE configs[2] names bf16: fp32's exponent range, no activation can overflow; fp16 (configs[4]) is "
                                "8x tighter at 0.93x the rate but saturates at 65504 - `--precision fp16` / `fp32` select the others")
             extras["precision_acceptance"] = acc

@@ -1,5 +1,5 @@
 """What the reduced-precision column kernels (bf16 / fp16) do to the RESULT of a dense reconstruction, measured against the
-fp32-grade sweep (column kernel v5, itself held to the reference's goldens at 1e-4) on the same features and weights:
+fp32-grade sweep (column kernel v8, itself held to the reference's goldens at 1e-4) on the same features and weights:
 
   * field:  max / mean |d logit|, max |d occupancy|, number of voxels on the other side of the 0.5 level
   * mesh :  vertex / face counts and their deltas, and a symmetric nearest-vertex distance in voxel units between the two
