@@ -355,3 +355,36 @@ def test_restated_layer1_kernel_is_closer_to_fp32_than_dense_kernel(setup):
         L.surs_profile_enable(0)
         L.surs_set_grid_kernel(0)
         L.surs_set_operand_split(0)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2), ("fp16", 4e-3)])
+def test_sweep_edge_geometries_vs_point_path(setup, dtype, tol):
+    """The column kernels on sweeps the other tests do not cover, against the fp32 point evaluator on the oracle's coordinates:
+    a calibration that flips the depth axis (z_feat decreases with k: the tile box of the restated layer 1 takes min / max of its
+    two ends), bounds that reach outside the image (columns with a zero mask), and a non-cubic grid whose depth is neither a
+    multiple of the 64- nor of the 128-voxel tile.  fp32: logits at 1e-4."""
+    import oracle
+    nat, g = setup["native"], setup["g"]
+    lg = lambda p: torch.log(p.double() / (1 - p.double()))
+    flip = (np.diag([1.0, 1.0, -1.0, 1.0]).astype(np.float32) @ common.CALIB).astype(np.float32)
+    for calib, b_min, b_max, res in ((flip, [-0.5] * 3, [0.5] * 3, (20, 24, 200)),
+                                     (common.CALIB, [-0.6, -0.55, -0.5], [0.6, 0.5, 0.45], (24, 20, 72))):
+        rx, ry, rz = res
+        m = np.eye(4)
+        for a, r in enumerate(res):
+            m[a, a] = (b_max[a] - b_min[a]) / r
+            m[a, 3] = b_min[a]
+        ii, jj, kk = np.meshgrid(np.arange(rx), np.arange(ry), np.arange(rz), indexing="ij")
+        idx = np.stack([ii.reshape(-1), jj.reshape(-1), kk.reshape(-1), np.ones(rx * ry * rz)]).astype(np.float64)
+        pts = torch.from_numpy((m[:3] @ idx).astype(np.float32)).to(g.dev())
+        cal = np.asarray(calib, np.float32).reshape(-1)[:12]
+        blob = g.blob("f16" if dtype == "fp16" else "bf16")
+        vh, vl = nat.query_grid(0, rx, ry, rz, m[:3].reshape(-1), cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, dtype, setup["ws"])
+        phr, plr, lhr, llr = nat.query_points(pts, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], g.blob("bf16"), setup["ws"], want_logits=True)
+        assert (vh.reshape(-1) - phr).abs().max().item() < tol and (vl.reshape(-1) - plr).abs().max().item() < tol
+        assert torch.equal(vh.reshape(-1) == 0, phr == 0)        # the same columns are masked
+        if b_min[0] < -0.5:
+            assert int((phr == 0).sum().item()) > 0
+        if dtype == "fp32":
+            ok = (phr > 0) & (phr < 1)
+            assert (lg(vh.reshape(-1)[ok]) - lhr.double()[ok]).abs().max().item() < 1e-4
