@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -1088,7 +1089,7 @@ struct GridProf {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<double> pts;
-    unsigned long long *kstat = nullptr;   // device counter: residual k-steps of column kernel v7 (executed-FLOP statistic)
+    std::map<int, unsigned long long *> kstat;   // per device: counter of the residual k-steps of column kernels v7 / v8 (executed-FLOP statistic)
     double tiles = 0;                      // (z tile, MLP) pairs the timed v7 launches processed
 } g_prof;
 }  // namespace
@@ -1098,7 +1099,7 @@ static void prof_reset_locked(bool on) {
     g_prof.ev.clear();
     g_prof.pts.clear();
     g_prof.tiles = 0;
-    if (g_prof.kstat) (void)hipMemset(g_prof.kstat, 0, sizeof(unsigned long long));
+    for (auto &k : g_prof.kstat) (void)hipMemset(k.second, 0, sizeof(unsigned long long));   // (unified addressing: any current device)
     g_prof.on = on;
 }
 
@@ -1134,7 +1135,11 @@ extern "C" int surs_profile_read_ksteps(double *tile_mlps, double *ksteps) {
     std::lock_guard<std::mutex> lock(g_prof.mu);
     for (auto &e : g_prof.ev) SURS_HIP_CHECK(hipEventSynchronize(e.second));
     unsigned long long v = 0;
-    if (g_prof.kstat) SURS_HIP_CHECK(hipMemcpy(&v, g_prof.kstat, sizeof(v), hipMemcpyDeviceToHost));
+    for (auto &k : g_prof.kstat) {
+        unsigned long long one = 0;
+        SURS_HIP_CHECK(hipMemcpy(&one, k.second, sizeof(one), hipMemcpyDeviceToHost));
+        v += one;
+    }
     if (tile_mlps) *tile_mlps = g_prof.tiles;
     if (ksteps) *ksteps = (double)v;
     return 0;
@@ -1392,11 +1397,14 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             std::lock_guard<std::mutex> lock(g_prof.mu);
             prof = g_prof.on;
             if (prof && restated) {
-                if (!g_prof.kstat) {
-                    SURS_HIP_CHECK(hipMalloc((void **)&g_prof.kstat, sizeof(unsigned long long)));
-                    SURS_HIP_CHECK(hipMemset(g_prof.kstat, 0, sizeof(unsigned long long)));
+                int dev = 0;
+                SURS_HIP_CHECK(hipGetDevice(&dev));
+                unsigned long long *&ctr = g_prof.kstat[dev];
+                if (!ctr) {
+                    SURS_HIP_CHECK(hipMalloc((void **)&ctr, sizeof(unsigned long long)));
+                    SURS_HIP_CHECK(hipMemset(ctr, 0, sizeof(unsigned long long)));
                 }
-                a.kstat = g_prof.kstat;
+                a.kstat = ctr;
                 g_prof.tiles += 2.0 * (double)nc * (dtype == SURS_F32 ? (rz + 63) / 64 : (rz + 127) / 128);
             }
         }
