@@ -136,6 +136,16 @@ int surs_set_operand_split(int parts);
  * (DESIGN.md section 4.1).  A/B comparisons and regression tests; process-wide. */
 int surs_set_grid_kernel(int version);
 
+/* How many of the 1024 layer-0 channels the default column kernels (layer 1 restated along the column) would
+ * list per z tile (`tile` = 128 for the reduced precisions, 64 for SURS_F32) on this sweep: evaluated on the ry columns of axis-0
+ * plane `i_plane` of the grid `mat` describes - every slab of one grid gives the same answer.  listed[0]: mean over (column,
+ * tile) for the lr classifier, listed[1]: an upper bound for the hr classifier; both -1 where the column kernels do not apply.
+ * `listed` is host memory; the call synchronises the stream.  The host mirror runs the dense column kernels (version 3 / 5) when
+ * listed[0] exceeds 400.  Workspace as for surs_query_grid. */
+int surs_query_grid_probe(int i_plane, int ry, int rz, int tile, const double *mat, const float *calib, float zmul, float zdiv,
+                          const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,
+                          void *workspace, size_t workspace_bytes, float *listed, void *stream);
+
 /* bytes of device workspace the two query entry points need for `max_points` points per call / grid batch */
 size_t surs_query_workspace_bytes(int max_points);
 

@@ -68,6 +68,7 @@ _SIGS = {
     "surs_query_views_workspace_bytes": (_sz, [_i, _i]),
     "surs_query_grid": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "surs_query_grid_workspace_bytes": (_sz, [_i, _i, _i]),
+    "surs_query_grid_probe": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "surs_octree_select": (C.c_int, [_vp, _i, _i, _vp, _i, _vp, C.POINTER(C.c_int), _vp]),
     "surs_query_grid_indexed": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "surs_octree_scatter": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

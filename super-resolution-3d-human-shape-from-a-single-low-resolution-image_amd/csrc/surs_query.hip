@@ -1203,6 +1203,92 @@ static int grid_set_attributes() {
     return 0;
 }
 
+// Column constants of a batch of columns (src.mode = 2, src.base = first column): F = gathered features, cmask, and
+// CC[col][2944] = Wc^T F[:, col] + bc - the split-operand layer kernel in its transposed-output form on the split image of F
+// (SURS_GEMM_X3=0 / SURS_GEMM_BIG=0: the older kernels on the fp32 F).  Workspace carved by the caller (col_base_bytes).
+static int column_constants(hipStream_t st, const PointSource &src, long long nc, long long ncp, const float *feat_lr, int hl, int wl,
+                            const float *feat_hr, int hh, int wh, const char *blob, const MlpBlobHeader &h, float *F, float *CC,
+                            float *cmask) {
+    int rc = 0;
+    const bool split = gemm_use_x3() && gemm_use_big();
+    const int parts = split_parts();
+    unsigned short *Fs = (unsigned short *)(cmask + COL_BATCH);
+    const long long fs_part = (long long)C0PAD * COL_BATCH;
+    if (parts == 2)
+        hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
+    else
+        hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+                           feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
+    SURS_LAUNCH_CHECK();
+    if (split) {
+        if ((rc = g3_set_attributes())) return rc;
+        SplitSeg s1 = {Fs, fs_part, C_G / 16}, s2 = {nullptr, 0, 0};
+        const int nb256 = (int)(ncp / 256);
+        if (parts == 2)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T, 2>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128, 2),
+                               st, (const unsigned short *)(blob + h.wc2), CC_PAD, C_G, s1, s2, COL_BATCH,
+                               (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
+        else
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128),
+                               st, (const unsigned short *)(blob + h.wc3), CC_PAD, C_G, s1, s2, COL_BATCH,
+                               (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
+        SURS_LAUNCH_CHECK();
+    } else {
+        rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
+                         (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// One workgroup per column: how many layer-0 channels the restated column kernels (v7 / v8) would list per z tile - the
+// classification of grid_mlp_v7 with the hr classifier's p range taken as [0, 1] (an upper bound).  out[0] += lr, out[1] += hr.
+__global__ __launch_bounds__(256) void probe_count_kernel(const float *__restrict__ cc, const float *__restrict__ zvec, int rz, int tile,
+                                                          double z0, double dz, float c22, float c23, float zmul, float zdiv, float zmid,
+                                                          unsigned long long *__restrict__ out) {
+    const int tid = threadIdx.x;
+    const float *row = cc + (size_t)blockIdx.x * CC_PAD;
+    const f32x4 al = *reinterpret_cast<const f32x4 *>(row + CC_A0_LR + 4 * tid), ah = *reinterpret_cast<const f32x4 *>(row + CC_A0_HR + 4 * tid);
+    const f32x4 zl = *reinterpret_cast<const f32x4 *>(zvec + ZV_W0Z_LR + 4 * tid), zh = *reinterpret_cast<const f32x4 *>(zvec + ZV_W0Z_HR + 4 * tid);
+    const f32x4 ph = *reinterpret_cast<const f32x4 *>(zvec + ZV_W0P_HR + 4 * tid);
+    auto zf_of = [&](int k) {
+        const double zt = dz * (double)k;
+        const float zw = (float)(zt + z0);
+        const float Z = c23 + c22 * zw;
+        return Z * zmul / zdiv;
+    };
+    unsigned nl = 0, nh = 0;
+    for (int k0 = 0; k0 < rz; k0 += tile) {
+        const float e0 = zf_of(k0), e1 = zf_of(k0 + tile - 1);
+        const float zlo = fminf(e0, e1), zhi = fmaxf(e0, e1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            {
+                const float xm = fmaf(zmid, zl[i], al[i]);
+                const float t0 = zl[i] * zlo, t1 = zl[i] * zhi;
+                const float mn = al[i] + fminf(t0, t1), mx = al[i] + fmaxf(t0, t1);
+                nl += ((xm > 0.0f) ? (mn > 0.0f) : (mx <= 0.0f)) ? 0u : 1u;
+            }
+            {
+                const float xm = fmaf(0.5f, ph[i], fmaf(zmid, zh[i], ah[i]));
+                const float t0 = zh[i] * zlo, t1 = zh[i] * zhi;
+                const float mn = ah[i] + fminf(t0, t1) + fminf(0.0f, ph[i]), mx = ah[i] + fmaxf(t0, t1) + fmaxf(0.0f, ph[i]);
+                nh += ((xm > 0.0f) ? (mn > 0.0f) : (mx <= 0.0f)) ? 0u : 1u;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nl += __shfl_xor(nl, d);
+        nh += __shfl_xor(nh, d);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(out, (unsigned long long)nl);
+        atomicAdd(out + 1, (unsigned long long)nh);
+    }
+}
+
 extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
                                float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
                                const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *vol_hr,
@@ -1286,37 +1372,8 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
         const long long ncp = (long long)ceil_div(nc, 256) * 256;   // <= COL_BATCH; rows nc.. of CC are never read
         src.base = (long long)i0 * ry + c0;
-        // column constants CC[col][2944] = Wc^T F[:, col] + bc: the split-bf16 layer kernel in its transposed-output form
-        // on the split image of F (SURS_GEMM_X3=0 / SURS_GEMM_BIG=0: the older kernels on the fp32 F)
-        const bool split = gemm_use_x3() && gemm_use_big();
         const int parts = split_parts();
-        unsigned short *Fs = (unsigned short *)(cmask + COL_BATCH);
-        const long long fs_part = (long long)C0PAD * COL_BATCH;
-        if (parts == 2)
-            hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
-                               feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
-        else
-            hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
-                               feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
-        SURS_LAUNCH_CHECK();
-        if (split) {
-            if ((rc = g3_set_attributes())) return rc;
-            SplitSeg s1 = {Fs, fs_part, C_G / 16}, s2 = {nullptr, 0, 0};
-            const int nb256 = (int)(ncp / 256);
-            if (parts == 2)
-                hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T, 2>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128, 2),
-                                   st, (const unsigned short *)(blob + h.wc2), CC_PAD, C_G, s1, s2, COL_BATCH,
-                                   (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
-            else
-                hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32_T>), dim3(gemm_grid(CC_PAD / 128, nb256)), dim3(512), g3_lds_bytes(128),
-                                   st, (const unsigned short *)(blob + h.wc3), CC_PAD, C_G, s1, s2, COL_BATCH,
-                                   (const float *)(blob + h.bc), CC, (long long)CC_PAD, (unsigned short *)nullptr, 0LL, nb256);
-            SURS_LAUNCH_CHECK();
-        } else {
-            rc = launch_gemm(st, true, (const float *)(blob + h.wc), blob + h.wc3, CC_PAD, F, C_G, COL_BATCH, nullptr, 0, 0,
-                             (const float *)(blob + h.bc), 0, CC, CC_PAD, ncp);
-            if (rc) return rc;
-        }
+        if ((rc = column_constants(st, src, nc, ncp, feat_lr, hl, wl, feat_hr, hh, wh, blob, h, F, CC, cmask))) return rc;
         GridArgs a;
         a.cc = CC;
         a.colmask = cmask;
@@ -1472,6 +1529,58 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             g_prof.pts.push_back((double)nc * rz);
         }
     }
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// How many of the 1024 layer-0 channels would the restated column kernels list per z tile on this sweep?  Evaluated on the
+// columns of ONE axis-0 plane of the grid (any slab of the same grid gives the same answer, so the ranks of a sharded sweep
+// agree): mean listed channels per (column, tile) for the lr classifier and an upper bound (p_lr range taken as [0, 1]) for
+// the hr classifier.  listed[0] = listed[1] = -1 where the column kernels do not apply (general calibration).  Synchronises
+// the stream.  The host uses it to fall back to the dense column kernels on fields that list most channels.
+// ------------------------------------------------------------------------------------------------
+extern "C" int surs_query_grid_probe(int i_plane, int ry, int rz, int tile, const double *mat, const float *calib, float zmul,
+                                     float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                                     const void *mlp_blob, void *workspace, size_t workspace_bytes, float *listed, void *stream) {
+    SURS_REQUIRE(mat && calib && feat_lr && feat_hr && mlp_blob && workspace && listed, "null argument");
+    SURS_REQUIRE(ry > 0 && rz > 0 && i_plane >= 0 && (tile == 64 || tile == 128), "bad probe arguments");
+    SURS_REQUIRE(ry <= COL_BATCH, "probe plane wider than a column batch");
+    SURS_REQUIRE(workspace_bytes >= col_ws_bytes(COL_BATCH), "workspace too small");
+    listed[0] = listed[1] = -1.0f;
+    const float cX = (float)(calib[0] * mat[2] + calib[1] * mat[6] + calib[2] * mat[10]);
+    const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
+    if (cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f) return 0;
+    hipStream_t st = as_stream(stream);
+    const MlpBlobHeader h = blob_layout(SURS_BF16);
+    const char *blob = (const char *)mlp_blob;
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.ry = ry;
+    src.rz = rz;
+    for (int i = 0; i < 12; ++i) src.mat[i] = mat[i];
+    fill_calib(src, calib, zmul, zdiv);
+    src.mode = 2;
+    src.base = (long long)i_plane * ry;
+    float *F = (float *)workspace;
+    float *CC = F + (size_t)C0PAD * COL_BATCH;
+    float *cmask = CC + (size_t)CC_PAD * COL_BATCH;
+    const long long nc = ry, ncp = (long long)ceil_div(nc, 256) * 256;
+    int rc = column_constants(st, src, nc, ncp, feat_lr, hl, wl, feat_hr, hh, wh, blob, h, F, CC, cmask);
+    if (rc) return rc;
+    unsigned long long *ctr = (unsigned long long *)((char *)workspace + col_base_bytes(COL_BATCH));
+    SURS_HIP_CHECK(hipMemsetAsync(ctr, 0, 16, st));
+    const float zw = (float)(mat[10] * (double)(rz / 2) + mat[11]);
+    const float zmid = (calib[11] + calib[10] * zw) * zmul / zdiv;
+    hipLaunchKernelGGL(probe_count_kernel, dim3((unsigned)nc), dim3(256), 0, st, CC, (const float *)(blob + h.zvec), rz, tile, mat[11], mat[10],
+                       calib[10], calib[11], zmul, zdiv, zmid, ctr);
+    SURS_LAUNCH_CHECK();
+    unsigned long long v[2] = {0, 0};
+    SURS_HIP_CHECK(hipMemcpyAsync(v, ctr, 16, hipMemcpyDeviceToHost, st));
+    SURS_HIP_CHECK(hipStreamSynchronize(st));
+    const double denom = (double)nc * (double)((rz + tile - 1) / tile);
+    listed[0] = (float)((double)v[0] / denom);
+    listed[1] = (float)((double)v[1] / denom);
     return 0;
 }
 

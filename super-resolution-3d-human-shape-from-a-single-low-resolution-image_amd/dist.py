@@ -152,10 +152,12 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
     planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
     sweep = torch.cuda.current_stream(dev)
     done, ex = [], None
+    kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws)   # (probes the whole grid: every rank the same)
     for a in range(0, nloc, planes):
         b = min(nloc, a + planes)
         try:
-            native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b])
+            native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b],
+                              kernel=kern)
         except native._lib.SursError as e:
             if e.code != -3:
                 raise

@@ -30,9 +30,12 @@ def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=Non
     if prec not in ("fp32", "fp32x") and native.DTYPES[prec] != net._core_dtype:
         raise ValueError("network was packed for %s, reconstruction asked for %s: set opt.precision before loading" %
                          (net.precision, prec))
+    # (the dense column kernels where the sweep lists most channels: the same choice for every slab of this grid)
+    kern = native.grid_kernel_for(resolution, resolution, resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec,
+                                  net._workspace())
     try:
         vh, vl = native.query_grid(i0, i1, resolution, resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec,
-                                   net._workspace())
+                                   net._workspace(), kernel=kern)
     except native._lib.SursError as e:
         if e.code != -3:
             raise
@@ -164,10 +167,12 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
     # the whole sweep is enqueued first (no host synchronisation in it), with an event behind every slab ...
     sweep = torch.cuda.current_stream(dev)
     done = []
+    kern = native.grid_kernel_for(R, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws)
     for i0 in range(0, R, planes):
         i1 = min(R, i0 + planes)
         try:
-            native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1])
+            native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1],
+                              kernel=kern)
         except native._lib.SursError as e:
             if e.code != -3:
                 raise

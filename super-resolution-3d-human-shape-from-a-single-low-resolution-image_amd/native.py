@@ -301,8 +301,9 @@ def query_points_views(points, calibs, projection, zmul, zdiv, feat_lr, feat_hr,
     return (phr, plr, lg[0], lg[1]) if want_logits else (phr, plr)
 
 
-def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None):
-    """Dense sweep of grid slab [i0, i1): returns (vol_hr, vol_lr) float32 device tensors [(i1-i0), ry, rz]."""
+def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None, kernel=0):
+    """Dense sweep of grid slab [i0, i1): returns (vol_hr, vol_lr) float32 device tensors [(i1-i0), ry, rz].
+    kernel: column-kernel version for this call (grid_kernel_for's choice; 0 = the library's default / process setting)."""
     dev = blob.device
     if vol_hr is None:
         vol_hr = torch.empty((i1 - i0, ry, rz), dtype=torch.float32, device=dev)
@@ -312,10 +313,53 @@ def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, d
     code = DTYPES[dtype] if isinstance(dtype, str) else dtype
     need = lib().surs_query_grid_workspace_bytes(ry, rz, code)
     w = ws.get(need)
-    check(lib().surs_query_grid(i0, i1, ry, rz, m, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
-                                feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), code, _ptr(w), w.numel(), _ptr(vol_hr),
-                                _ptr(vol_lr), _stream()))
+    if kernel:
+        check(lib().surs_set_grid_kernel(int(kernel)))
+    try:
+        check(lib().surs_query_grid(i0, i1, ry, rz, m, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
+                                    feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), code, _ptr(w), w.numel(), _ptr(vol_hr),
+                                    _ptr(vol_lr), _stream()))
+    finally:
+        if kernel:
+            lib().surs_set_grid_kernel(0)
     return vol_hr, vol_lr
+
+
+LISTED_DENSE_THRESHOLD = 400.0   # mean listed channels per tile above which the dense column kernels are the faster ones
+
+
+def probe_listed(i_plane, ry, rz, tile, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws):
+    """surs_query_grid_probe: (mean listed layer-0 channels per z tile for the lr classifier, upper bound for hr), or
+    (-1, -1) where the column kernels do not apply.  Synchronises the stream."""
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    need = lib().surs_query_grid_workspace_bytes(ry, rz, DTYPES["bf16"])
+    w = ws.get(need)
+    out = (C.c_float * 2)(-1.0, -1.0)
+    check(lib().surs_query_grid_probe(int(i_plane), ry, rz, tile, m, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h,
+                                      feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), _ptr(w), w.numel(), out, _stream()))
+    return float(out[0]), float(out[1])
+
+
+def grid_kernel_for(rx, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws):
+    """Column-kernel version for a sweep of the rx x ry x rz grid `mat` describes: 0 (the library's default: layer 1 restated
+    along the column) unless the probe says the sweep lists so many channels per tile that the dense kernels (3 for bf16 /
+    fp16, 5 for fp32) are faster.  A deterministic function of the grid, the calibration, the features and
+    the weights - the middle axis-0 plane of the WHOLE grid is probed, so every slab and every rank of a sharded sweep makes
+    the same choice.  Cached per workspace; SURS_GRID_AUTO=0 or an explicit SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL turn it off."""
+    if os.environ.get("SURS_GRID_AUTO", "1") == "0" or "SURS_GRID_KERNEL" in os.environ or "SURS_GRID_F32_KERNEL" in os.environ:
+        return 0
+    if dtype not in ("fp32", "bf16", "fp16") or ry > 16384:
+        return 0
+    key = (feat_lr.buf.data_ptr(), feat_lr.buf._version, feat_hr.buf.data_ptr(), feat_hr.buf._version, blob.data_ptr(), blob._version,
+           np.asarray(calib, np.float32).tobytes(), np.asarray(mat, np.float64).tobytes(), dtype, rx, ry, rz, float(zmul), float(zdiv))
+    cache = getattr(ws, "_kernel_choice", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    lr, _ = probe_listed(rx // 2, ry, rz, 64 if dtype == "fp32" else 128, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
+    kern = (5 if dtype == "fp32" else 3) if lr > LISTED_DENSE_THRESHOLD else 0
+    ws._kernel_choice = (key, kern, lr)
+    return kern
 
 
 # ------------------------------------------------------------------ marching cubes

@@ -388,3 +388,47 @@ def test_sweep_edge_geometries_vs_point_path(setup, dtype, tol):
         if dtype == "fp32":
             ok = (phr > 0) & (phr < 1)
             assert (lg(vh.reshape(-1)[ok]) - lhr.double()[ok]).abs().max().item() < 1e-4
+
+
+def test_dense_kernels_chosen_where_most_channels_are_listed(setup):
+    """native.grid_kernel_for (what reconstruction / reconstruction_streamed / reconstruction_sharded ask before a sweep): the
+    library default (layer 1 restated along the column) for the ordinary field, the dense column kernels (3 / 5) for a field in
+    which nearly every layer-0 channel changes branch inside a z tile (the depth weights of layer 0 scaled by 60) - there the
+    restated kernels would be the slower ones.  The probe looks at the middle plane of the whole grid, so a slab gets the same
+    answer; the chosen kernel's result equals the explicitly selected kernel's bit for bit."""
+    import oracle
+    from surs_amd import _lib
+    nat, g = setup["native"], setup["g"]
+    L = _lib.lib()
+    R = 96
+    mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+    cal = common.CALIB.reshape(-1)[:12]
+    ws = setup["ws"]
+    R2 = 256
+    mat2 = oracle.coords_matrix(R2, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+    for prec in ("bf16", "fp32"):
+        blob = g.blob("bf16")
+        assert nat.grid_kernel_for(R2, R2, R2, mat2, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws) == 0
+        lr, hr = nat.probe_listed(R2 // 2, R2, R2, 64 if prec == "fp32" else 128, mat2, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, ws)
+        print(prec, "listed per tile at R=256: lr %.1f, hr bound %.1f" % (lr, hr))
+        assert 0 < lr < 300 and hr >= lr * 0.5, (lr, hr)
+    sd = {k: np.array(v, copy=True) for k, v in common.state_dict().items() if k.startswith("mlp_")}
+    for m in ("mlp_lr.", "mlp_hr."):
+        sd[m + "conv0.weight"][:, 320] *= 60.0
+    blob, _ = nat.pack_mlp(sd, "bf16", g.dev())
+    for prec, dense in (("bf16", 3), ("fp32", 5)):
+        kern = nat.grid_kernel_for(R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws)
+        assert kern == dense, (prec, kern, ws._kernel_choice[2])
+        a = [v.clone() for v in nat.query_grid(8, 40, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws, kernel=kern)]
+        try:
+            L.surs_set_grid_kernel(dense)
+            b = [v.clone() for v in nat.query_grid(8, 40, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws)]
+            L.surs_set_grid_kernel(7 if prec == "bf16" else 8)
+            c = nat.query_grid(8, 40, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws)
+        finally:
+            L.surs_set_grid_kernel(0)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # the restated kernels still agree on this field (many chunks per tile; its layer-0 activations are 60x the usual
+        # size, and so are the fp32 roundings: 1e-3 instead of the 1e-4 of the ordinary fields)
+        tol = 3e-2 if prec == "bf16" else 1e-3
+        assert (a[0] - c[0]).abs().max().item() < tol and (a[1] - c[1]).abs().max().item() < tol
