@@ -418,6 +418,7 @@ static int g3_set_attributes() {
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 2)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 1)));
     }
     return 0;
 }
@@ -1403,7 +1404,15 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
             }
             const long long part_lr = 2LL * ncp * D1, part_hr = 3LL * ncp * D1;
             const dim3 pg((unsigned)(ncp / 64), D1 / 64);
-            if (parts == 2)
+            // operand parts of this GEMM: the sweep's split (two f16 / three bf16 parts: fp32 grade) for the fp32-grade and the f16
+            // kernel; ONE f16 part for the bf16 kernel - 11 significant bits, 8x what bf16 gives the rest of the classifier, a third
+            // of the MFMA work, no measurable change of the bf16 sweep's error (SURS_R_PARTS=0: the split's parts there too)
+            static const int r_parts_env = getenv("SURS_R_PARTS") ? atoi(getenv("SURS_R_PARTS")) : 1;
+            const int rparts = (dtype == SURS_BF16 && r_parts_env == 1) ? 1 : parts;
+            if (rparts == 1)
+                hipLaunchKernelGGL(colsum_prepare_kernel<1>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
+                                   g_lr, part_lr, g_hr, part_hr);
+            else if (rparts == 2)
                 hipLaunchKernelGGL(colsum_prepare_kernel<2>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
                                    g_lr, part_lr, g_hr, part_hr);
             else
@@ -1416,7 +1425,11 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                 SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
                 const int nb256 = (int)(npm / 256);
                 float *R = m ? r_hr : r_lr;
-                if (parts == 2)
+                if (rparts == 1)   // (the first part of the two-part weight image is f16(w))
+                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 1>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 1),
+                                       st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
+                                       (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
+                else if (rparts == 2)
                     hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 2>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 2),
                                        st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
                                        (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
