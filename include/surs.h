@@ -12,7 +12,7 @@
  *   surs_avgpool2             F.avg_pool2d(x,2,2)        lib/model/HGFilters.py:101
  *   surs_bicubic_up2          bicubic x2, both alignments lib/model/HGFilters.py:115, lib/model/SuRSSR_v3.py:140
  *   surs_pixel_shuffle2       PixelShuffle(2)+LeakyReLU   lib/model/SuRSSR_v3.py:111-115
- *   surs_axpby / surs_add3    residual adds / cat         lib/model/HGFilters.py:66-74,117,203-206
+ *   surs_add3                 residual adds / cat         lib/model/HGFilters.py:66-74,117,203-206
  *   surs_query_points         query_mr+query_sr+get_preds lib/model/SuRSNet.py:131-187, lib/model/BaseSuRSNet.py:80-85,
  *                                                        lib/geometry.py:4-31, lib/model/DepthNormalizer.py:18,
  *                                                        lib/model/SurfaceClassifier.py:53-81
@@ -132,8 +132,10 @@ size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], con
  * range), 0 = back to the default (or the SURS_SPLIT environment variable).  Both meet the 1e-4 logit tolerance. */
 int surs_set_operand_split(int parts);
 
-/* Reduced-precision column kernel of surs_query_grid: 0 = default (or the SURS_GRID_KERNEL environment variable), 1-4, 7
- * (DESIGN.md section 4.1).  A/B comparisons and regression tests; process-wide. */
+/* Column kernel of surs_query_grid, process-wide (A/B comparisons and regression tests; a per-call choice goes through
+ * surs_query_grid_opt): 0 = default (or the SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL environment variables); reduced precision
+ * 3 (dense layer 1), 7, 10 (layer 1 restated along the column, four / eight waves); fp32-grade 5 (dense), 8 (restated) -
+ * DESIGN.md section 4.1. */
 int surs_set_grid_kernel(int version);
 
 /* How many of the 1024 layer-0 channels the default column kernels (layer 1 restated along the column) would
@@ -185,6 +187,21 @@ int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const flo
                     const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,
                     int dtype, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr, void *stream);
 size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype);
+
+/* The same sweep with per-call choices instead of process-wide ones (nothing global is read for a field that is set, nothing
+ * global is written): `kernel` = column-kernel version (0 = the process setting / default; reduced precision 3, 7, 10;
+ * fp32-grade 5, 8 - DESIGN.md 4.1), `operand_parts` = operand split of the fp32-grade GEMMs behind the sweep (0 = process
+ * setting, 2 = two f16 parts, 3 = three bf16 parts).  opt == NULL behaves as surs_query_grid.  Safe to call from several host
+ * threads on different streams. */
+typedef struct SursGridOptions {
+    int kernel;
+    int operand_parts;
+    int reserved[6];   /* must be zero */
+} SursGridOptions;
+int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul, float zdiv,
+                        const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,
+                        int dtype, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr,
+                        const SursGridOptions *opt, void *stream);
 
 /* Octree sweep (eval_grid_octree, lib/sdf.py:55-120), one level at a time; volumes are float64 [R][R][R] like the
  * reference's numpy arrays, `dirty` is uint8 [R][R][R].

@@ -34,6 +34,11 @@ class NonFiniteVolumeError(FloatingPointError):
     kernels (fp32's exponent range)."""
 
 
+class GridOptions(C.Structure):
+    """SursGridOptions of include/surs.h: per-call column kernel / operand split of surs_query_grid_opt."""
+    _fields_ = [("kernel", C.c_int), ("operand_parts", C.c_int), ("reserved", C.c_int * 6)]
+
+
 class McCounts(C.Structure):
     _fields_ = [("n_verts", C.c_int32), ("n_faces", C.c_int32), ("vmin", C.c_float), ("vmax", C.c_float)]
 
@@ -67,6 +72,8 @@ _SIGS = {
                                           _vp, _vp]),
     "surs_query_views_workspace_bytes": (_sz, [_i, _i]),
     "surs_query_grid": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
+    "surs_query_grid_opt": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp,
+                                      C.POINTER(GridOptions), _vp]),
     "surs_query_grid_workspace_bytes": (_sz, [_i, _i, _i]),
     "surs_query_grid_probe": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "surs_octree_select": (C.c_int, [_vp, _i, _i, _vp, _i, _vp, C.POINTER(C.c_int), _vp]),

@@ -392,14 +392,15 @@ static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const v
 // Operand split of the 256-point layer kernels (SplitKind): two f16 parts (default: three products per MAC, 4 bytes per value;
 // |x| < 65504) or, with SURS_SPLIT=bf16x3, three bf16 parts (six products, 6 bytes, fp32's exponent range).  The older layer
 // kernels (SURS_GEMM_BIG=0 / SURS_GEMM_X3=0) only know the bf16 form.
-static int g_split_override = 0;   // surs_set_operand_split
+static int g_split_override = 0;   // surs_set_operand_split (process-wide)
+static thread_local int t_split_call = 0;   // SursGridOptions::operand_parts of the surs_query_grid_opt call running on this thread
 static int split_parts() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("SURS_SPLIT");
         v = (e && e[0] == 'b') ? 3 : 2;
     }
-    const int want = g_split_override ? g_split_override : v;
+    const int want = t_split_call ? t_split_call : (g_split_override ? g_split_override : v);
     return (gemm_use_x3() && gemm_use_big()) ? want : 3;
 }
 
@@ -565,7 +566,6 @@ struct GridArgs {
     const float *colmask;  // [ncols]
     const float *zvec;     // [ZV_N]
     const char *core;      // SLABS_TOTAL slabs
-    const char *core16;    // the same cores in 16x16x32 fragment order (kernel v4)
     const char *corex;     // the same cores as two f16 parts per weight (kernel v5, fp32-grade)
     const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
     const char *w1t;       // layer-1 weights channel-major (kernel v7)
@@ -582,35 +582,7 @@ struct GridArgs {
     float zmul, zdiv;
 };
 
-constexpr int GRID_LDS_RING = 2 * SLAB_BYTES;
-constexpr int GRID_LDS_BYTES = GRID_LDS_RING + (CC_PAD + ZV_N) * 4;
-
 __device__ __forceinline__ float lrelu01(float x) { return fmaxf(x, 0.01f * x); }
-
-// every wave waits for its own LDS-DMA pieces, then the workgroup barrier publishes the slab
-__device__ __forceinline__ void slab_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-// Issue the LDS-DMA of the next 32 KiB slab of the weight stream: 4 waves x 8 pieces of 1 KiB (64 lanes x 16 B).
-// `gsrc` is this lane's running source pointer (stream base + wave*8192 + lane*16); it advances by one slab per
-// call and wraps after SLABS_TOTAL, so no slab address is loop invariant (hipcc would hoist and spill hundreds).
-struct SlabStream {
-    const char *gsrc;
-    int count;  // slabs issued since the last wrap
-};
-__device__ __forceinline__ void stage_slab(SlabStream &st, char *lds_dst_wave) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(st.gsrc + i * 1024),
-                                         (__attribute__((address_space(3))) void *)(lds_dst_wave + i * 1024), 16, 0, 0);
-    st.gsrc += SLAB_BYTES;
-}
-
-// LDS byte offsets of the constant region (after the slab ring)
-constexpr int LDS_CC = GRID_LDS_RING;             // column constants [CC_PAD] fp32
-constexpr int LDS_ZV = GRID_LDS_RING + CC_PAD * 4;  // z-vectors [ZV_N] fp32
 
 // All LDS addresses in the hot loops are (one per-lane base register) + (compile-time immediate): the per-lane
 // parts are made opaque so that hipcc neither re-associates them into hundreds of distinct hoisted address
@@ -620,197 +592,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
     return v;
 }
 
-template <int DT, int M /* 0 lr, 1 hr */>
-__device__ __forceinline__ float grid_mlp(SlabStream &st, char *smem, int wave, int lane, float zf, float p_in) {
-    typedef HalfT<DT> H;
-    typedef typename H::vec8 vec8;
-    constexpr int A0 = LDS_CC + 4 * (M ? CC_A0_HR : CC_A0_LR), A2 = LDS_CC + 4 * (M ? CC_A2_HR : CC_A2_LR),
-                  A3 = LDS_CC + 4 * (M ? CC_A3_HR : CC_A3_LR), A4 = LDS_CC + 4 * (M ? CC_A4_HR : CC_A4_LR);
-    constexpr int W0Z = LDS_ZV + 4 * (M ? ZV_W0Z_HR : ZV_W0Z_LR), W0P = LDS_ZV + 4 * ZV_W0P_HR,
-                  B1 = LDS_ZV + 4 * (M ? ZV_B1_HR : ZV_B1_LR), W2Z = LDS_ZV + 4 * (M ? ZV_W2Z_HR : ZV_W2Z_LR),
-                  W2P = LDS_ZV + 4 * ZV_W2P_HR, W3Z = LDS_ZV + 4 * (M ? ZV_W3Z_HR : ZV_W3Z_LR),
-                  W3P = LDS_ZV + 4 * ZV_W3P_HR, W4C = LDS_ZV + 4 * (M ? ZV_W4C_HR : ZV_W4C_LR),
-                  W4Z = LDS_ZV + 4 * (M ? ZV_W4Z_HR : ZV_W4Z_LR), W4P = LDS_ZV + 4 * ZV_W4P_HR;
-    const unsigned h16 = opaque((unsigned)(lane >> 5) * 16u);   // accumulator rows: channel 4h within a group of 8
-    const unsigned lane16 = opaque((unsigned)lane * 16u);       // A fragments: 16 B per lane
-    char *cst = smem + h16;                                     // + immediate: constants indexed by channel
-    char *frag = smem + lane16;                                 // + immediate: fragment (ks, T) of a slab
-    char *dma = smem + opaque((unsigned)wave * 8192u);          // + immediate: this wave's share of a ring buffer
-    auto ld4 = [&](int byte_off) { return *reinterpret_cast<const f32x4 *>(cst + byte_off); };
-    auto ldfrag = [&](int byte_off) { return *reinterpret_cast<const vec8 *>(frag + byte_off); };
-
-    // ---------------- layer 1: 1024 -> 512, B operand generated on the fly from the column constants
-    // accumulator register r of row tile T is channel 32T + (r&3) + 8(r>>2) + 4h: 4 consecutive per group g = r>>2
-    f32x16 acc[16];
-#pragma unroll
-    for (int T = 0; T < 16; ++T)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = ld4(B1 + 4 * (32 * T + 8 * g));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[T][4 * g + r] = b[r];
-        }
-#pragma unroll 1
-    for (int sl = 0; sl < SLABS_L1; sl += 2) {
-        // channels of this lane's B fragment: 16*(2*(sl+half)+ks) + 8h + j  ->  bytes 128*sl + 2*h16 + imm
-        char *kb = smem + opaque(128u * (unsigned)sl + 2u * h16);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            stage_slab(st, dma + (half ^ 1) * SLAB_BYTES);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int imm = 64 * (2 * half + ks) + 16 * q;
-                    const f32x4 c = *reinterpret_cast<const f32x4 *>(kb + A0 + imm);
-                    const f32x4 wz = *reinterpret_cast<const f32x4 *>(kb + W0Z + imm);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaf(zf, wz[r], c[r]);
-                    if (M) {
-                        const f32x4 wp = *reinterpret_cast<const f32x4 *>(kb + W0P + imm);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[4 * q + r] = fmaf(p_in, wp[r], v[4 * q + r]);
-                    }
-                }
-                vec8 bfrag;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bfrag[j] = (typename H::elem)lrelu01(v[j]);
-#pragma unroll
-                for (int T = 0; T < 16; ++T)
-                    acc[T] = H::mfma(ldfrag(half * SLAB_BYTES + (ks * 16 + T) * 1024), bfrag, acc[T]);
-            }
-            slab_barrier();
-        }
-    }
-    // y1 as B fragments: k-step s' = 2T + u takes registers 8u..8u+7 of tile T
-    vec8 y1[32];
-#pragma unroll
-    for (int T = 0; T < 16; ++T)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y1[2 * T + u][j] = (typename H::elem)lrelu01(acc[T][8 * u + j]);
-
-    // ---------------- layer 2 core: 512 -> 256, accumulator preloaded with the column/z part
-    f32x16 acc2[8];
-#pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int off = 4 * (32 * T + 8 * g);
-            const f32x4 c = ld4(A2 + off), wz = ld4(W2Z + off);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc2[T][4 * g + r] = fmaf(zf, wz[r], c[r]);
-            if (M) {
-                const f32x4 wp = ld4(W2P + off);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc2[T][4 * g + r] = fmaf(p_in, wp[r], acc2[T][4 * g + r]);
-            }
-        }
-#pragma unroll
-    for (int sl = 0; sl < SLABS_L2; ++sl) {
-        stage_slab(st, dma + ((sl & 1) ^ 1) * SLAB_BYTES);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int T = 0; T < 8; ++T)
-                acc2[T] = H::mfma(ldfrag((sl & 1) * SLAB_BYTES + (ks * 8 + T) * 1024), y1[4 * sl + ks], acc2[T]);
-        slab_barrier();
-    }
-    vec8 y2[16];
-#pragma unroll
-    for (int T = 0; T < 8; ++T)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y2[2 * T + u][j] = (typename H::elem)lrelu01(acc2[T][8 * u + j]);
-
-    // ---------------- layer 3 core: 256 -> 128
-    f32x16 acc3[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int off = 4 * (32 * T + 8 * g);
-            const f32x4 c = ld4(A3 + off), wz = ld4(W3Z + off);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc3[T][4 * g + r] = fmaf(zf, wz[r], c[r]);
-            if (M) {
-                const f32x4 wp = ld4(W3P + off);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc3[T][4 * g + r] = fmaf(p_in, wp[r], acc3[T][4 * g + r]);
-            }
-        }
-#pragma unroll
-    for (int sl = 0; sl < SLABS_L3; ++sl) {
-        // the slab after this MLP's last one is the first slab of the other MLP (the stream wraps around)
-        stage_slab(st, dma + ((sl & 1) ^ 1) * SLAB_BYTES);
-        if (M == 1 && sl == SLABS_L3 - 2) st.gsrc -= (size_t)SLABS_TOTAL * SLAB_BYTES;  // next stage fetches slab 0
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int T = 0; T < 4; ++T)
-                acc3[T] = H::mfma(ldfrag((sl & 1) * SLAB_BYTES + (ks * 4 + T) * 1024), y2[8 * sl + ks], acc3[T]);
-        slab_barrier();
-    }
-    // ---------------- layer 4: 128 -> 1 on the VALU (fp32); the two halves of the channel set live in lanes l, l^32
-    float part = 0.0f;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 w = ld4(W4C + 4 * (32 * T + 8 * g));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part = fmaf(w[r], lrelu01(acc3[T][4 * g + r]), part);
-        }
-    part += __shfl_xor(part, 32);
-    float y4 = fmaf(zf, *reinterpret_cast<const float *>(smem + W4Z), *reinterpret_cast<const float *>(smem + A4));
-    if (M) y4 = fmaf(p_in, *reinterpret_cast<const float *>(smem + W4P), y4);
-    return y4 + part;
-}
-
-template <int DT>
-__global__ __launch_bounds__(256, 1) void grid_mlp_kernel(GridArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *colc = reinterpret_cast<float *>(smem + GRID_LDS_RING);
-    float *zv = colc + CC_PAD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < ZV_N; i += 256) zv[i] = a.zvec[i];
-    // first slab of the stream
-    SlabStream st;
-    st.gsrc = a.core + wave * 8192 + lane * 16;
-    st.count = 0;
-    stage_slab(st, smem + wave * 8192);
-    const int nzc = (a.rz + 127) / 128;
-    for (int col = blockIdx.x; col < a.ncols; col += gridDim.x) {
-        __syncthreads();  // everyone is done with the previous column's constants (and slab 0 has landed)
-        const float *src = a.cc + (size_t)col * CC_PAD;
-        for (int i = tid; i < CC_N; i += 256) colc[i] = src[i];
-        const float cmask = a.colmask[col];
-        __syncthreads();
-        for (int zc = 0; zc < nzc; ++zc) {
-            const int k = zc * 128 + wave * 32 + (lane & 31);
-            const double zt = a.dz * (double)k;
-            const float zw = (float)(zt + a.z0);
-            const float Z = a.c23 + a.c22 * zw;
-            const float zf = Z * a.zmul / a.zdiv;
-            const float l_lr = grid_mlp<DT, 0>(st, smem, wave, lane, zf, 0.0f);
-            const float p_lr = cmask * (1.0f / (1.0f + expf(-l_lr)));
-            const float l_hr = grid_mlp<DT, 1>(st, smem, wave, lane, zf, p_lr);
-            const float p_hr = cmask * (1.0f / (1.0f + expf(-l_hr)));
-            if (k < a.rz) {
-                float *dst = (lane < 32) ? a.vol_lr : a.vol_hr;
-                dst[(size_t)col * a.rz + k] = (lane < 32) ? p_lr : p_hr;
-            }
-        }
-    }
-    __syncthreads();  // drain the last prefetch before the workgroup retires
-}
-
-#include "surs_grid_v2.inc"
 #include "surs_grid_v3.inc"
-#include "surs_grid_v4.inc"
 #include "surs_grid_v5.inc"
 #include "surs_grid_v7.inc"
 #include "surs_grid_v8.inc"
@@ -902,10 +684,14 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
     return 0;
 }
 
+#ifndef SURS_DEFAULT_GRID_KERNEL
+#define SURS_DEFAULT_GRID_KERNEL 7
+#endif
 static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
+static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 7 || v == 10 || v == 5 || v == 8; }
 extern "C" int surs_set_grid_kernel(int version) {
-    SURS_REQUIRE(version == 0 || (version >= 1 && version <= 5) || version == 7 || version == 8,
-                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 1-4 or 7, fp32-grade 5 or 8");
+    SURS_REQUIRE(grid_kernel_known(version),
+                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3, 7 or 10, fp32-grade 5 or 8");
     g_grid_kernel_override = version;
     return 0;
 }
@@ -1189,14 +975,8 @@ static bool grid_f32_use_columns() {
 static int grid_set_attributes() {
     static DeviceOnce attr;
     if (!attr.first()) return 0;
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v2<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID2_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v4<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, GRID5_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
@@ -1290,10 +1070,44 @@ __global__ __launch_bounds__(256) void probe_count_kernel(const float *__restric
     }
 }
 
+static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
+                           float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                           const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *vol_hr,
+                           float *vol_lr, int kernel_call, void *stream);
+
+extern "C" int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
+                                   float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                                   const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *vol_hr,
+                                   float *vol_lr, const SursGridOptions *opt, void *stream) {
+    int kernel = 0, parts = 0;
+    if (opt) {
+        kernel = opt->kernel;
+        parts = opt->operand_parts;
+        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 7, 10 (reduced precision), 5, 8 (fp32-grade)");
+        SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "SursGridOptions.operand_parts: 0, 2 or 3");
+    }
+    // the operand split is read deep inside the launch helpers: scoped to this call and this thread, the process setting
+    // (surs_set_operand_split) is neither read nor changed when the caller gave one
+    const int saved = t_split_call;
+    t_split_call = parts;
+    const int rc = query_grid_impl(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, hl, wl, feat_hr, hh, wh, mlp_blob, dtype, workspace,
+                                   workspace_bytes, vol_hr, vol_lr, kernel, stream);
+    t_split_call = saved;
+    return rc;
+}
+
 extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
                                float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
                                const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *vol_hr,
                                float *vol_lr, void *stream) {
+    return query_grid_impl(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, hl, wl, feat_hr, hh, wh, mlp_blob, dtype, workspace,
+                           workspace_bytes, vol_hr, vol_lr, 0, stream);
+}
+
+static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
+                           float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                           const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *vol_hr,
+                           float *vol_lr, int kernel_call, void *stream) {
     SURS_REQUIRE(mat && calib && feat_lr && feat_hr && mlp_blob && workspace && vol_hr && vol_lr, "null argument");
     SURS_REQUIRE(i1 >= i0 && ry > 0 && rz > 0, "bad grid range");
     SURS_REQUIRE(dtype == SURS_F32 || dtype == SURS_BF16 || dtype == SURS_F16 || dtype == SURS_F32_GEMM, "unknown dtype %d", dtype);
@@ -1346,27 +1160,28 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    // Reduced precision: SURS_GRID_KERNEL / surs_set_grid_kernel select the column kernel: 7 (default) = v3 with layer 1 restated
-    // as a per-column affine part + the residuals of the channels whose LeakyReLU branch changes inside the z tile (1.9x v3,
-    // closer to the fp32 sweep); 3 = waves split the output channels, weights straight from L2 into registers, dense layer 1;
-    // 4 = the same on the 16x16x32 MFMA shape (experimental: higher clock, more cycles, +1 %); 2 = waves split the points,
-    // weights through an LDS-DMA ring; 1 = the simple one-barrier-per-slab form of 2.  1 and 2 are bit-identical and kept as
-    // the regression reference of 3, which differs from them only in the summation order of the final 128-term dot product;
-    // 7 differs from 3 by a few 16-bit roundings of layer 0.  SURS_F32: kernel v5 (split-f16 operands, fp32-grade).
+    // Column kernel of this sweep.  Reduced precision: 10 (default) = layer 1 restated along the column as a per-column affine
+    // part + the residuals of the channels whose LeakyReLU branch changes inside the z tile, eight waves per workgroup; 7 = the
+    // same arithmetic on four waves (its regression reference); 3 = dense layer 1 (what the host asks for on fields that list most
+    // channels; differs from 7 / 10 by a few 16-bit roundings of layer 0).  fp32-grade (SURS_F32): 8 (default, restated) or 5
+    // (dense).  Precedence: the call's SursGridOptions.kernel, then surs_set_grid_kernel, then SURS_GRID_KERNEL /
+    // SURS_GRID_F32_KERNEL, then the default.
     static int kver_env = -1;
     if (kver_env < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
-        kver_env = (e && ((e[0] >= '1' && e[0] <= '4') || e[0] == '7')) ? (e[0] - '0') : 7;
+        const int v = e ? atoi(e) : 0;
+        kver_env = (v == 3 || v == 7 || v == 10) ? v : SURS_DEFAULT_GRID_KERNEL;
     }
-    static int kver32_env = -1;   // fp32-grade column kernel: 8 (default: restated layer 1) or 5 (dense layer 1)
+    static int kver32_env = -1;
     if (kver32_env < 0) {
         const char *e = getenv("SURS_GRID_F32_KERNEL");
         kver32_env = (e && e[0] == '5') ? 5 : 8;
     }
-    const bool ov32 = g_grid_kernel_override == 5 || g_grid_kernel_override == 8;
-    const int kver = (g_grid_kernel_override && !ov32) ? g_grid_kernel_override : kver_env;
-    const int kver32 = ov32 ? g_grid_kernel_override : kver32_env;
-    const bool restated = dtype == SURS_F32 ? kver32 == 8 : kver == 7;
+    const auto is32 = [](int v) { return v == 5 || v == 8; };
+    int kver = kver_env, kver32 = kver32_env;
+    if (g_grid_kernel_override) (is32(g_grid_kernel_override) ? kver32 : kver) = g_grid_kernel_override;
+    if (kernel_call) (is32(kernel_call) ? kver32 : kver) = kernel_call;
+    const bool restated = dtype == SURS_F32 ? kver32 == 8 : (kver == 7 || kver == 10);
     if ((rc = grid_set_attributes())) return rc;
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
@@ -1380,7 +1195,6 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
         a.colmask = cmask;
         a.zvec = (const float *)(blob + h.zvec);
         a.core = blob + h.core;
-        a.core16 = blob + h.core16;
         a.corex = blob + h.corex;
         a.b1frag = blob + h.b1frag;
         a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
@@ -1493,28 +1307,15 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                 hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_BF16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
             else
                 hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_F16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
-        } else if (kver == 4) {
-            if (dtype == SURS_BF16)
-                hipLaunchKernelGGL(grid_mlp_kernel_v4<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
-            else
-                hipLaunchKernelGGL(grid_mlp_kernel_v4<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
-        } else if (kver == 3) {
+        } else {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
             else
                 hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
-        } else if (kver == 2) {
-            if (dtype == SURS_BF16)
-                hipLaunchKernelGGL(grid_mlp_kernel_v2<SURS_BF16>, dim3(grid), dim3(256), GRID2_LDS_BYTES, st, a);
-            else
-                hipLaunchKernelGGL(grid_mlp_kernel_v2<SURS_F16>, dim3(grid), dim3(256), GRID2_LDS_BYTES, st, a);
-        } else if (dtype == SURS_BF16)
-            hipLaunchKernelGGL(grid_mlp_kernel<SURS_BF16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
-        else
-            hipLaunchKernelGGL(grid_mlp_kernel<SURS_F16>, dim3(grid), dim3(256), GRID_LDS_BYTES, st, a);
+        }
         SURS_LAUNCH_CHECK();
 #ifdef SURS_V3_TRACE
-        if ((dtype == SURS_F32 || kver == 3 || kver == 4 || kver == 7) && c0 == 0 && getenv("SURS_V3_TRACE")) {
+        if ((dtype == SURS_F32 || kver == 3 || kver == 7) && c0 == 0 && getenv("SURS_V3_TRACE")) {
             unsigned long long t[64];
             SURS_HIP_CHECK(hipStreamSynchronize(st));
             SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));

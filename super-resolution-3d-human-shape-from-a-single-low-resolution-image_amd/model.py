@@ -218,11 +218,15 @@ class SuRSNet:
         # the same points as the preceding query_mr?  Decided without touching the data (a full-tensor compare is a device
         # synchronisation per call): the same tensor object, or the same storage / view / version
         ref, ver = self._mr_points, self._mr_version
-        same = (points is ref and points._version == ver) or (
+        if points is ref and points._version != ver:
+            raise NotImplementedError("the points tensor was modified in place between query_mr and query_sr: the fused "
+                                      "kernel has already fed each point its own lr prediction")
+        same = (points is ref) or (
             points.data_ptr() == ref.data_ptr() and points.shape == ref.shape and points.stride() == ref.stride()
-            and points.dtype == ref.dtype and points._version == ver)
-        if not same:   # another tensor: accepted if it holds the same values (this comparison synchronises; callers that pass
-            #            the tensor they gave query_mr - the reference's eval_func, gen_mesh - never get here)
+            and points.dtype == ref.dtype and points._version == ver and ref._version == ver)
+        if not same and ref._version == ver:
+            # another tensor: accepted if it holds the same values (this comparison synchronises; callers that pass the
+            # tensor they gave query_mr - the reference's eval_func, gen_mesh - never get here)
             same = points.shape == ref.shape and bool(torch.equal(points.to(ref.device), ref))
         if not same:
             raise NotImplementedError("query_sr on points other than the preceding query_mr's is not supported: the "

@@ -301,9 +301,12 @@ def query_points_views(points, calibs, projection, zmul, zdiv, feat_lr, feat_hr,
     return (phr, plr, lg[0], lg[1]) if want_logits else (phr, plr)
 
 
-def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None, kernel=0):
+def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None, kernel=0,
+               operand_parts=0):
     """Dense sweep of grid slab [i0, i1): returns (vol_hr, vol_lr) float32 device tensors [(i1-i0), ry, rz].
-    kernel: column-kernel version for this call (grid_kernel_for's choice; 0 = the library's default / process setting)."""
+    kernel: column-kernel version for this call (grid_kernel_for's choice; 0 = the library's default / process setting);
+    operand_parts: 2 / 3 = operand split of the fp32-grade GEMMs behind this sweep (0 = process setting).  Both travel in the
+    call's SursGridOptions: no process-wide state is touched."""
     dev = blob.device
     if vol_hr is None:
         vol_hr = torch.empty((i1 - i0, ry, rz), dtype=torch.float32, device=dev)
@@ -313,15 +316,10 @@ def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, d
     code = DTYPES[dtype] if isinstance(dtype, str) else dtype
     need = lib().surs_query_grid_workspace_bytes(ry, rz, code)
     w = ws.get(need)
-    if kernel:
-        check(lib().surs_set_grid_kernel(int(kernel)))
-    try:
-        check(lib().surs_query_grid(i0, i1, ry, rz, m, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
+    opt = _lib.GridOptions(int(kernel), int(operand_parts))
+    check(lib().surs_query_grid_opt(i0, i1, ry, rz, m, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
                                     feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), code, _ptr(w), w.numel(), _ptr(vol_hr),
-                                    _ptr(vol_lr), _stream()))
-    finally:
-        if kernel:
-            lib().surs_set_grid_kernel(0)
+                                    _ptr(vol_lr), C.byref(opt), _stream()))
     return vol_hr, vol_lr
 
 
@@ -346,19 +344,18 @@ def grid_kernel_for(rx, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, 
     along the column) unless the probe says the sweep lists so many channels per tile that the dense kernels (3 for bf16 /
     fp16, 5 for fp32) are faster.  A deterministic function of the grid, the calibration, the features and
     the weights - the middle axis-0 plane of the WHOLE grid is probed, so every slab and every rank of a sharded sweep makes
-    the same choice.  Cached per workspace; SURS_GRID_AUTO=0 or an explicit SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL turn it off."""
+    the same choice.  Probed on every call (one plane of column constants, about 0.3 ms and a stream synchronisation): the
+    feature buffers are written through raw pointers into recycled allocator blocks, so nothing the host can see tells one
+    subject's features from the next one's.  SURS_GRID_AUTO=0 or an explicit SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL turn it
+    off.  The last decision is left in ws.kernel_choice = (kernel, listed channels per tile) for reports."""
     if os.environ.get("SURS_GRID_AUTO", "1") == "0" or "SURS_GRID_KERNEL" in os.environ or "SURS_GRID_F32_KERNEL" in os.environ:
         return 0
     if dtype not in ("fp32", "bf16", "fp16") or ry > 16384:
         return 0
-    key = (feat_lr.buf.data_ptr(), feat_lr.buf._version, feat_hr.buf.data_ptr(), feat_hr.buf._version, blob.data_ptr(), blob._version,
-           np.asarray(calib, np.float32).tobytes(), np.asarray(mat, np.float64).tobytes(), dtype, rx, ry, rz, float(zmul), float(zdiv))
-    cache = getattr(ws, "_kernel_choice", None)
-    if cache is not None and cache[0] == key:
-        return cache[1]
     lr, _ = probe_listed(rx // 2, ry, rz, 64 if dtype == "fp32" else 128, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
     kern = (5 if dtype == "fp32" else 3) if lr > LISTED_DENSE_THRESHOLD else 0
-    ws._kernel_choice = (key, kern, lr)
+    ws.kernel_choice = (kern, lr)
+    ws.probes = getattr(ws, "probes", 0) + 1
     return kern
 
 

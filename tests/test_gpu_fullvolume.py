@@ -1,0 +1,80 @@
+"""Whole-volume parity of the restated column kernels at BASELINE's full size (512^3 = 134 217 728 voxels, full-size
+feature maps): every voxel of the default kernels' volumes against the dense-layer-1 kernels they restate
+(lib/model/SurfaceClassifier.py:53-81 along lib/sdf.py:32-52's sweep) -
+
+  * fp32-grade: v8 (restated) against v5 (dense layer 1, the frame the 1e-4 parity tests of round 1 were run on),
+  * fp16:       v10 and v7 (restated, eight / four waves) against v3 (dense layer 1),
+
+on three fields: the bench's noise-like field, the smooth closed body field, and the noise field with layer 0's depth
+column scaled by 60 (nearly every channel changes branch inside a tile: multi-chunk lists at full size).  Measured in logit
+space (float64 from the occupancies) and as the number of voxels on the other side of the 0.5 level.  Bounds: about twice
+the values measured on MI355X (profiles/r03_fullvolume.json)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+R = 512
+#                 fp32-grade: max|dlogit|, flipped      fp16: max|dlogit|, mean|dlogit|, flipped fraction
+BOUNDS = {
+    "noise": ((1e-4, 100), (0.02, 0.002, 1e-3)),
+    "body": ((1e-4, 100), (0.2, 0.02, 1e-3)),
+    "gain60": ((1e-3, 2000), (0.5, 0.02, 1e-2)),
+}
+
+
+def _inputs(field, dev):
+    import precision_report as pr
+    if field == "body":
+        sd, Fl, Fh = pr.body_inputs(dev)
+        return sd, Fl, Fh, None
+    sd, Fl, Fh, keep = pr.noise_inputs(dev)
+    if field == "gain60":
+        sd = {k: (v.clone() if torch.is_tensor(v) else np.array(v, copy=True)) for k, v in sd.items()}
+        for m in ("mlp_lr.", "mlp_hr."):
+            sd[m + "conv0.weight"][:, 320] *= 60.0
+    return sd, Fl, Fh, keep
+
+
+@pytest.mark.parametrize("field", sorted(BOUNDS))
+def test_restated_kernels_equal_dense_kernels_on_the_whole_volume(field):
+    import precision_report as pr
+    from surs_amd import native
+    dev = native.require_gpu()
+    sd, Fl, Fh, keep = _inputs(field, dev)
+    (b32_max, b32_flip), (b16_max, b16_mean, b16_flip) = BOUNDS[field]
+    out = {}
+    # fp32-grade pair
+    ref, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=5)
+    new, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=8)
+    for i, tag in enumerate(("hr", "lr")):
+        st = pr.field_stats(new["fp32"][i], ref["fp32"][i])
+        out["v8_vs_v5_" + tag] = st
+        print(field, "v8 vs v5", tag, st)
+        assert bool(torch.isfinite(new["fp32"][i]).all())
+        assert st["max_abs_dlogit"] < b32_max and st["flipped_voxels"] <= b32_flip, (field, tag, st)
+    del ref, new
+    # fp16 pairs
+    ref, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp16",), dev, kernel=3)
+    for kv in (7, 10):
+        new, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp16",), dev, kernel=kv)
+        for i, tag in enumerate(("hr", "lr")):
+            st = pr.field_stats(new["fp16"][i], ref["fp16"][i])
+            out["v%d_vs_v3_%s" % (kv, tag)] = st
+            print(field, "v%d vs v3 fp16" % kv, tag, st)
+            assert bool(torch.isfinite(new["fp16"][i]).all())
+            assert st["max_abs_dlogit"] < b16_max and st["mean_abs_dlogit"] < b16_mean and st["flipped_fraction"] < b16_flip, (field, kv, tag, st)
+        del new
+    dump = os.environ.get("SURS_FULLVOLUME_JSON")
+    if dump:
+        import json
+        prev = json.load(open(dump)) if os.path.exists(dump) else {}
+        prev[field] = out
+        json.dump(prev, open(dump, "w"), indent=1)

@@ -3,8 +3,8 @@ full-size feature maps (256^2 x 256 and 1024^2 x 64), against the fp32-grade swe
 GPU tests hold to the reference's goldens at 1e-4) - in logit space, as a count of voxels on the other side of the 0.5
 level, and on the extracted meshes (vertex / face counts, symmetric nearest-vertex distance in voxel units).  Two fields:
 the bench's noise-like field and a smooth closed body-sized blob (tools/precision_report.py, SURVEY.md section 7 "parity
-under reduced precision ... and a mesh-level metric").  Bounds = about twice the values measured on MI355X
-(profiles/r02_precision_report_512.json)."""
+under reduced precision ... and a mesh-level metric").  Bounds = at most twice the values measured on MI355X
+(profiles/r02_precision_report_512.json; the 99.9th-percentile distance is bounded by the matching radius)."""
 import os
 import sys
 
@@ -17,10 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 #            max|dlogit| mean|dlogit| flipped fraction  |dV|/V   mean dist  p99.9 dist  unmatched fraction
 BOUNDS = {
-    ("body", "bf16"): (0.25, 0.03, 4e-4, 5e-3, 0.20, 0.95, 1e-3),
-    ("body", "fp16"): (0.03, 0.004, 5e-5, 1e-3, 0.03, 0.50, 1e-5),
-    ("noise", "bf16"): (0.015, 0.003, 3e-3, 1e-2, 0.06, 0.95, 5e-3),
-    ("noise", "fp16"): (0.0015, 0.0003, 1.5e-4, 1e-3, 0.004, 0.25, 2e-5),
+    ("body", "bf16"): (0.125, 0.021, 2.2e-4, 1.3e-4, 0.14, 0.95, 1e-5),
+    ("body", "fp16"): (0.015, 0.0027, 2.8e-5, 4e-5, 0.023, 0.50, 1e-5),
+    ("noise", "bf16"): (0.0113, 0.002, 1.9e-3, 5e-3, 0.044, 0.95, 1.2e-3),
+    ("noise", "fp16"): (0.0015, 0.00023, 1.1e-4, 1.3e-4, 0.004, 0.22, 1e-5),
 }
 
 

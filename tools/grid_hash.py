@@ -1,5 +1,5 @@
-"""Prints sha256 digests of the column-kernel volumes for a few grid sizes (used by tests/test_gpu_query.py to compare
-the pipelined kernel against the simple one bit for bit: SURS_GRID_KERNEL=1 selects the simple kernel)."""
+"""Prints sha256 digests of the column-kernel volumes for a few grid sizes, three launches each (race screen; compare two
+builds of one kernel bit for bit: SURS_GRID_KERNEL / SURS_LIB_PATH select kernel and library)."""
 import hashlib
 import os
 import sys

@@ -110,8 +110,8 @@ def mesh_stats(ws, vol, ref, R, sample=1 << 20):
             "from_ref": _dist_summary(nearest_vertex_distance(vr, v, R, sample, seed=1))}
 
 
-def sweeps(sd, Fl, Fh, R, precisions, dev, zmul=512, zdiv=200.0):
-    """{precision: (vol_hr, vol_lr)} of the dense R^3 sweep, plus the sweep times."""
+def sweeps(sd, Fl, Fh, R, precisions, dev, zmul=512, zdiv=200.0, kernel=0):
+    """{precision: (vol_hr, vol_lr)} of the dense R^3 sweep, plus the sweep times.  kernel: column-kernel version (0 = default)."""
     mlp = {k: v for k, v in sd.items() if k.startswith("mlp_")}
     cal = CALIB.reshape(-1)[:12]
     m = np.eye(4)
@@ -123,10 +123,10 @@ def sweeps(sd, Fl, Fh, R, precisions, dev, zmul=512, zdiv=200.0):
         blob, _ = native.pack_mlp(mlp, prec, dev)
         vh = torch.empty((R, R, R), dtype=torch.float32, device=dev)
         vl = torch.empty_like(vh)
-        native.query_grid(0, min(R, 8), R, R, m[:3].reshape(-1), cal, zmul, zdiv, Fl, Fh, blob, prec, ws, vh[:8], vl[:8])   # warm-up
+        native.query_grid(0, min(R, 8), R, R, m[:3].reshape(-1), cal, zmul, zdiv, Fl, Fh, blob, prec, ws, vh[:8], vl[:8], kernel=kernel)   # warm-up
         torch.cuda.synchronize()
         t = time.perf_counter()
-        native.query_grid(0, R, R, R, m[:3].reshape(-1), cal, zmul, zdiv, Fl, Fh, blob, prec, ws, vh, vl)
+        native.query_grid(0, R, R, R, m[:3].reshape(-1), cal, zmul, zdiv, Fl, Fh, blob, prec, ws, vh, vl, kernel=kernel)
         torch.cuda.synchronize()
         times[prec] = time.perf_counter() - t
         out[prec] = (vh, vl)
