@@ -595,6 +595,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 #include "surs_grid_v3.inc"
 #include "surs_grid_v5.inc"
 #include "surs_grid_v7.inc"
+#include "surs_grid_v10.inc"
 #include "surs_grid_v8.inc"
 
 // Column kernel v7's per-column affine part, step 1: the vectors g . a0, g . w0z (lr) and g . a0, g . w0z, g . w0p (hr) of a
@@ -981,6 +982,8 @@ static int grid_set_attributes() {
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v8, hipFuncAttributeMaxDynamicSharedMemorySize, GRID8_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
     return 0;
 }
 
@@ -1302,6 +1305,11 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
                 hipLaunchKernelGGL(grid_mlp_kernel_v8, dim3(grid), dim3(256), GRID8_LDS_BYTES, st, a);
             else
                 hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
+        } else if (kver == 10) {
+            if (dtype == SURS_BF16)
+                hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_BF16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
+            else
+                hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_F16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
         } else if (kver == 7) {
             if (dtype == SURS_BF16)
                 hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_BF16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
@@ -1315,7 +1323,7 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
         }
         SURS_LAUNCH_CHECK();
 #ifdef SURS_V3_TRACE
-        if ((dtype == SURS_F32 || kver == 3 || kver == 7) && c0 == 0 && getenv("SURS_V3_TRACE")) {
+        if ((dtype == SURS_F32 || kver == 3 || kver == 7 || kver == 10) && c0 == 0 && getenv("SURS_V3_TRACE")) {
             unsigned long long t[64];
             SURS_HIP_CHECK(hipStreamSynchronize(st));
             SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
