@@ -167,19 +167,20 @@ def main():
         exe = k_pts * flop_exec / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         peak = PEAK_MFMA / 1e12
         r = {"kernel": "grid_mlp_kernel_v%s (split-f16, 3 products per MAC)" % os.environ.get("SURS_GRID_F32_KERNEL", "8")[:1] if prec == "fp32" else
-                       "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "7")[:1], prec),
+                       "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "10"), prec),
              "bound": "mfma", "unit": "TFLOP/s",
-             # contract fields: ALGORITHMIC flops (the reference's un-reduced 4 564 998 FLOP per query) per launch /
-             # the launch's duration; peak = the dense f16/bf16 MFMA peak divided by the MFMA products one fp32-grade MAC costs
-             "achieved": alg, "peak": peak / nprod, "frac": alg / (peak / nprod),
-             "achieved_algorithmic": alg, "frac_algorithmic": alg / (peak / nprod),
-             # what the matrix pipe actually executes (column-constant reduction: 2 752 512 FLOP per query and product)
+             # contract fields = what the matrix pipe EXECUTES per launch / the launch's duration against the dense f16 / bf16 MFMA
+             # peak: a utilisation.  (The column kernels restate layer 1 exactly - DESIGN 4.1c - and execute far fewer FLOP than
+             # the reference's dense products; the algorithmic rate is kept below as a labelled extra and is NOT a utilisation.)
+             "achieved": exe, "peak": peak, "frac": exe / peak,
              "achieved_executed": exe, "frac_executed": exe / peak, "mfma_products_per_mac": nprod,
+             "achieved_algorithmic": alg, "frac_algorithmic": alg / (peak / nprod),
+             "frac_algorithmic_note": "reference FLOP (4 564 998 per query, SURVEY 8d) / time / (peak / products per MAC); restated layer 1: "
+                                      "not a utilisation, can exceed 1",
              "avg_launch_ms": k_avg_ms, "queries_per_launch": k_pts,
              "flop_per_query_algorithmic": FLOP_PER_QUERY, "flop_per_query_executed": flop_exec,
              "traffic": None}
         if kavg is not None:
-            # frac (algorithmic) can exceed 1: the restated layer 1 does not execute the reference's dense product
             r["layer1_residual_ksteps_per_tile"] = kavg
             r["layer1_listed_channels_per_tile_upper"] = 16.0 * kavg
         # HBM bytes / MFMA-busy cycles come from separate rocprofv3 --pmc passes (tools/profile_round.sh) and are only valid
@@ -209,6 +210,53 @@ def main():
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
                                "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
+    if world == 1 and not args.no_extras:
+        # The restated column kernels' cost depends on the weights and features (how many layer-0 channels change LeakyReLU branch
+        # inside a z tile).  (1) dense_floor: the same step on the dense-layer-1 kernels (v3 / v5) - the data-independent guarantee,
+        # and what the host falls back to above 400 listed channels per tile.  (2) listed_sensitivity: the sweep alone with layer 0's
+        # depth column (conv0.weight[:, 320]) scaled by 1, 4, 16, 60 - listed channels per tile, time on the restated kernel, and
+        # what native.grid_kernel_for picks.
+        try:
+            lib.surs_set_grid_kernel(5 if args.precision == "fp32" else 3)
+            dfl, stf, _, (kf, pf, _) = run(opt, 2, 1)
+            lib.surs_set_grid_kernel(0)
+            extras["dense_floor"] = {"kernel": "grid_mlp_kernel_v5" if args.precision == "fp32" else "grid_mlp_kernel_v3<%s>" % args.precision,
+                                     "value": float(R) ** 3 * 2 / dfl, "unit": "queries/s", "ms_per_step": dfl / 2 * 1e3, "stage_ms": stf,
+                                     "avg_launch_ms": kf, "note": "dense layer 1: independent of weights and features"}
+            from surs_amd import native
+            fl, fh = net.features()
+            ws = net._workspace()
+            from surs_amd import sdf
+            mat = sdf.create_grid(R, R, R, b_min, b_max)[1][:3].reshape(-1)
+            cal = calib[0].cpu().numpy().reshape(-1)[:12]
+            zmul, zdiv = net._zscale()
+            vh = torch.empty((R, R, R), dtype=torch.float32, device=dev)
+            vl = torch.empty_like(vh)
+            rows = []
+            for gain in (1.0, 4.0, 16.0, 60.0):
+                sdg = {k: np.array(v, copy=True) for k, v in sd.items() if k.startswith("mlp_")}
+                for mm in ("mlp_lr.", "mlp_hr."):
+                    sdg[mm + "conv0.weight"][:, 320] *= gain
+                blob, _ = native.pack_mlp(sdg, args.precision, dev)
+                tile = 64 if args.precision == "fp32" else 128
+                lr, hr = native.probe_listed(R // 2, R, R, tile, mat, cal, zmul, zdiv, fl, fh, blob, ws)
+                pick = native.grid_kernel_for(R, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws)
+                row = {"gain": gain, "listed_lr_per_tile": lr, "listed_hr_per_tile_upper": hr,
+                       "host_picks": pick or (8 if args.precision == "fp32" else 10)}
+                for name, kern in (("restated_ms", 8 if args.precision == "fp32" else 10), ("dense_ms", 5 if args.precision == "fp32" else 3)):
+                    native.query_grid(0, 32, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws, vh[:32], vl[:32], kernel=kern)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    native.query_grid(0, R, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws, vh, vl, kernel=kern)
+                    torch.cuda.synchronize()
+                    row[name] = (time.perf_counter() - t0) * 1e3
+                rows.append(row)
+            del vh, vl
+            extras["listed_sensitivity"] = {"what": "%d^3 sweep alone (no encoder, no marching cubes), layer-0 depth column x gain" % R,
+                                            "dense_threshold_listed": native.LISTED_DENSE_THRESHOLD, "rows": rows}
+        except Exception as e:
+            lib.surs_set_grid_kernel(0)
+            extras["dense_floor"] = {"error": repr(e)}
     if world == 1 and not args.no_extras:
         # a run of subjects (apps/eval_SuRS.py:74-80) - per subject: decoded 8-bit pixels -> img_LR -> encoder ->
         # reconstruction (no OBJ files).  sequential = host normalise + upload + gen_mesh's order; pipelined = device input stage,
@@ -318,7 +366,10 @@ def cpu_baseline(net, sd, R, b_min, b_max):
     dt = time.perf_counter() - t
     return {"value": n / dt, "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
             "sample": "%d grid points (the x-plane i=%d of the %d^3 grid) through oracle.query, fp32, OpenMP" % (n, R // 2, R),
-            "seconds": dt}
+            "seconds": dt,
+            "note": "a plain OpenMP loop on every host thread of the GPU box: a stated baseline, not a like-for-like figure.  The "
+                    "reference itself (PyTorch CPU, 8 cores of the build container) evaluates 3.8 - 4.9e4 queries/s "
+                    "(profiles/r02_reference_cpu_times.json, tools/ref_time.py)"}
 
 
 if __name__ == "__main__":

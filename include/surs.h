@@ -131,6 +131,9 @@ size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], con
  * rate, 22 significant bits, |activation| and |feature| < 65504), 3 = three bf16 parts, six products (24 bits, fp32's exponent
  * range), 0 = back to the default (or the SURS_SPLIT environment variable).  Both meet the 1e-4 logit tolerance. */
 int surs_set_operand_split(int parts);
+/* The same for the calling host thread only (0 = back to the process-wide setting); takes precedence over it.  The host mirror
+ * uses it to repeat a query or a sweep on three bf16 parts after an f16 overflow (non-finite results). */
+int surs_set_operand_split_local(int parts);
 
 /* Column kernel of surs_query_grid, process-wide (A/B comparisons and regression tests; a per-call choice goes through
  * surs_query_grid_opt): 0 = default (or the SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL environment variables); reduced precision

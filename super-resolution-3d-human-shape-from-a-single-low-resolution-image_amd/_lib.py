@@ -65,6 +65,7 @@ _SIGS = {
     "surs_conv_pack_weights_x2": (_sz, [_vp, _i, _i, _i, _vp]),
     "surs_mlp_pack": (_sz, [_vp, _vp, _vp, _vp, _i, _vp]),
     "surs_set_operand_split": (C.c_int, [_i]),
+    "surs_set_operand_split_local": (C.c_int, [_i]),
     "surs_set_grid_kernel": (C.c_int, [_i]),
     "surs_query_workspace_bytes": (_sz, [_i]),
     "surs_query_points": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),

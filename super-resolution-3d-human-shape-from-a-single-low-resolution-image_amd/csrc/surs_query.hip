@@ -686,7 +686,7 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 }
 
 #ifndef SURS_DEFAULT_GRID_KERNEL
-#define SURS_DEFAULT_GRID_KERNEL 7
+#define SURS_DEFAULT_GRID_KERNEL 10
 #endif
 static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
 static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 7 || v == 10 || v == 5 || v == 8; }
@@ -694,6 +694,14 @@ extern "C" int surs_set_grid_kernel(int version) {
     SURS_REQUIRE(grid_kernel_known(version),
                  "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3, 7 or 10, fp32-grade 5 or 8");
     g_grid_kernel_override = version;
+    return 0;
+}
+
+// The same choice for the calling host thread only (0 = back to the process setting): what a retry after an f16 overflow uses,
+// without touching what other threads compute with.
+extern "C" int surs_set_operand_split_local(int parts) {
+    SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "parts: 0 (process setting), 2 (f16 x 2) or 3 (bf16 x 3)");
+    t_split_call = parts;
     return 0;
 }
 
@@ -1092,7 +1100,7 @@ extern "C" int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double 
     // the operand split is read deep inside the launch helpers: scoped to this call and this thread, the process setting
     // (surs_set_operand_split) is neither read nor changed when the caller gave one
     const int saved = t_split_call;
-    t_split_call = parts;
+    if (parts) t_split_call = parts;
     const int rc = query_grid_impl(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, hl, wl, feat_hr, hh, wh, mlp_blob, dtype, workspace,
                                    workspace_bytes, vol_hr, vol_lr, kernel, stream);
     t_split_call = saved;

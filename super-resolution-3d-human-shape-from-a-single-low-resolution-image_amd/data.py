@@ -87,11 +87,18 @@ class DeviceInputStage:
         self._pin = {}
 
     def _staged(self, key, a):
-        buf = self._pin.get((key, a.shape))
-        if buf is None:
-            buf = self._pin[(key, a.shape)] = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
+        ent = self._pin.get((key, a.shape))
+        if ent is None:
+            ent = self._pin[(key, a.shape)] = [torch.empty(a.shape, dtype=torch.uint8, pin_memory=True), None]
+        buf, uploaded = ent
+        if uploaded is not None:
+            uploaded.synchronize()   # the previous subject's upload has read the buffer: only now may the host overwrite it
         buf.numpy()[...] = a
-        return buf.to(self.device, non_blocking=True)
+        d = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        ent[1] = ev
+        return d
 
     def prepare(self, rgb, mask):
         from . import native

@@ -11,7 +11,10 @@ gloo with host staging in the tests):
   2. counts      all_gather      (n_verts, n_faces, min, max) per field: exclusive vertex offsets, the level-range check
   3. boundary    rank r -> r+1   the vertex ids of the x- / y-edges in the slab's top plane (2 x 2 x R^2 int32): the first
                                  cell layer of slab r+1 references vertices that slab r created
-  4. meshes      rank r -> dst   vertices (world space, float64) and faces (int32, whole-mesh numbering)
+  4. meshes      rank r -> dst   vertices (world space, float64) and faces (int32, whole-mesh numbering): on one node every rank
+                                 copies its part over its OWN PCIe link into a POSIX shared-memory block that `dst` maps
+                                 (SharedMeshStore; 8 links instead of 0.7 GB funnelled through rank dst's xGMI links and then its
+                                 one PCIe link); across nodes point-to-point to dst
 
 Concatenated in rank order the result is bit-identical to the single-GPU extraction (tests/test_gpu_dist.py): vertex
 coordinates are computed in whole-grid coordinates, a slab numbers its vertices in sweep order, and the faces are renumbered
@@ -35,9 +38,14 @@ def _world(group=None):
     return 1, 0
 
 
-def _host_staged(t):
+def _host_staged(t, group=None):
     """gloo moves host memory only: device tensors are staged through the host there (tests); RCCL takes them as they are."""
-    return t.is_cuda and dist.get_backend() == "gloo"
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _global_rank(group, r):
+    """P2POp peers are ranks of the default group: translate a rank of `group`."""
+    return r if group is None else dist.get_global_rank(group, r)
 
 
 class Exchange:
@@ -50,19 +58,19 @@ class Exchange:
 
     def send(self, t, dst):
         t = t.contiguous()
-        if _host_staged(t):
+        if _host_staged(t, self.group):
             t = t.cpu()     # synchronises: the producer of t has finished
         self.keep.append(t)
-        self.ops.append(dist.P2POp(dist.isend, t, dst, self.group))
+        self.ops.append(dist.P2POp(dist.isend, t, _global_rank(self.group, dst), self.group))
 
     def recv(self, out, src):
         assert out.is_contiguous()
-        if _host_staged(out):
+        if _host_staged(out, self.group):
             tmp = torch.empty(out.shape, dtype=out.dtype)
             self.post.append((out, tmp))
             out = tmp
         self.keep.append(out)
-        self.ops.append(dist.P2POp(dist.irecv, out, src, self.group))
+        self.ops.append(dist.P2POp(dist.irecv, out, _global_rank(self.group, src), self.group))
 
     def start(self):
         self.works = dist.batch_isend_irecv(self.ops) if self.ops else []
@@ -109,6 +117,63 @@ def gather_slabs(local, resolution, dst=0, group=None):
     return full
 
 
+class SharedMeshStore:
+    """Host memory that every rank of one node can write and `dst` can read: a file in /dev/shm, mapped by each process and
+    (on a GPU box) registered with the HIP runtime as pinned memory, so that a rank's device-to-host copy of its part of a mesh
+    is one DMA over its own PCIe link.  One store per (creator pid, tag); grows on demand; the creator unlinks it at exit."""
+    _maps = {}
+
+    @staticmethod
+    def _path(owner_pid, tag):
+        return "/dev/shm/surs_mesh_%d_%s" % (owner_pid, tag)
+
+    @classmethod
+    def open(cls, owner_pid, tag, nbytes, create):
+        import atexit
+        import mmap
+        import os
+        path = cls._path(owner_pid, tag)
+        cur = cls._maps.get(path)
+        if cur is not None and cur[1] >= nbytes:
+            return cur[0]
+        if cur is not None:
+            cls._release(path)
+        if create:
+            size = max(1 << 20, int(nbytes * 1.25))
+            fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
+            if os.fstat(fd).st_size < size:
+                os.ftruncate(fd, size)
+            if path not in cls._owned:
+                cls._owned.add(path)
+                atexit.register(lambda p=path: os.path.exists(p) and os.unlink(p))
+        else:
+            fd = os.open(path, os.O_RDWR)
+        size = os.fstat(fd).st_size
+        mm = mmap.mmap(fd, size)
+        os.close(fd)
+        buf = torch.frombuffer(mm, dtype=torch.uint8)
+        pinned = False
+        if torch.cuda.is_available():
+            try:   # page-lock the mapping: device-to-host copies into it then run at PCIe rate
+                pinned = int(torch.cuda.cudart().cudaHostRegister(buf.data_ptr(), size, 0)) == 0
+            except Exception:
+                pinned = False
+        cls._maps[path] = (buf, size, mm, pinned)
+        return buf
+
+    _owned = set()
+
+    @classmethod
+    def _release(cls, path):
+        buf, size, mm, pinned = cls._maps.pop(path)
+        if pinned:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(buf.data_ptr())
+            except Exception:
+                pass
+        del buf
+
+
 def offsets_from_counts(counts):
     """counts [world] -> exclusive prefix sums (int64): where each rank's vertices / faces start in the whole mesh."""
     c = np.asarray(counts, np.int64)
@@ -117,6 +182,30 @@ def offsets_from_counts(counts):
 
 def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, dst=0, want_normals=False,
                            timing=None, group=None):
+    """reconstruction_sharded_once, and - as mesh_util.reconstruction does on one GPU - once more on three bf16 parts per operand
+    (fp32's exponent range) when the fp32-grade sweep produced non-finite occupancies on any rank (every rank raises and
+    repeats together: the counts exchange carries the flag)."""
+    from . import native
+    try:
+        return reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform, dst, want_normals, timing, group)
+    except native._lib.NonFiniteVolumeError:
+        if getattr(opt, "precision", "fp32") != "fp32":
+            raise
+        import warnings
+        warnings.warn("reconstruction_sharded: non-finite occupancies from the two-part f16 operand split; repeating on three "
+                      "bf16 parts", stacklevel=2)
+        with native.wide_operands():
+            fl, fh = net.features()
+            bad = not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all()))
+            flags = all_gather_rows([1.0 if bad else 0.0], fl.buf.device, group)   # (the encoder is deterministic; agree anyway)
+            if flags.any():
+                net.reencode_wide()
+            return reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform, dst, want_normals, timing,
+                                               group, wide=True)
+
+
+def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, dst=0, want_normals=False,
+                                timing=None, group=None, wide=False):
     """One reconstruction on all ranks of the group: each rank sweeps the x-slab slab_range(R, rank, world) and extracts its
     part of the two meshes.  Returns the 8-tuple of mesh_util.reconstruction on `dst` (normals / values None), None on the
     other ranks.  Every rank raises the same ValueError / RuntimeError as marching_cubes_lewiner when the level is outside
@@ -127,7 +216,7 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
     R = int(resolution)
     if world == 1:
         return mesh_util.reconstruction(opt, net, net._device(), calib_tensor, R, b_min, b_max, use_octree=False,
-                                        want_normals=want_normals)
+                                        transform=transform, want_normals=want_normals)
     if want_normals:
         raise NotImplementedError("slab mode returns vertices and faces (what gen_mesh keeps); normals accumulate across slabs")
     if R < 2 * world:
@@ -139,7 +228,7 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
     calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
     fl, fh = net.features()
     zmul, zdiv = net._zscale()
-    prec = getattr(opt, "precision", "fp32")
+    prec = "fp32x" if wide else getattr(opt, "precision", "fp32")
     blob = net._mlp_blob()
     ws = net._workspace()
     dev = blob.device
@@ -147,41 +236,50 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
     keys = ("slab", 0), ("slab", 1)
     first = any(ws.mc_capacity.get(k) is None for k in keys)
     streams = None if first else [native.MeshStream(ws, k, v, m12, 0.5, False, zoff=i0) for k, v in zip(keys, vols)]
-    # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
-    import os
-    planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
-    sweep = torch.cuda.current_stream(dev)
-    done, ex = [], None
-    kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws)   # (probes the whole grid: every rank the same)
-    for a in range(0, nloc, planes):
-        b = min(nloc, a + planes)
-        try:
-            native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b],
-                              kernel=kern)
-        except native._lib.SursError as e:
-            if e.code != -3:
-                raise
-            prec = "fp32"   # general calibration / grid transform: the column kernel does not apply
-            native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b])
-        ev = torch.cuda.Event()
-        ev.record(sweep)
-        done.append((b, ev))
-        if ex is None:
-            ex = Exchange(group)
-            for v in vols:
-                if rank > 0:
-                    ex.send(v[0], rank - 1)
-                if halo:
-                    ex.recv(v[nloc], rank + 1)
-            ex.start()
-    ex.wait()                      # the sweep's stream (RCCL) / the host (gloo) has the halo planes from here on
-    halo_ev = torch.cuda.Event()
-    halo_ev.record(sweep)
-    if timing is not None:
-        timing.record()
-    # ---- extraction: layer by layer behind the sweep's launches (from the second reconstruction on), or in one piece
-    res, nonfinite = None, False
+    # A failure on one rank (out of memory, a kernel error, ...) must not leave the others waiting in the next collective: the
+    # halo exchange is the only collective step inside this block and comes first; whatever is raised behind it is carried to the
+    # counts exchange as a status flag, where every rank raises.
+    status, failure = 0, None
+    res = tables = runs = ex = None
+
+    def halo_exchange():
+        e = Exchange(group)
+        for v in vols:
+            if rank > 0:
+                e.send(v[0], rank - 1)
+            if halo:
+                e.recv(v[nloc], rank + 1)
+        return e.start()
+
     try:
+        # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
+        import os
+        planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
+        sweep = torch.cuda.current_stream(dev)
+        done = []
+        kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws)   # (probes the whole grid: every rank the same)
+        for a in range(0, nloc, planes):
+            b = min(nloc, a + planes)
+            try:
+                native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b],
+                                  kernel=kern)
+            except native._lib.SursError as e:
+                if e.code != -3:
+                    raise
+                prec = "fp32"   # general calibration / grid transform: the column kernel does not apply
+                native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b])
+            ev = torch.cuda.Event()
+            ev.record(sweep)
+            done.append((b, ev))
+            if ex is None:
+                ex = halo_exchange()
+        ex.wait()                      # the sweep's stream (RCCL) / the host (gloo) has the halo planes from here on
+        halo_ev = torch.cuda.Event()
+        halo_ev.record(sweep)
+        if timing is not None:
+            timing.record()
+        # ---- extraction: layer by layer behind the sweep's launches (from the second reconstruction on), or in one piece
+        res = None
         if streams is not None:
             for b, ev in done[:-1]:
                 for s in streams:
@@ -200,15 +298,19 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
                 res.append((world_v, faces))
                 runs.append(run)
                 tables.append(w)
+        counts = [(r.n_verts, r.n_faces, r.vmin, r.vmax) for r in runs]
+
     except native._lib.NonFiniteVolumeError:
-        nonfinite = True   # this rank's slab holds NaN: tell everybody through the counts (a lone raise would hang the others)
-    if nonfinite:
+        status = 1
+    except Exception as e:   # noqa: BLE001 - reported to every rank below, re-raised on this one
+        status, failure = 2, e
+    if status and ex is None:
+        halo_exchange().wait()   # (failed before the halo step: the neighbours are waiting in theirs)
+    if status:
         nan = float("nan")
         counts = [(0, 0, nan, nan)] * 2
         res = [(torch.empty((0, 3), dtype=torch.float64, device=dev), torch.empty((0, 3), dtype=torch.int32, device=dev))] * 2
         tables = [None, None]
-    else:
-        counts = [(r.n_verts, r.n_faces, r.vmin, r.vmax) for r in runs]
     n0 = vols[0].shape[0]
 
     def top_ids(f):
@@ -221,30 +323,45 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
         native.check(native.lib().surs_mc_slab_fixup(native._ptr(faces), faces.shape[0], own_off, native._ptr(below), below_off,
                                                      native._stream()))
 
-    out = assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst, group)
+    out = assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst, group, status=status, failure=failure)
     if out is None:
         torch.cuda.current_stream(dev).synchronize()   # the sends have left before the buffers go back to the allocator
         return None
-    host = ws.to_host([out[0][0], out[0][1], out[1][0], out[1][1]])
+    flat = [out[0][0], out[0][1], out[1][0], out[1][1]]
+    if all(not t.is_cuda for t in flat):   # delivered through shared host memory: views of it, valid until the next sharded reconstruction
+        host = [t.numpy() for t in flat]
+    else:
+        host = ws.to_host(flat)
     return host[0], host[1], None, None, host[2], host[3], None, None
 
 
-def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None, level=0.5):
+def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None, level=0.5, status=0, failure=None):
     """Steps 2-4 of the module docstring.  res[f] = (verts [V,3], faces int32 [F,3]) of this rank's slab of field f in local
     numbering (references to the slab below as -(2 + slot)); counts[f] = (n_verts, n_faces, vmin, vmax); top_ids(f) -> int32
     [2,R,R] ids of the x- / y-edge vertices in the slab's top plane; fixup(f, faces, own_offset, below_ids, below_offset)
     renumbers `faces` in place.  Returns [(verts, faces)] per field of the whole mesh on `dst`, None on the other ranks.
+    status: 0, 1 (this rank's slab holds NaN) or 2 (this rank failed with `failure`): travels with the counts, every rank raises.
     (The kernels behind top_ids / fixup are the product's on the GPU; the gloo test passes numpy stand-ins.)"""
+    import os
+    import socket
+    import zlib
     world, rank = _world(group)
     nfields = len(res)
-    row = []
+    row = [float(status), float(zlib.crc32(socket.gethostname().encode())), float(os.getpid())]
     for c in counts:
         row += list(c)
-    allc = all_gather_rows(row, dev, group)          # [world, 4 * nfields]
-    if np.isnan(allc).any():   # some rank's slab holds NaN values: every rank raises
+    allh = all_gather_rows(row, dev, group)          # [world, 3 + 4 * nfields]
+    st, allc = allh[:, 0], allh[:, 3:]
+    if (st == 2).any():
+        if failure is not None:
+            raise failure
+        raise RuntimeError("the slab sweep failed on rank(s) %s" % np.nonzero(st == 2)[0].tolist())
+    if (st == 1).any() or np.isnan(allc).any():   # some rank's slab holds NaN values: every rank raises
         from ._lib import NonFiniteVolumeError
         raise NonFiniteVolumeError("the occupancy volume contains NaN values (rank(s) %s)" %
-                                   sorted(set(np.nonzero(np.isnan(allc))[0].tolist())))
+                                   sorted(set(np.nonzero(np.isnan(allc))[0].tolist()) | set(np.nonzero(st == 1)[0].tolist())))
+    one_node = bool((allh[:, 1] == allh[0, 1]).all()) and os.environ.get("SURS_SLAB_P2P", "0") != "1" and os.path.isdir("/dev/shm")
+    owner_pid = int(allh[dst, 2])
     for f in range(nfields):
         lo, hi = allc[:, 4 * f + 2].min(), allc[:, 4 * f + 3].max()
         if level < lo or level > hi:
@@ -263,6 +380,34 @@ def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None,
     ex.start().wait()
     for f in range(nfields):
         fixup(f, res[f][1], int(voff[f][rank]), below[f], int(voff[f][rank - 1]) if rank > 0 else 0)
+    # ---- meshes to dst: on one node through shared host memory, every rank over its own PCIe link
+    if one_node:
+        stores = []
+        for f in range(nfields):
+            nv, nf = allc[:, 4 * f].astype(np.int64), allc[:, 4 * f + 1].astype(np.int64)
+            vb, fb = int(nv.sum()) * 3 * res[f][0].element_size(), int(nf.sum()) * 3 * 4
+            stores.append((nv, nf, vb, fb))
+        if rank == dst:
+            for f, (nv, nf, vb, fb) in enumerate(stores):
+                SharedMeshStore.open(owner_pid, "f%d_v" % f, vb, True)
+                SharedMeshStore.open(owner_pid, "f%d_f" % f, fb, True)
+        dist.barrier(group)      # the blocks exist (and are large enough) before anybody maps them
+        out = []
+        for f, (nv, nf, vb, fb) in enumerate(stores):
+            bv = SharedMeshStore.open(owner_pid, "f%d_v" % f, vb, False)
+            bf = SharedMeshStore.open(owner_pid, "f%d_f" % f, fb, False)
+            V = bv[:vb].view(res[f][0].dtype).view(-1, 3)
+            F = bf[:fb].view(torch.int32).view(-1, 3)
+            va, fa = int(voff[f][rank]), int(offsets_from_counts(nf)[rank])
+            if nv[rank]:
+                V[va:va + int(nv[rank])].copy_(res[f][0])
+            if nf[rank]:
+                F[fa:fa + int(nf[rank])].copy_(res[f][1])
+            out.append((V, F))
+        if res[0][0].is_cuda:
+            torch.cuda.current_stream(dev).synchronize()
+        dist.barrier(group)      # every part has landed
+        return out if rank == dst else None
     # ---- meshes to dst
     ex = Exchange(group)
     out = []

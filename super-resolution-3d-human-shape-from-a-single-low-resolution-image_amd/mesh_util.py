@@ -200,41 +200,52 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
 def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_octree=False, num_samples=50000,
                    transform=None, want_normals=True, features=None, after_enqueue=None):
     """-> verts_hr, faces_hr, normals_hr, values_hr, verts_lr, faces_lr, normals_lr, values_lr  (numpy).
-    features / after_enqueue: see reconstruction_streamed (single view only)."""
-    if net.num_views > 1 or getattr(net, "projection_mode", "orthogonal") != "orthogonal":
-        # multi-view / perspective: the per-point layer kernels (surs_query_points_views) behind the same two sweeps
-        if use_octree:
-            vh, vl, mat = eval_volumes_octree_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+    features / after_enqueue: see reconstruction_streamed (single view only).
+
+    Range: with `--precision fp32` every fp32-grade product runs on two f16 parts per operand (|x| < 65504); the reference is
+    plain fp32.  A field that comes out non-finite (marching cubes reports it: NonFiniteVolumeError) is computed again on three
+    bf16 parts - fp32's exponent range - in every branch: the dense sweep on the per-point layer kernels ('fp32x'), the octree and
+    multi-view sweeps under native.wide_operands(), and the encoder re-run the same way when its features are what overflowed."""
+    called = []
+    hook = (lambda: (called.append(1), after_enqueue())) if after_enqueue is not None else None
+
+    def run(wide):
+        if net.num_views > 1 or getattr(net, "projection_mode", "orthogonal") != "orthogonal":
+            # multi-view / perspective: the per-point layer kernels (surs_query_points_views) behind the same two sweeps
+            if use_octree:
+                vh, vl, mat = eval_volumes_octree_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+            else:
+                vh, vl, mat = eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
+        elif use_octree:
+            vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
+        elif wide:
+            vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, precision="fp32x", features=features)
         else:
-            vh, vl, mat = eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform)
-    elif use_octree:
-        vh, vl, mat = eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
-        if after_enqueue is not None:
-            after_enqueue()
-    else:
-        called = []
-        hook = (lambda: (called.append(1), after_enqueue())) if after_enqueue is not None else None
-        try:
             out = reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform, want_normals, features=features,
                                           after_enqueue=hook)
             if out is not None:
                 return out
             vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, features=features)
-            if after_enqueue is not None and not called:
-                after_enqueue()
-            return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
-        except native._lib.NonFiniteVolumeError:
-            if getattr(opt, "precision", "fp32") != "fp32":
-                raise
-            # the fp32-grade column kernel carries its operands as two f16 parts: an activation beyond 65504 becomes inf and the
-            # field NaN.  The layer kernels (three bf16 parts: fp32's exponent range) give the same fp32-grade result, 4x slower.
-            import warnings
-            warnings.warn("reconstruction: the fp32-grade column kernel overflowed its f16 range (NaN occupancies); repeating the "
-                          "sweep on the per-point layer kernels", stacklevel=2)
-            if after_enqueue is not None and not called:
-                after_enqueue()
-            vh, vl, mat = eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform, precision="fp32x", features=features)
-    return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
+        if hook is not None and not called:
+            hook()
+        return meshes_from_volumes(net, [vh, vl], mat, want_normals=want_normals)
+
+    try:
+        return run(False)
+    except native._lib.NonFiniteVolumeError:
+        if getattr(opt, "precision", "fp32") != "fp32":
+            raise   # (bf16 / fp16 were asked for explicitly: their range is theirs)
+        import warnings
+        warnings.warn("reconstruction: non-finite occupancies from the two-part f16 operand split; repeating on three bf16 parts "
+                      "(fp32's exponent range)", stacklevel=2)
+        if hook is not None and not called:
+            hook()
+        with native.wide_operands():
+            if features is None:
+                fl, fh = net.features()
+                if not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all())):
+                    net.reencode_wide()
+            return run(True)
 
 
 def _obj_text(verts, faces):

@@ -137,6 +137,7 @@ class SuRSNet:
     def super_res(self, images):
         """images [V,3,H,W] -> (img_SR [V,3,2H,2W], feature_lr [V,256,H/2,W/2], feature_hr [V,64,2H,2W])."""
         W = self._encoder_weights()
+        self._last_images = images   # (kept for reencode_wide: the retry after an f16 overflow)
         outs = [encoder.super_res(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
         cat = lambda i: torch.cat([_as_nchw_view(o[i]) for o in outs], 0) if len(outs) > 1 else _as_nchw_view(outs[0][i])
         self.im_SR, self.feature_lr, self.feature_hr = cat(0), cat(1), cat(2)
@@ -156,6 +157,18 @@ class SuRSNet:
         self._feat_hr_imgs = [[pv[0] for pv in per_view]]
         self.im_feat_list_hr = [torch.cat([_as_nchw_view(pv[0]) for pv in per_view], 0) if len(per_view) > 1
                                 else _as_nchw_view(per_view[0][0])]
+
+    def reencode_wide(self):
+        """Runs the encoder again on the images of the last super_res() call with every fp32-grade product on three bf16 parts
+        (native.wide_operands): what reconstruction() / query_* do when the features came out non-finite (an activation beyond
+        the f16 range of the default two-part split).  Returns False if there is nothing to re-encode."""
+        if getattr(self, "_last_images", None) is None:
+            return False
+        with native.wide_operands():
+            _, f_lr, f_hr = self.super_res(self._last_images)
+            self.filter_hr(f_hr)
+            self.filter_lr(f_lr)
+        return True
 
     def encode_image(self, image):
         """super_res -> filter_hr -> filter_lr of ONE view without touching the model's state: returns the two feature maps
@@ -186,8 +199,8 @@ class SuRSNet:
                 raise NotImplementedError("one subject per call: points must be [1,3,N] (gen_mesh never batches subjects)")
             pts = points[0].to(dev, torch.float32).contiguous()
             calib = calibs[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
-            fl, fh = self.features()
-            phr, plr = native.query_points(pts, calib, zmul, zdiv, fl, fh, self._mlp_blob(), self._workspace())
+            run = lambda: native.query_points(pts, calib, zmul, zdiv, *self.features(), self._mlp_blob(), self._workspace())
+            phr, plr = self._finite_or_wide(run)
             return phr.view(1, 1, -1), plr.view(1, 1, -1)
         # multi-view and / or perspective: the view mean of SurfaceClassifier.py:70-76 needs every view of the one subject
         # in the call: points [V,3,N] as reshape_sample_tensor (train_util.py:40-51) lays them out, calibs [V,4,4]
@@ -201,9 +214,29 @@ class SuRSNet:
             raise RuntimeError("the encoder ran on %d views, num_views is %d" % (fl.shape[0], V))
         pts = points.to(dev, torch.float32).contiguous()
         cal = calibs.detach().to("cpu", torch.float32).numpy().reshape(V, -1)[:, :12]
-        phr, plr = native.query_points_views(pts, cal, self.projection_mode, zmul, zdiv, fl, fh, self._mlp_blob(),
-                                             self._workspace())
+        def run():
+            fl = self.im_feat_list_lr[-1].to(dev).permute(0, 2, 3, 1).contiguous()
+            fh = self.im_feat_list_hr[0].to(dev).permute(0, 2, 3, 1).contiguous()
+            return native.query_points_views(pts, cal, self.projection_mode, zmul, zdiv, fl, fh, self._mlp_blob(), self._workspace())
+        phr, plr = self._finite_or_wide(run)
         return phr.view(V, 1, -1), plr.view(V, 1, -1)
+
+    def _finite_or_wide(self, run):
+        """run() -> (pred_hr, pred_lr).  The fp32 point kernels carry their operands as two f16 parts (|x| < 65504); the reference
+        is plain fp32.  Non-finite predictions (the callers copy them to the host next, so the check costs no extra
+        synchronisation) are computed again on three bf16 parts - fp32's exponent range -, after re-running the encoder the same
+        way if its features are what overflowed."""
+        phr, plr = run()
+        if bool(torch.isfinite(phr).all()) and bool(torch.isfinite(plr).all()):
+            return phr, plr
+        import warnings
+        warnings.warn("query: non-finite predictions from the two-part f16 operand split; repeating on three bf16 parts", stacklevel=3)
+        with native.wide_operands():
+            fl, fh = self.features() if self.num_views == 1 else (self.im_feat_list_lr[-1], self.im_feat_list_hr[0])
+            feats_ok = bool(torch.isfinite(fl.buf if hasattr(fl, "buf") else fl).all()) and bool(torch.isfinite(fh.buf if hasattr(fh, "buf") else fh).all())
+            if not feats_ok:
+                self.reencode_wide()
+            return run()
 
     def query_mr(self, points, calibs, transforms=None, labels=None):
         """Evaluates both classifiers in one fused pass; preds_hr is kept for the following query_sr."""

@@ -76,11 +76,39 @@ class Img:
         return img
 
 
+import contextlib
+import threading
+
+_wide = threading.local()
+
+
+@contextlib.contextmanager
+def wide_operands():
+    """Everything computed inside runs its fp32-grade matrix products on three bf16 parts per operand (fp32's exponent range)
+    instead of two f16 parts (|x| < 65504): the point / octree / multi-view kernels and the GEMMs behind the sweep through the
+    calling thread's operand split (surs_set_operand_split_local), the encoder's 3x3 convolutions through ConvWeights'
+    bf16 x 3 image (packed on first use).  What reconstruction() and SuRSNet.query_* repeat a computation under after it produced
+    non-finite values - the reference is plain fp32 and has no such range limit."""
+    prev = getattr(_wide, "on", False)
+    _wide.on = True
+    check(lib().surs_set_operand_split_local(3))
+    try:
+        yield
+    finally:
+        _wide.on = prev
+        check(lib().surs_set_operand_split_local(3 if prev else 0))
+
+
+def wide_operands_active():
+    return getattr(_wide, "on", False)
+
+
 class ConvWeights:
     """Packed conv weights ([tap][cin_pad][cout_pad]) + bias on the device."""
 
     def __init__(self, w, b, device):
         w = np.ascontiguousarray(w, np.float32)
+        self._host_w, self._w3_wide = w, None
         self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
         n = lib().surs_conv_pack_weights(None, self.cout, self.cin, self.k, None)
         packed = np.empty(n, np.float32)
@@ -98,6 +126,18 @@ class ConvWeights:
             pack(w.ctypes.data_as(C.c_void_p), self.cout, self.cin, self.k, buf.ctypes.data_as(C.c_void_p))
             self.w3 = torch.from_numpy(buf).to(device)
 
+    def split_image(self):
+        """(packed split weights, parts) for the 3x3 / stride-1 kernel; inside wide_operands() the bf16 x 3 image, packed on first use."""
+        if self.w3 is None or self.parts == 3 or not wide_operands_active():
+            return self.w3, self.parts
+        if self._w3_wide is None:
+            pack = lib().surs_conv_pack_weights_x3
+            nb = pack(None, self.cout, self.cin, self.k, None)
+            buf = np.empty(nb, np.uint8)
+            pack(self._host_w.ctypes.data_as(C.c_void_p), self.cout, self.cin, self.k, buf.ctypes.data_as(C.c_void_p))
+            self._w3_wide = torch.from_numpy(buf).to(self.w.device)
+        return self._w3_wide, 3
+
 
 def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope=0.0, residual=None):
     pad = cw.k // 2
@@ -107,7 +147,8 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
         out = Img(ho, wo, cw.cout, device=x.buf.device)
     assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
     x3 = cw.w3 is not None and stride == 1 and x.c % 16 == 0 and x.ld % 4 == 0 and (x.buf.data_ptr() + 4 * x.off) % 16 == 0
-    fn, wt = ((lib().surs_conv2d_nhwc_x3 if cw.parts == 3 else lib().surs_conv2d_nhwc_x2), cw.w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
+    w3, parts = cw.split_image() if x3 else (None, 0)
+    fn, wt = ((lib().surs_conv2d_nhwc_x3 if parts == 3 else lib().surs_conv2d_nhwc_x2), w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
     check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
              residual.ptr() if residual is not None else None,

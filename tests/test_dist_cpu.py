@@ -153,6 +153,38 @@ def test_slab_mesh_assembly_world2():
     _run_assemble(2)
 
 
+def test_slab_mesh_assembly_point_to_point(monkeypatch):
+    """The cross-node delivery (meshes sent to dst point to point) instead of the shared-memory blocks of one node."""
+    monkeypatch.setenv("SURS_SLAB_P2P", "1")
+    _run_assemble(3)
+
+
+def _failing_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    empty = [(torch.empty((0, 3), dtype=torch.float64), torch.empty((0, 3), dtype=torch.int32))] * 2
+    nan = float("nan")
+    try:
+        sdist.assemble_slab_meshes(empty, [(0, 0, nan, nan)] * 2 if rank == 1 else [(5, 7, 0.0, 1.0)] * 2, None, None, 8, torch.device("cpu"),
+                                   status=2 if rank == 1 else 0, failure=MemoryError("rank 1 ran out of memory") if rank == 1 else None)
+        out[rank] = "no error"
+    except MemoryError as e:
+        out[rank] = "MemoryError"
+    except RuntimeError as e:
+        out[rank] = "RuntimeError: " + str(e)
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_raises_on_every_rank():
+    """A rank that fails in its sweep carries a status flag into the counts exchange: it re-raises its own exception, the others
+    raise too instead of waiting in the next collective."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_failing_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert out[1] == "MemoryError" and out[0].startswith("RuntimeError") and "rank(s) [1]" in out[0] and out[2] == out[0], dict(out)
+
+
 def test_slab_mesh_assembly_world3_ragged():
     _run_assemble(3)
 

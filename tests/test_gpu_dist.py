@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-@pytest.mark.parametrize("world,R", [(2, 40), (3, 50)])
+@pytest.mark.parametrize("world,R", [(2, 40), (3, 50), (2, 512), (4, 512)])
 def test_sharded_reconstruction_equals_single_process(world, R):
+    """(world, 512): BASELINE's full grid, 2 and 4 ranks sharing the one GPU - the slab kernels, the halo / counts / boundary-id
+    exchange and the shared-memory mesh delivery at the size configs[3] runs them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_slab_check.py"), str(world), str(R)], capture_output=True,
                        text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -42,3 +44,32 @@ def test_bench_multi_rank_paths_on_one_gpu(mode):
     assert d["config"]["parallelism"] == mode + "2" and d["config"]["mesh"]["verts_hr"] > 0
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0
+
+
+def test_nccl_backend_world_size_one():
+    """The RCCL code path of dist.py that a single-GPU box can execute: init_process_group("nccl", device_id=...) as bench.py
+    calls it, all_gather_rows on device tensors, an Exchange with an empty point-to-point batch, barrier, gather_slabs and
+    reconstruction_sharded with one rank (no 8-GPU node has been available to run more)."""
+    code = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(29400 + os.getpid() %% 500)
+dev = torch.device('cuda', 0); torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+from surs_amd import dist as sdist
+rows = sdist.all_gather_rows([1.0, 2.5, float('nan')], dev)
+assert rows.shape == (1, 3) and rows[0, 1] == 2.5 and np.isnan(rows[0, 2])
+sdist.Exchange().start().wait()
+t = torch.arange(8 * 4 * 4, dtype=torch.float32, device=dev).reshape(8, 4, 4)
+assert sdist.gather_slabs(t, 8) is t
+dist.barrier()
+x = torch.ones(4, device=dev); dist.all_reduce(x); assert float(x.sum()) == 4.0
+sub = dist.new_group([0])
+assert sdist.all_gather_rows([3.0], dev, sub)[0, 0] == 3.0 and sdist._global_rank(sub, 0) == 0
+dist.destroy_process_group()
+print('nccl world 1 ok')
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nccl world 1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

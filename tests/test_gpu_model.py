@@ -275,14 +275,36 @@ def test_fp32_sweep_falls_back_when_f16_range_overflows():
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = mesh_util.reconstruction(common.opt(), net, dev, calib, R, b_min, b_max, use_octree=False, want_normals=False)
-    assert any("f16 range" in str(x.message) for x in w)
+    assert any("f16 operand split" in str(x.message) for x in w)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[5], want[5])
     # the second reconstruction of a workspace takes the streamed path (extraction beside the sweep): same answer
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = mesh_util.reconstruction(common.opt(), net, dev, calib, R, b_min, b_max, use_octree=False, want_normals=False)
-    assert any("f16 range" in str(x.message) for x in w)
+    assert any("f16 operand split" in str(x.message) for x in w)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[5], want[5])
+    # every other branch has the same way out (the reference is plain fp32 and has no range limit).  The octree sweep -
+    # gen_mesh's default - evaluates its lattice points with the point kernels: repeated under native.wide_operands()
+    from surs_amd import native
+    with native.wide_operands():
+        want_o = mesh_util.reconstruction(common.opt(), net, dev, calib, R, b_min, b_max, use_octree=True, want_normals=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got_o = mesh_util.reconstruction(common.opt(), net, dev, calib, R, b_min, b_max, use_octree=True, want_normals=False)
+    assert any("f16 operand split" in str(x.message) for x in w)
+    assert len(got_o[0]) > 0 and np.array_equal(got_o[0], want_o[0]) and np.array_equal(got_o[1], want_o[1])
+    # ... and so do the per-batch methods: finite predictions, equal to the three-part computation
+    pts = torch.from_numpy(weights.synthetic_points(3000, seed=4)[None]).to(dev)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net.query_mr(pts, calib)
+    assert any("non-finite predictions" in str(x.message) for x in w)
+    phr, plr = net.get_preds()
+    assert bool(torch.isfinite(phr).all()) and bool(torch.isfinite(plr).all())
+    with native.wide_operands():
+        fl_i, fh_i = net.features()
+        w_hr, w_lr = native.query_points(pts[0], common.CALIB.reshape(-1)[:12], *net._zscale(), fl_i, fh_i, net._mlp_blob(), net._workspace())
+    assert torch.equal(phr.view(-1), w_hr) and torch.equal(plr.view(-1), w_lr)
 
 
 def test_multiview_octree_vs_oracle(golden_dir):
