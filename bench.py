@@ -253,7 +253,7 @@ def main():
                 rows.append(row)
             del vh, vl
             extras["listed_sensitivity"] = {"what": "%d^3 sweep alone (no encoder, no marching cubes), layer-0 depth column x gain" % R,
-                                            "dense_threshold_listed": native.LISTED_DENSE_THRESHOLD, "rows": rows}
+                                            "dense_threshold_listed": native.LISTED_DENSE_THRESHOLDS[args.precision], "rows": rows}
         except Exception as e:
             lib.surs_set_grid_kernel(0)
             extras["dense_floor"] = {"error": repr(e)}

@@ -364,7 +364,10 @@ def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, d
     return vol_hr, vol_lr
 
 
-LISTED_DENSE_THRESHOLD = 400.0   # mean listed channels per tile above which the dense column kernels are the faster ones
+# mean listed channels per tile above which the dense column kernels are the faster ones (profiles/r03_listed_sensitivity.json:
+# the eight-wave bf16 / fp16 kernel still wins at 490 listed - 254 against 290 ms at 512^3 - and gains 0.3 ms per listed channel)
+LISTED_DENSE_THRESHOLD = 400.0
+LISTED_DENSE_THRESHOLDS = {"fp32": 400.0, "bf16": 600.0, "fp16": 600.0}
 
 
 def probe_listed(i_plane, ry, rz, tile, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws):
@@ -394,7 +397,7 @@ def grid_kernel_for(rx, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, 
     if dtype not in ("fp32", "bf16", "fp16") or ry > 16384:
         return 0
     lr, _ = probe_listed(rx // 2, ry, rz, 64 if dtype == "fp32" else 128, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
-    kern = (5 if dtype == "fp32" else 3) if lr > LISTED_DENSE_THRESHOLD else 0
+    kern = (5 if dtype == "fp32" else 3) if lr > LISTED_DENSE_THRESHOLDS[dtype] else 0
     ws.kernel_choice = (kern, lr)
     ws.probes = getattr(ws, "probes", 0) + 1
     return kern

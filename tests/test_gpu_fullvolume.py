@@ -7,8 +7,10 @@ feature maps): every voxel of the default kernels' volumes against the dense-lay
 
 on three fields: the bench's noise-like field, the smooth closed body field, and the noise field with layer 0's depth
 column scaled by 60 (nearly every channel changes branch inside a tile: multi-chunk lists at full size).  Measured in logit
-space (float64 from the occupancies) and as the number of voxels on the other side of the 0.5 level.  Bounds: about twice
-the values measured on MI355X (profiles/r03_fullvolume.json)."""
+space and as the number of voxels on the other side of the 0.5 level.  The logits are recovered in float64 from the fp32
+occupancies where those resolve them to 1e-5 (|logit| < 5: an occupancy within 6e-8 of 1 says nothing about its logit at
+1e-4); the saturated voxels are compared as occupancies (2e-6).  Bounds: about twice the values measured on MI355X
+(profiles/r03_fullvolume.json)."""
 import os
 import sys
 
@@ -24,9 +26,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 R = 512
 #                 fp32-grade: max|dlogit|, flipped      fp16: max|dlogit|, mean|dlogit|, flipped fraction
 BOUNDS = {
-    "noise": ((1e-4, 100), (0.02, 0.002, 1e-3)),
-    "body": ((1e-4, 100), (0.2, 0.02, 1e-3)),
-    "gain60": ((1e-3, 2000), (0.5, 0.02, 1e-2)),
+    "noise": ((2.5e-5, 40), (2.2e-3, 2.4e-4, 1.5e-4)),
+    "body": ((4e-5, 4), (1.6e-2, 1.6e-3, 2.6e-5)),
+    "gain60": ((1.4e-3, 40), (2.2e-2, 1.5e-3, 2.1e-4)),
 }
 
 
@@ -55,26 +57,28 @@ def test_restated_kernels_equal_dense_kernels_on_the_whole_volume(field):
     ref, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=5)
     new, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=8)
     for i, tag in enumerate(("hr", "lr")):
-        st = pr.field_stats(new["fp32"][i], ref["fp32"][i])
+        st = pr.field_stats(new["fp32"][i], ref["fp32"][i], plim=0.0067)
         out["v8_vs_v5_" + tag] = st
         print(field, "v8 vs v5", tag, st)
         assert bool(torch.isfinite(new["fp32"][i]).all())
-        assert st["max_abs_dlogit"] < b32_max and st["flipped_voxels"] <= b32_flip, (field, tag, st)
+        assert st["max_abs_dlogit"] < b32_max and st["flipped_voxels"] <= b32_flip and st["max_abs_docc"] < 0.3 * b32_max + 2e-6, (field, tag, st)
     del ref, new
     # fp16 pairs
     ref, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp16",), dev, kernel=3)
     for kv in (7, 10):
         new, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp16",), dev, kernel=kv)
         for i, tag in enumerate(("hr", "lr")):
-            st = pr.field_stats(new["fp16"][i], ref["fp16"][i])
+            st = pr.field_stats(new["fp16"][i], ref["fp16"][i], plim=0.0067)
             out["v%d_vs_v3_%s" % (kv, tag)] = st
             print(field, "v%d vs v3 fp16" % kv, tag, st)
             assert bool(torch.isfinite(new["fp16"][i]).all())
             assert st["max_abs_dlogit"] < b16_max and st["mean_abs_dlogit"] < b16_mean and st["flipped_fraction"] < b16_flip, (field, kv, tag, st)
-        del new
+        if kv == 10:   # the eight-wave kernel reproduces the four-wave kernel's bits
+            assert all(torch.equal(a, b) for a, b in zip(new["fp16"], prev)), field
+        prev = new["fp16"]
     dump = os.environ.get("SURS_FULLVOLUME_JSON")
     if dump:
         import json
-        prev = json.load(open(dump)) if os.path.exists(dump) else {}
-        prev[field] = out
-        json.dump(prev, open(dump, "w"), indent=1)
+        allf = json.load(open(dump)) if os.path.exists(dump) else {}
+        allf[field] = out
+        json.dump(allf, open(dump, "w"), indent=1)

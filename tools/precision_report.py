@@ -37,8 +37,9 @@ def _upload(feat_chw, dev):
     return native.Img(h, w, c, c, t.reshape(-1))
 
 
-def field_stats(v, ref, chunk=1 << 24):
-    """v, ref: float32 device volumes of occupancies.  Logits are recovered in float64 (exact to ~1e-7 away from 0 / 1)."""
+def field_stats(v, ref, chunk=1 << 24, plim=1e-6):
+    """v, ref: float32 device volumes of occupancies.  Logits are recovered in float64 from voxels with plim < p < 1 - plim: an fp32
+    occupancy resolves its logit to 6e-8 / min(p, 1 - p) only (1e-5 at plim = 0.0067, i.e. |logit| < 5; 0.06 at plim = 1e-6)."""
     a, b = v.reshape(-1), ref.reshape(-1)
     n = a.numel()
     mx_l = sum_l = 0.0
@@ -49,7 +50,7 @@ def field_stats(v, ref, chunk=1 << 24):
         x, y = a[s:s + chunk].double(), b[s:s + chunk].double()
         mx_p = max(mx_p, (x - y).abs().max().item())
         flips += int(((x > 0.5) != (y > 0.5)).sum().item())
-        ok = (x > 1e-6) & (x < 1 - 1e-6) & (y > 1e-6) & (y < 1 - 1e-6)
+        ok = (x > plim) & (x < 1 - plim) & (y > plim) & (y < 1 - plim)
         d = (torch.log(x / (1 - x)) - torch.log(y / (1 - y))).abs()[ok]
         if d.numel():
             mx_l = max(mx_l, d.max().item())
