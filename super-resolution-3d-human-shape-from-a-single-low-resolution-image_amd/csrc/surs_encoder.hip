@@ -475,58 +475,211 @@ static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipSt
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
+// ---------------------------------------------------------------- 1x1 convolution (pointwise), split-f16 operands
+// Y[pix][co] = bias[co] + sum_c X'[pix][c] W[co][c]: HBM-bound (one read of the input, one write of the output), so the whole
+// output row of a pixel is produced from ONE read of its input row: a workgroup takes 128 pixels x CT * 64 output channels
+// (all 256 of the hourglass's 1x1 convolutions), wave (ph, ch) = pixels [64 ph, + 64) x channels [32 CT ch, + 32 CT).
+// Activations go from global memory straight into MFMA A fragments (lane = pixel, 8 consecutive channels = 32 contiguous
+// bytes of the NHWC row; the fused GroupNorm-apply + ReLU and the hi / lo split happen in registers: no LDS staging, no
+// barrier in the loop), the weights come as B fragments from the packer's split image (surs_conv_pack_weights_x2 with one
+// tap: L2 resident).  Products as in conv_x3_kernel<..., 2>: x_lo w_hi + x_hi w_lo + x_hi w_hi in fp32.  The fp32-MFMA kernel
+// it replaces re-read the input once per 64 output channels and ran at 0.7 TB/s (185 us per 256^2 x 256 -> 256 layer).
+template <int CT>
+__global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
+    typedef ConvSplit<2> CS;
+    typedef typename CS::vec8 vec8;
+    __shared__ float gn[2 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ph = wave & 1, ch = wave >> 1, li = lane & 31, kh = lane >> 5;
+    const long long npix = (long long)a.h * a.w;
+    const long long p0 = (long long)blockIdx.x * 128 + 64 * ph;
+    const int n0 = blockIdx.y * (64 * CT) + 32 * CT * ch;
+    const int nch = a.cin_pad / CK;
+    const size_t per_part = (size_t)nch * a.cout_pad * 16;
+    if (a.in_scale) {
+        for (int c = tid; c < a.cin_pad; c += 256) {
+            gn[c] = c < a.cin ? a.in_scale[c] : 0.f;
+            gn[1024 + c] = c < a.cin ? a.in_shift[c] : 0.f;
+        }
+        __syncthreads();
+    }
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][j][q] = 0.0f;
+    const float *xp[2];
+    bool ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long pix = p0 + 32 * t + li;
+        ok[t] = pix < npix;
+        xp[t] = a.x + (size_t)(ok[t] ? pix : 0) * a.x_ld + 8 * kh;
+    }
+    const unsigned short *wq = wsplit + ((size_t)n0 + li) * 16 + 8 * kh;
+    f32x4 xa[2][2], xn[2][2];
+    vec8 wb[CT][2];
+    auto fetch_x = [&](int s, f32x4 (&xx)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xx[t][0] = *reinterpret_cast<const f32x4 *>(xp[t] + s * CK);
+            xx[t][1] = *reinterpret_cast<const f32x4 *>(xp[t] + s * CK + 4);
+        }
+    };
+    fetch_x(0, xa);
+    for (int s = 0; s < nch; ++s) {
+        // this k-step's weight fragments (L2) and the next k-step's activations (HBM) are in flight while the activations of
+        // this one are normalised and split
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wb[j][p] = *reinterpret_cast<const vec8 *>(wq + p * per_part + ((size_t)s * a.cout_pad + 32 * j) * 16);
+        if (s + 1 < nch) fetch_x(s + 1, xn);
+        vec8 ah[2], al[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unsigned short hi[8], lo[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float v = xa[t][q >> 2][q & 3];
+                if (a.in_scale) v = fmaxf(v * gn[s * CK + 8 * kh + q] + gn[1024 + s * CK + 8 * kh + q], 0.f);
+                v = ok[t] ? v : 0.f;
+                unsigned short parts[2];
+                CS::split(v, parts);
+                hi[q] = parts[0];
+                lo[q] = parts[1];
+            }
+            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+            const u16x8 h8 = {hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]}, l8 = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+            ah[t] = __builtin_bit_cast(vec8, h8);
+            al[t] = __builtin_bit_cast(vec8, l8);
+        }
+        // the partial products that matter, smallest first
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[t][j] = CS::mfma(al[t], wb[j][0], acc[t][j]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[t][j] = CS::mfma(ah[t], wb[j][1], acc[t][j]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[t][j] = CS::mfma(ah[t], wb[j][0], acc[t][j]);
+        if (s + 1 < nch) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xa[t][0] = xn[t][0];
+                xa[t][1] = xn[t][1];
+            }
+        }
+    }
+    // ---- epilogue: register q of a tile is pixel (q & 3) + 8 (q >> 2) + 4 (lane >> 5) of the tile, lane & 31 is the channel
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int co = n0 + 32 * j + li;
+            if (co >= a.cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long pix = p0 + 32 * t + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                if (pix >= npix) continue;
+                float v = acc[t][j][q] + b;
+                if (a.act == 1) v = v > 0.f ? v : a.slope * v;
+                if (a.res) v += a.res[(size_t)pix * a.res_ld + co];
+                a.y[(size_t)pix * a.y_ld + co] = v;
+            }
+        }
+}
+
+static int launch_conv1x1_x2(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
+    SURS_REQUIRE(a.cin_pad <= 1024, "split-operand convolution: at most 1024 input channels");
+    const long long npix = (long long)a.h * a.w;
+    const unsigned gx = (unsigned)((npix + 127) / 128);
+    if (a.cout_pad % 256 == 0)
+        hipLaunchKernelGGL(conv1x1_x2_kernel<4>, dim3(gx, a.cout_pad / 256), dim3(256), 0, st, a, wsplit);
+    else
+        hipLaunchKernelGGL(conv1x1_x2_kernel<1>, dim3(gx, a.cout_pad / 64), dim3(256), 0, st, a, wsplit);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- GroupNorm coefficients
-// two launches: (1) GN_SPLIT workgroups per group reduce a pixel slice each (double sums of x and x^2, NHWC reads
-// coalesced over the group's channels and consecutive pixels), (2) one small launch folds the partials with the affine
-// parameters.  One workgroup per group (32 workgroups on 256 CUs) took 15 of the encoder's 28 ms.
-constexpr int GN_SPLIT = 64;
+// two launches: (1) GN_SPLIT workgroups reduce a pixel slice each - ALL channels of it, so that the NHWC rows are read whole and
+// coalesced (16 bytes per thread): double sums of x and x^2 per thread and channel quad, folded per group in a fixed order; (2)
+// one small launch folds the partials with the affine parameters.  (Round 1: one workgroup per group took 15 of the encoder's
+// 28 ms; round 2: one workgroup per (group, slice) read 32-byte pieces with a division per element: 1.4 TB/s.)
+constexpr int GN_SPLIT = 512;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict__ x, int hw, int c, int x_ld, int groups,
                                                          double *__restrict__ partial /* [groups][GN_SPLIT][2] */) {
-    __shared__ double red[2][4];
-    const int g = blockIdx.x, sp = blockIdx.y, cg = c / groups;
+    __shared__ double red[256][8];
+    const int sp = blockIdx.x, cg = c / groups, tid = threadIdx.x;
     const int p0 = (int)((long long)hw * sp / GN_SPLIT), p1 = (int)((long long)hw * (sp + 1) / GN_SPLIT);
-    const long long n = (long long)(p1 - p0) * cg;
-    double s = 0.0, ss = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 256) {
-        const long long pix = p0 + i / cg;
-        const int ch = (int)(i % cg);
-        const double v = x[pix * x_ld + g * cg + ch];
-        s += v;
-        ss += v * v;
-    }
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const int c4 = c / 4;                 // channel quads per pixel (the host checks c % 4 == 0, c <= 1024, 16-byte aligned rows)
+    const int ppl = 256 / c4;             // pixels in flight per iteration (>= 1)
+    const int q = tid % c4, pl = tid / c4;
+    if (pl < ppl)
+        for (int p = p0 + pl; p < p1; p += ppl) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (size_t)p * x_ld + 4 * q);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o);
-        ss += __shfl_xor(ss, o);
+            for (int k = 0; k < 4; ++k) {
+                const double d = v[k];
+                s[k] += d;
+                ss[k] += d * d;
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid][k] = s[k];
+        red[tid][4 + k] = ss[k];
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        partial[((size_t)g * GN_SPLIT + sp) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partial[((size_t)g * GN_SPLIT + sp) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (tid < groups) {
+        // channels [g cg, (g + 1) cg): quad ch / 4, element ch % 4, of every pixel lane, in a fixed order
+        double S = 0, SS = 0;
+        for (int l = 0; l < ppl; ++l)
+            for (int ch = tid * cg; ch < (tid + 1) * cg; ++ch) {
+                S += red[l * c4 + ch / 4][ch % 4];
+                SS += red[l * c4 + ch / 4][4 + ch % 4];
+            }
+        partial[((size_t)tid * GN_SPLIT + sp) * 2 + 0] = S;
+        partial[((size_t)tid * GN_SPLIT + sp) * 2 + 1] = SS;
     }
 }
 
-__global__ void gn_finish_kernel(const double *__restrict__ partial, int hw, int c, int groups, float eps,
-                                 const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ scale,
-                                 float *__restrict__ shift) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    const int cg = c / groups, g = ch / cg;
+__global__ __launch_bounds__(64) void gn_finish_kernel(const double *__restrict__ partial, int hw, int c, int groups, float eps,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       float *__restrict__ scale, float *__restrict__ shift) {
+    // one wave per group: lane l adds partials l, l + 64, ... in order, then a butterfly over the lanes - a fixed summation tree
+    const int g = blockIdx.x, lane = threadIdx.x, cg = c / groups;
     double S = 0, SS = 0;
-    for (int sp = 0; sp < GN_SPLIT; ++sp) {   // fixed order: deterministic
+    for (int sp = lane; sp < GN_SPLIT; sp += 64) {
         S += partial[((size_t)g * GN_SPLIT + sp) * 2 + 0];
         SS += partial[((size_t)g * GN_SPLIT + sp) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        S += __shfl_xor(S, o);
+        SS += __shfl_xor(SS, o);
     }
     const double n = (double)hw * cg;
     const double mean = S / n;
     double var = SS / n - mean * mean;
     if (var < 0) var = 0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    scale[ch] = (float)(rstd * gamma[ch]);
-    shift[ch] = (float)(beta[ch] - mean * rstd * gamma[ch]);
+    for (int k = lane; k < cg; k += 64) {
+        const int ch = g * cg + k;
+        scale[ch] = (float)(rstd * gamma[ch]);
+        shift[ch] = (float)(beta[ch] - mean * rstd * gamma[ch]);
+    }
 }
 
 // ---------------------------------------------------------------- small HBM-bound kernels (one thread = one pixel x 4 channels)
@@ -699,9 +852,9 @@ extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_
                                    void *stream) {
     SURS_REQUIRE(x && wsplit && y, "null argument");
     SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
-    SURS_REQUIRE(ksize == 3 && stride == 1, "the split-bf16 kernel is built for 3x3, stride 1");
+    SURS_REQUIRE((ksize == 3 || ksize == 1) && stride == 1, "the split-f16 kernels are built for 3x3 and 1x1, stride 1");
     SURS_REQUIRE(cin % 16 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0,
-                 "the split-bf16 kernel needs cin %% 16 == 0 and 16-byte aligned pixels");
+                 "the split-f16 kernels need cin %% 16 == 0 and 16-byte aligned pixels");
     SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
     SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
     ConvArgs a;
@@ -712,6 +865,7 @@ extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.act = act; a.slope = slope;
     a.res = residual; a.res_ld = res_ld;
+    if (ksize == 1) return launch_conv1x1_x2(a, (const unsigned short *)wsplit, as_stream(stream));
     return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
@@ -734,9 +888,11 @@ extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, in
         if (!slot) SURS_HIP_CHECK(hipMalloc((void **)&slot, sizeof(double) * 64 * GN_SPLIT * 2));
         buf = slot;
     }
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(groups, GN_SPLIT), dim3(256), 0, st, x, hw, c, x_ld, groups, buf);
+    SURS_REQUIRE(c % 4 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && c <= 1024,
+                 "GroupNorm statistics: channels and pitch must be multiples of 4 (16-byte aligned rows), at most 1024 channels");
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SPLIT), dim3(256), 0, st, x, hw, c, x_ld, groups, buf);
     SURS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(ceil_div(c, 256)), dim3(256), 0, st, buf, hw, c, groups, eps, gamma, beta,
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(groups), dim3(64), 0, st, buf, hw, c, groups, eps, gamma, beta,
                        scale, shift);
     SURS_LAUNCH_CHECK();
     return 0;

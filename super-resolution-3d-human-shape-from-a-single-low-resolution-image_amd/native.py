@@ -117,9 +117,10 @@ class ConvWeights:
         self.w = torch.from_numpy(packed).to(device)
         self.b = torch.from_numpy(np.ascontiguousarray(b, np.float32)).to(device) if b is not None else None
         # split image for the 3x3 / stride-1 kernel: two f16 parts (surs_conv2d_nhwc_x2, default) or, with SURS_CONV_SPLIT=bf16x3,
-        # three bf16 parts (surs_conv2d_nhwc_x3: fp32's exponent range); SURS_CONV_X3=0: neither (fp32 MFMA kernel)
+        # three bf16 parts (surs_conv2d_nhwc_x3: fp32's exponent range); SURS_CONV_X3=0: neither (fp32 MFMA kernel).  1x1
+        # convolutions have a two-part kernel only (conv1x1_x2_kernel); with three parts asked for they stay on the fp32 MFMA kernel
         self.w3, self.parts = None, 3 if os.environ.get("SURS_CONV_SPLIT", "f16x2").startswith("b") else 2
-        if self.k == 3 and os.environ.get("SURS_CONV_X3", "1") != "0":
+        if (self.k == 3 or (self.k == 1 and self.parts == 2)) and os.environ.get("SURS_CONV_X3", "1") != "0":
             pack = lib().surs_conv_pack_weights_x3 if self.parts == 3 else lib().surs_conv_pack_weights_x2
             nb = pack(None, self.cout, self.cin, self.k, None)
             buf = np.empty(nb, np.uint8)
@@ -130,6 +131,8 @@ class ConvWeights:
         """(packed split weights, parts) for the 3x3 / stride-1 kernel; inside wide_operands() the bf16 x 3 image, packed on first use."""
         if self.w3 is None or self.parts == 3 or not wide_operands_active():
             return self.w3, self.parts
+        if self.k == 1:
+            return None, 0    # (1x1: the plain fp32 MFMA kernel is the wide form)
         if self._w3_wide is None:
             pack = lib().surs_conv_pack_weights_x3
             nb = pack(None, self.cout, self.cin, self.k, None)
@@ -148,6 +151,7 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
     assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
     x3 = cw.w3 is not None and stride == 1 and x.c % 16 == 0 and x.ld % 4 == 0 and (x.buf.data_ptr() + 4 * x.off) % 16 == 0
     w3, parts = cw.split_image() if x3 else (None, 0)
+    x3 = x3 and w3 is not None
     fn, wt = ((lib().surs_conv2d_nhwc_x3 if parts == 3 else lib().surs_conv2d_nhwc_x2), w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
     check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
