@@ -166,7 +166,7 @@ def main():
         flop_exec = FLOP_EXECUTED * nprod if kavg is None else 2 * (2 * (512 * 256 + 256 * 128) * nprod + (kavg * nprod + 1.0) * 16 * 512 * 2)
         exe = k_pts * flop_exec / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         peak = PEAK_MFMA / 1e12
-        r = {"kernel": "grid_mlp_kernel_v%s (split-f16, 3 products per MAC)" % os.environ.get("SURS_GRID_F32_KERNEL", "8")[:1] if prec == "fp32" else
+        r = {"kernel": "grid_mlp_kernel_v%s (split-f16, 3 products per MAC)" % os.environ.get("SURS_GRID_F32_KERNEL", "11") if prec == "fp32" else
                        "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "10"), prec),
              "bound": "mfma", "unit": "TFLOP/s",
              # contract fields = what the matrix pipe EXECUTES per launch / the launch's duration against the dense f16 / bf16 MFMA
@@ -242,8 +242,8 @@ def main():
                 lr, hr = native.probe_listed(R // 2, R, R, tile, mat, cal, zmul, zdiv, fl, fh, blob, ws)
                 pick = native.grid_kernel_for(R, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws)
                 row = {"gain": gain, "listed_lr_per_tile": lr, "listed_hr_per_tile_upper": hr,
-                       "host_picks": pick or (8 if args.precision == "fp32" else 10)}
-                for name, kern in (("restated_ms", 8 if args.precision == "fp32" else 10), ("dense_ms", 5 if args.precision == "fp32" else 3)):
+                       "host_picks": pick or (11 if args.precision == "fp32" else 10)}
+                for name, kern in (("restated_ms", 11 if args.precision == "fp32" else 10), ("dense_ms", 5 if args.precision == "fp32" else 3)):
                     native.query_grid(0, 32, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws, vh[:32], vl[:32], kernel=kern)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()

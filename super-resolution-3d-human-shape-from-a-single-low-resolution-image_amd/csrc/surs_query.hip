@@ -597,6 +597,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 #include "surs_grid_v7.inc"
 #include "surs_grid_v10.inc"
 #include "surs_grid_v8.inc"
+#include "surs_grid_v11.inc"
 
 // Column kernel v7's per-column affine part, step 1: the vectors g . a0, g . w0z (lr) and g . a0, g . w0z, g . w0p (hr) of a
 // column batch as the split image [parts][1024 / 16][nvec * ncp][16] that the layer GEMM kernel reads as its point operand
@@ -688,11 +689,14 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 #ifndef SURS_DEFAULT_GRID_KERNEL
 #define SURS_DEFAULT_GRID_KERNEL 10
 #endif
+#ifndef SURS_DEFAULT_GRID_F32_KERNEL
+#define SURS_DEFAULT_GRID_F32_KERNEL 11
+#endif
 static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
-static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 7 || v == 10 || v == 5 || v == 8; }
+static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 7 || v == 10 || v == 5 || v == 8 || v == 11; }
 extern "C" int surs_set_grid_kernel(int version) {
     SURS_REQUIRE(grid_kernel_known(version),
-                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3, 7 or 10, fp32-grade 5 or 8");
+                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3, 7 or 10, fp32-grade 5, 8 or 11");
     g_grid_kernel_override = version;
     return 0;
 }
@@ -990,6 +994,7 @@ static int grid_set_attributes() {
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v8, hipFuncAttributeMaxDynamicSharedMemorySize, GRID8_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v11, hipFuncAttributeMaxDynamicSharedMemorySize, GRID11_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
     return 0;
@@ -1094,7 +1099,7 @@ extern "C" int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double 
     if (opt) {
         kernel = opt->kernel;
         parts = opt->operand_parts;
-        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 7, 10 (reduced precision), 5, 8 (fp32-grade)");
+        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 7, 10 (reduced precision), 5, 8, 11 (fp32-grade)");
         SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "SursGridOptions.operand_parts: 0, 2 or 3");
     }
     // the operand split is read deep inside the launch helpers: scoped to this call and this thread, the process setting
@@ -1174,8 +1179,8 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
     // Column kernel of this sweep.  Reduced precision: 10 (default) = layer 1 restated along the column as a per-column affine
     // part + the residuals of the channels whose LeakyReLU branch changes inside the z tile, eight waves per workgroup; 7 = the
     // same arithmetic on four waves (its regression reference); 3 = dense layer 1 (what the host asks for on fields that list most
-    // channels; differs from 7 / 10 by a few 16-bit roundings of layer 0).  fp32-grade (SURS_F32): 8 (default, restated) or 5
-    // (dense).  Precedence: the call's SursGridOptions.kernel, then surs_set_grid_kernel, then SURS_GRID_KERNEL /
+    // channels; differs from 7 / 10 by a few 16-bit roundings of layer 0).  fp32-grade (SURS_F32): 11 (default: restated, eight
+    // waves), 8 (the same on four waves) or 5 (dense).  Precedence: the call's SursGridOptions.kernel, then surs_set_grid_kernel, then SURS_GRID_KERNEL /
     // SURS_GRID_F32_KERNEL, then the default.
     static int kver_env = -1;
     if (kver_env < 0) {
@@ -1186,13 +1191,14 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
     static int kver32_env = -1;
     if (kver32_env < 0) {
         const char *e = getenv("SURS_GRID_F32_KERNEL");
-        kver32_env = (e && e[0] == '5') ? 5 : 8;
+        const int v = e ? atoi(e) : 0;
+        kver32_env = (v == 5 || v == 8 || v == 11) ? v : SURS_DEFAULT_GRID_F32_KERNEL;
     }
-    const auto is32 = [](int v) { return v == 5 || v == 8; };
+    const auto is32 = [](int v) { return v == 5 || v == 8 || v == 11; };
     int kver = kver_env, kver32 = kver32_env;
     if (g_grid_kernel_override) (is32(g_grid_kernel_override) ? kver32 : kver) = g_grid_kernel_override;
     if (kernel_call) (is32(kernel_call) ? kver32 : kver) = kernel_call;
-    const bool restated = dtype == SURS_F32 ? kver32 == 8 : (kver == 7 || kver == 10);
+    const bool restated = dtype == SURS_F32 ? (kver32 == 8 || kver32 == 11) : (kver == 7 || kver == 10);
     if ((rc = grid_set_attributes())) return rc;
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
@@ -1309,7 +1315,9 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
         if (dtype == SURS_F32) {
-            if (kver32 == 8)
+            if (kver32 == 11)
+                hipLaunchKernelGGL(grid_mlp_kernel_v11, dim3(grid), dim3(V11_THREADS), GRID11_LDS_BYTES, st, a);
+            else if (kver32 == 8)
                 hipLaunchKernelGGL(grid_mlp_kernel_v8, dim3(grid), dim3(256), GRID8_LDS_BYTES, st, a);
             else
                 hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);

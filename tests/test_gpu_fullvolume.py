@@ -2,7 +2,8 @@
 feature maps): every voxel of the default kernels' volumes against the dense-layer-1 kernels they restate
 (lib/model/SurfaceClassifier.py:53-81 along lib/sdf.py:32-52's sweep) -
 
-  * fp32-grade: v8 (restated) against v5 (dense layer 1, the frame the 1e-4 parity tests of round 1 were run on),
+  * fp32-grade: v11 = v8 bit for bit (restated, eight / four waves) against v5 (dense layer 1, the frame the 1e-4 parity
+    tests of round 1 were run on),
   * fp16:       v10 and v7 (restated, eight / four waves) against v3 (dense layer 1),
 
 on three fields: the bench's noise-like field, the smooth closed body field, and the noise field with layer 0's depth
@@ -55,7 +56,10 @@ def test_restated_kernels_equal_dense_kernels_on_the_whole_volume(field):
     out = {}
     # fp32-grade pair
     ref, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=5)
-    new, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=8)
+    v8, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=8)
+    new, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=11)
+    assert all(torch.equal(a, b) for a, b in zip(new["fp32"], v8["fp32"])), field   # the eight-wave kernel reproduces v8's bits
+    del v8
     for i, tag in enumerate(("hr", "lr")):
         st = pr.field_stats(new["fp32"][i], ref["fp32"][i], plim=0.0067)
         out["v8_vs_v5_" + tag] = st

@@ -1,7 +1,8 @@
-"""Column kernel v10 (eight waves) against v7 (four waves, the same restated arithmetic): bitwise comparison on small and
-full-size grids (noise field; R = 24 runs many chunks per tile) and sweep times.
+"""The eight-wave column kernels against their four-wave forms (the same restated arithmetic: v10 vs v7 in bf16 / fp16, v11 vs
+v8 fp32-grade): bitwise comparison on small and full-size grids (noise field; R = 24 runs many chunks per tile) and sweep
+times on the same device.
 
-    python tools/gpu_v10_check.py [R_big]
+    python tools/gpu_v10_check.py [R_big] [kernels, e.g. 7,10 | 8,11] [precisions, e.g. bf16,fp16 | fp32]
 """
 import os
 import sys
@@ -21,15 +22,16 @@ from surs_amd import native  # noqa: E402
 def main():
     Rb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     kernels = [int(k) for k in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["7", "10"])]
+    precs = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("bf16", "fp16")
     dev = native.require_gpu()
     sd, Fl, Fh, keep = pr.noise_inputs(dev)
     for R in (24, 40, 136, Rb):
         res = {}
         for kv in kernels:
-            vols, times, _ = pr.sweeps(sd, Fl, Fh, R, ("bf16", "fp16"), dev, kernel=kv)
+            vols, times, _ = pr.sweeps(sd, Fl, Fh, R, precs, dev, kernel=kv)
             res[kv] = vols
             print("R=%d kernel v%d sweep seconds: %s" % (R, kv, {k: round(v, 4) for k, v in times.items()}), flush=True)
-        for prec in ("bf16", "fp16"):
+        for prec in precs:
             for i, tag in enumerate(("hr", "lr")):
                 a, b = res[kernels[0]][prec][i], res[kernels[-1]][prec][i]
                 d = (a - b).abs().max().item()
