@@ -10,7 +10,7 @@ import csv, glob, json, os, sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 PRODUCTS = {"bf16": 1, "fp32": 3}
 
 
@@ -95,6 +95,32 @@ def one(prec):
         "affine_fragment_bytes_per_launch": 16384 * 32768 if tiles else 0,   # kernels v7 / v8: [column][MLP][16][64][8] 16-bit
     }
 
+
+def sq(prec):
+    """Averages per launch of every SQ counter collected for the column kernel of `prec` (tools/profile_round.sh)."""
+    out = {}
+    for sub in ("pmc_sq1_" + prec, "pmc_sq2_" + prec):
+        acc = {}
+        for f in glob.glob(os.path.join(SRC, sub, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "grid_mlp_kernel" in r["Kernel_Name"]:
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                    out["kernel"] = r["Kernel_Name"]
+        for k, v in acc.items():
+            out[k] = sum(v) / len(v)
+    if "SQ_WAVE_CYCLES" in out:
+        w = out["SQ_WAVE_CYCLES"]
+        out["fraction_of_wave_cycles"] = {k: out[k] / w for k in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                                                                   "SQ_WAIT_INST_LDS") if k in out}
+    out["note"] = ("rocprofv3 --pmc over tools/gpu_grid_once.py 512 %s, averages per launch of 16384 columns x 512 voxels; SQ_* cycle "
+                   "counters are in units of 4 clocks, summed over the resident waves" % prec)
+    return out
+
+
+for prec in ("bf16", "fp32"):
+    d = sq(prec)
+    if len(d) > 1:
+        json.dump(d, open(os.path.join(ROOT, "profiles", "%s_sq_counters_%s.json" % (TAG, prec)), "w"), indent=1)
 
 s = {"lib_sha256": open(os.path.join(SRC, "lib_sha256.txt")).read().split()[0] if os.path.exists(os.path.join(SRC, "lib_sha256.txt")) else None,
      "round": TAG, "kernels": {p: one(p) for p in ("bf16", "fp32")},

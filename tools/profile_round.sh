@@ -20,5 +20,9 @@ for P in bf16 fp32; do
   rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_clk_$P -o clk -- python3 tools/gpu_grid_once.py 512 $P > $O/pmc_clk_$P.log 2>&1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_mfma_$P -o mfma -- python3 tools/gpu_grid_once.py 512 $P > $O/pmc_mfma_$P.log 2>&1
 done
+# SQ counters of the bf16 column kernel (two passes of <= 8 counters) and the fp32-grade one (one pass)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq1_bf16 -o sq -- python3 tools/gpu_grid_once.py 512 bf16 > $O/pmc_sq1_bf16.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_sq2_bf16 -o sq -- python3 tools/gpu_grid_once.py 512 bf16 > $O/pmc_sq2_bf16.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq1_fp32 -o sq -- python3 tools/gpu_grid_once.py 512 fp32 > $O/pmc_sq1_fp32.log 2>&1
 sha256sum super-resolution-3d-human-shape-from-a-single-low-resolution-image_amd/libsurs_hip.so > $O/lib_sha256.txt
 find $O -name "*.csv" | head -40
