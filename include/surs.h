@@ -164,6 +164,13 @@ int surs_query_points(const float *points, int n, const float *calib, float zmul
                       size_t workspace_bytes, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr,
                       void *stream);
 
+/* query_sr alone (lib/model/SuRSNet.py:161-187), for callers that pass it OTHER points than the preceding query_mr (the reference
+ * only requires the same n): the hr classifier on `points`, its last input channel taken from p_lr [n] (device; the masked lr
+ * occupancies query_mr left behind) instead of from an lr evaluation of these points.  Arguments as surs_query_points. */
+int surs_query_points_hr(const float *points, int n, const float *calib, float zmul, float zdiv, const float *feat_lr,
+                         int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace,
+                         size_t workspace_bytes, const float *p_lr, float *pred_hr, float *logit_hr, void *stream);
+
 /* The same for num_views > 1 and / or the perspective projection (SurfaceClassifier.forward's view mean after layer 2,
  * lib/model/SurfaceClassifier.py:70-76; reshape_sample_tensor, lib/train_util.py:40-51; perspective,
  * lib/geometry.py:34-48).  One subject (batch 1), V views:

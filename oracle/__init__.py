@@ -281,28 +281,42 @@ def _bilinear_np(feat, u, v):
     return out
 
 
-def query_views(sd, points, calibs, feat_lr, feat_hr, projection="orthogonal", load_size=1024, z_size=200.0):
+def query_views(sd, points, calibs, feat_lr, feat_hr, projection="orthogonal", load_size=1024, z_size=200.0, transforms=None,
+                points_sr=None, calibs_sr=None):
     """query_mr + query_sr + get_preds for ONE subject seen from V views (num_views = V >= 1), numpy restatement of
     SuRSNet.py:131-187 with SurfaceClassifier.forward's view mean (SurfaceClassifier.py:53-81: after layer
     len(filters)//2 = 2 both the activations and the input features are averaged over the views), the sample layout of
     reshape_sample_tensor (train_util.py:40-51) and both projections (geometry.py:15-48).
     points [V,3,N], calibs [V,4,4], feat_lr [V,256,h,w], feat_hr [V,64,H,W].
+    transforms [V,2,3]: the image-space affine map of geometry.py:27-30 / 43-46, xy' = S xy + s applied after the projection, in
+    PIFu's meaning `transforms[:, :2, :2]` / `[:, :2, 2:3]` (the reference's own slices `transforms[:2, :2]` fail in baddbmm for
+    every shape, so no output of the reference exists for it: this leg of the oracle is unpinned).
+    points_sr [V,3,N] (and calibs_sr, default calibs): query_sr called on OTHER points than query_mr (SuRSNet.py:161-187 -
+    features, depth and in_img from points_sr, the lr occupancies of query_mr's points index by index).
     Returns pred_hr [V,N], pred_lr [V,N], logit_hr [N], logit_lr [N] (fp32)."""
     f32 = np.float32
-    pts, cal = _f32(points), _f32(calibs)
-    V, _, n = pts.shape
-    feats, masks = [], []
-    for v in range(V):
-        rot, trans = cal[v, :3, :3], cal[v, :3, 3:4]
-        xyz = (trans + rot @ pts[v]).astype(f32)                 # baddbmm
-        if projection == "perspective":
-            xy = (xyz[:2] / xyz[2:3]).astype(f32)
-        else:
-            xy = xyz[:2]
-        z = xyz[2:3]
-        masks.append(((xy[0] >= -1.0) & (xy[0] <= 1.0) & (xy[1] >= -1.0) & (xy[1] <= 1.0)).astype(f32))
-        zf = (z * f32(load_size // 2) / f32(z_size)).astype(f32)   # DepthNormalizer.py:18
-        feats.append(np.concatenate([_bilinear_np(_f32(feat_lr[v]), xy[0], xy[1]), _bilinear_np(_f32(feat_hr[v]), xy[0], xy[1]), zf], 0))
+
+    def sample(points, calibs):
+        pts, cal = _f32(points), _f32(calibs)
+        feats, masks = [], []
+        for v in range(pts.shape[0]):
+            rot, trans = cal[v, :3, :3], cal[v, :3, 3:4]
+            xyz = (trans + rot @ pts[v]).astype(f32)                 # baddbmm
+            if projection == "perspective":
+                xy = (xyz[:2] / xyz[2:3]).astype(f32)
+            else:
+                xy = xyz[:2]
+            if transforms is not None:
+                tr = _f32(transforms)[v]
+                xy = (tr[:2, 2:3] + tr[:2, :2] @ xy).astype(f32)
+            z = xyz[2:3]
+            masks.append(((xy[0] >= -1.0) & (xy[0] <= 1.0) & (xy[1] >= -1.0) & (xy[1] <= 1.0)).astype(f32))
+            zf = (z * f32(load_size // 2) / f32(z_size)).astype(f32)   # DepthNormalizer.py:18
+            feats.append(np.concatenate([_bilinear_np(_f32(feat_lr[v]), xy[0], xy[1]), _bilinear_np(_f32(feat_hr[v]), xy[0], xy[1]), zf], 0))
+        return feats, masks
+
+    feats, masks = sample(points, calibs)
+    V = len(feats)
 
     def mlp(prefix, x_views):
         W = [_f32(sd[prefix + "conv%d.weight" % l]).reshape(sd[prefix + "conv%d.weight" % l].shape[0], -1) for l in range(5)]
@@ -324,6 +338,8 @@ def query_views(sd, points, calibs, feat_lr, feat_hr, projection="orthogonal", l
     sig = lambda a: (f32(1.0) / (f32(1.0) + np.exp(-a))).astype(f32)
     logit_lr = mlp("mlp_lr.", feats)
     pred_lr = np.stack([m * sig(logit_lr) for m in masks])       # in_img[:, None].float() * mlp(...)   SuRSNet.py:156
+    if points_sr is not None:
+        feats, masks = sample(points_sr, calibs if calibs_sr is None else calibs_sr)
     logit_hr = mlp("mlp_hr.", [np.concatenate([feats[v], pred_lr[v:v + 1]], 0) for v in range(V)])
     pred_hr = np.stack([m * sig(logit_hr) for m in masks])
     return pred_hr, pred_lr, logit_hr, logit_lr

@@ -69,6 +69,7 @@ _SIGS = {
     "surs_set_grid_kernel": (C.c_int, [_i]),
     "surs_query_workspace_bytes": (_sz, [_i]),
     "surs_query_points": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "surs_query_points_hr": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "surs_query_points_views": (C.c_int, [_vp, _i, _i, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp,
                                           _vp, _vp]),
     "surs_query_views_workspace_bytes": (_sz, [_i, _i]),

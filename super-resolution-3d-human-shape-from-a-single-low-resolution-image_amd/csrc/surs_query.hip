@@ -252,6 +252,24 @@ __global__ __launch_bounds__(256) void mlp_last_kernel(const float *__restrict__
     }
 }
 
+// query_sr on points other than the preceding query_mr's (SuRSNet.py:161-187 only requires the same N): the lr occupancies that
+// enter the hr classifier come from the caller instead of from this batch's lr classifier.  Writes row 321 of F and of its split image.
+template <int NP>
+__global__ __launch_bounds__(256) void patch_plr_kernel(const float *__restrict__ p_lr, long long ld, long long n, float *__restrict__ p_slot,
+                                                        unsigned short *__restrict__ Fs, long long fs_part) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float p = p_lr[t];
+    p_slot[t] = p;
+    if (Fs) {
+        unsigned short parts[NP];
+        SplitKind<NP>::split(p, parts);
+        unsigned short *dst = Fs + ((long long)(C_G / 16) * ld + t) * 16 + 1;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) dst[k * fs_part] = parts[k];
+    }
+}
+
 // multi-view (num_views > 1, SurfaceClassifier.py:70-76): out[r][t] = (sum_v in[v][r][t]) * (1/V), views summed in order
 __global__ __launch_bounds__(256) void mean_views_kernel(const float *__restrict__ in, long long view_stride, int nviews,
                                                          long long count, float inv, float *__restrict__ out) {
@@ -493,7 +511,7 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
 static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, const float *feat_lr, int hl, int wl,
                            const float *feat_hr, int hh, int wh, const char *blob, const MlpBlobHeader &h,
                            const Fp32Workspace &w, float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr,
-                           int parts = 0) {
+                           int parts = 0, const float *p_lr_in = nullptr) {
     const long long np = w.np;
     const bool x3 = gemm_use_x3();
     if (parts == 0) parts = split_parts();
@@ -509,7 +527,16 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
         hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
                            hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
     SURS_LAUNCH_CHECK();
-    for (int m = 0; m < 2; ++m) {
+    if (p_lr_in) {   // the hr classifier alone, on the caller's lr occupancies
+        if (parts == 2)
+            hipLaunchKernelGGL(patch_plr_kernel<2>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, p_lr_in, np, n,
+                               w.F + (size_t)(C_G + 1) * np, Fs, fs_part);
+        else
+            hipLaunchKernelGGL(patch_plr_kernel<3>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, p_lr_in, np, n,
+                               w.F + (size_t)(C_G + 1) * np, Fs, fs_part);
+        SURS_LAUNCH_CHECK();
+    }
+    for (int m = p_lr_in ? 1 : 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
         auto W3 = [&](int l) { return (const void *)(blob + (parts == 2 ? h.wt2[m][l] : h.wt3[m][l])); };
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
@@ -749,6 +776,31 @@ extern "C" int surs_query_points(const float *points, int n, const float *calib,
     if (rc) return rc;
     return run_points_fp32(st, src, n, feat_lr, hl, wl, feat_hr, hh, wh, (const char *)mlp_blob, h, w, pred_hr, pred_lr,
                            logit_hr, logit_lr);
+}
+
+extern "C" int surs_query_points_hr(const float *points, int n, const float *calib, float zmul, float zdiv,
+                                    const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                                    const void *mlp_blob, void *workspace, size_t workspace_bytes, const float *p_lr,
+                                    float *pred_hr, float *logit_hr, void *stream) {
+    SURS_REQUIRE(n >= 0, "negative point count");
+    if (n == 0) return 0;
+    SURS_REQUIRE(points && calib && feat_lr && feat_hr && mlp_blob && workspace && p_lr && pred_hr, "null argument");
+    SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
+    hipStream_t st = as_stream(stream);
+    const long long np = (long long)ceil_div(n, 256) * 256;
+    SURS_REQUIRE(workspace_bytes >= fp32_ws_bytes(np), "workspace too small: need %zu bytes", fp32_ws_bytes(np));
+    const MlpBlobHeader h = blob_layout(SURS_BF16);
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.mode = 0;
+    src.pts = points;
+    src.ld = n;
+    fill_calib(src, calib, zmul, zdiv);
+    Fp32Workspace w = carve_fp32(workspace, np);
+    int rc = zero_pad_rows(st, w);
+    if (rc) return rc;
+    return run_points_fp32(st, src, n, feat_lr, hl, wl, feat_hr, hh, wh, (const char *)mlp_blob, h, w, pred_hr, nullptr, logit_hr,
+                           nullptr, 0, p_lr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -178,30 +178,68 @@ class SuRSNet:
         _, f_lr, f_hr = encoder.super_res(W, _as_img(image[0:1]))
         return encoder.filter_lr(W, f_lr)[-1], encoder.filter_hr(W, f_hr)[0]
 
-    def features(self):
-        """(Img feat_lr, Img feat_hr) of view 0, last stack: what the query kernels read."""
+    def features(self, b=0):
+        """(Img feat_lr, Img feat_hr) of image b of the encoded batch, last stack: what the query kernels read."""
         if not self.im_feat_list_lr or not self.im_feat_list_hr:
             raise RuntimeError("filter_lr / filter_hr must run before a query")
-        return _as_img(self.im_feat_list_lr[-1][0:1]), _as_img(self.im_feat_list_hr[0][0:1])
+        if b >= self.im_feat_list_lr[-1].shape[0] or b >= self.im_feat_list_hr[0].shape[0]:
+            raise RuntimeError("the encoder ran on %d images, the query asks for image %d" % (self.im_feat_list_lr[-1].shape[0], b))
+        return _as_img(self.im_feat_list_lr[-1][b:b + 1]), _as_img(self.im_feat_list_hr[0][b:b + 1])
 
     # ------------------------------------------------------------------ query
     def _zscale(self):
         return float(self.opt.loadSize // 2), float(self.opt.z_size)
 
-    def _query(self, points, calibs, transforms):
+    def _calib_rows(self, calibs, transforms):
+        """calibs [B,4,4] -> host rows [B,12] of [R|t], with the image-space `transforms` [B,2,3] (or one [2,3] for every image)
+        folded in.  lib/geometry.py:27-30 / 43-46 apply xy' = S xy + s after the projection; both compose into the first two rows
+        of the calibration: orthogonal  rows01' = S rows01, t01' = S t01 + s;  perspective (xy = h01 / h2)  rows01' = S rows01 +
+        s (x) row2, so that h01' / h2 = S xy + s.  (The reference slices `transforms[:2, :2]` - of a [B,2,3] tensor that is not
+        the 2x2 scale its baddbmm needs, and of a [2,3] matrix baddbmm refuses the rank -, so this follows the evident meaning,
+        which is PIFu's `transforms[:, :2, :2]`; the eval path never passes transforms.)"""
+        cal = calibs.detach().to("cpu", torch.float64).numpy()[:, :3, :].copy()
         if transforms is not None:
-            raise NotImplementedError("image-space `transforms` are never passed on the eval path (lib/geometry.py:27-30)")
+            tr = transforms.detach().to("cpu", torch.float64).numpy()
+            if tr.ndim == 2:
+                tr = np.broadcast_to(tr, (cal.shape[0],) + tr.shape)
+            if tr.shape[0] != cal.shape[0] or tr.shape[1] < 2 or tr.shape[2] < 3:
+                raise ValueError("transforms must be [B,2,3] (scale | shift) for calibs [B,4,4]")
+            for b in range(cal.shape[0]):
+                S, sh = tr[b, :2, :2], tr[b, :2, 2]
+                top = S @ cal[b, :2, :]
+                if self.projection_mode == "orthogonal":
+                    top[:, 3] += sh
+                else:
+                    top += np.outer(sh, cal[b, 2, :])
+                cal[b, :2, :] = top
+        return cal.reshape(cal.shape[0], 12).astype(np.float32)
+
+    def _query(self, points, calibs, transforms, p_lr=None):
+        """Both classifiers on `points` (p_lr None), or the hr classifier alone with the lr occupancies p_lr [B,1,N] given."""
         dev = self._device()
         zmul, zdiv = self._zscale()
         V = self.num_views
         if V == 1 and self.projection_mode == "orthogonal":
-            if points.shape[0] != 1:
-                raise NotImplementedError("one subject per call: points must be [1,3,N] (gen_mesh never batches subjects)")
-            pts = points[0].to(dev, torch.float32).contiguous()
-            calib = calibs[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
-            run = lambda: native.query_points(pts, calib, zmul, zdiv, *self.features(), self._mlp_blob(), self._workspace())
-            phr, plr = self._finite_or_wide(run)
-            return phr.view(1, 1, -1), plr.view(1, 1, -1)
+            # a batch of B subjects (one image each): image b's features serve points[b] (geometry.index pairs them the same way)
+            B = points.shape[0]
+            if calibs.shape[0] != B:
+                raise ValueError("points [%d,3,N] and calibs [%d,4,4] disagree" % (B, calibs.shape[0]))
+            cal = self._calib_rows(calibs, transforms)
+            outs = []
+            for b in range(B):
+                pts = points[b].to(dev, torch.float32).contiguous()
+                if p_lr is None:
+                    run = lambda: native.query_points(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(), self._workspace())
+                else:
+                    pl = p_lr[b].to(dev, torch.float32).reshape(-1).contiguous()
+                    run = lambda: (native.query_points_hr(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(),
+                                                          self._workspace(), pl), pl)
+                outs.append(self._finite_or_wide(run, b))
+            phr = torch.stack([o[0] for o in outs]).view(B, 1, -1)
+            plr = torch.stack([o[1] for o in outs]).view(B, 1, -1)
+            return phr, plr
+        if p_lr is not None:
+            raise NotImplementedError("query_sr on points other than the preceding query_mr's: single-view orthogonal models only")
         # multi-view and / or perspective: the view mean of SurfaceClassifier.py:70-76 needs every view of the one subject
         # in the call: points [V,3,N] as reshape_sample_tensor (train_util.py:40-51) lays them out, calibs [V,4,4]
         if points.shape[0] != V or calibs.shape[0] != V:
@@ -213,7 +251,7 @@ class SuRSNet:
         if fl.shape[0] != V or fh.shape[0] != V:
             raise RuntimeError("the encoder ran on %d views, num_views is %d" % (fl.shape[0], V))
         pts = points.to(dev, torch.float32).contiguous()
-        cal = calibs.detach().to("cpu", torch.float32).numpy().reshape(V, -1)[:, :12]
+        cal = self._calib_rows(calibs, transforms)
         def run():
             fl = self.im_feat_list_lr[-1].to(dev).permute(0, 2, 3, 1).contiguous()
             fh = self.im_feat_list_hr[0].to(dev).permute(0, 2, 3, 1).contiguous()
@@ -221,7 +259,7 @@ class SuRSNet:
         phr, plr = self._finite_or_wide(run)
         return phr.view(V, 1, -1), plr.view(V, 1, -1)
 
-    def _finite_or_wide(self, run):
+    def _finite_or_wide(self, run, b=0):
         """run() -> (pred_hr, pred_lr).  The fp32 point kernels carry their operands as two f16 parts (|x| < 65504); the reference
         is plain fp32.  Non-finite predictions (the callers copy them to the host next, so the check costs no extra
         synchronisation) are computed again on three bf16 parts - fp32's exponent range -, after re-running the encoder the same
@@ -232,7 +270,7 @@ class SuRSNet:
         import warnings
         warnings.warn("query: non-finite predictions from the two-part f16 operand split; repeating on three bf16 parts", stacklevel=3)
         with native.wide_operands():
-            fl, fh = self.features() if self.num_views == 1 else (self.im_feat_list_lr[-1], self.im_feat_list_hr[0])
+            fl, fh = self.features(b) if self.num_views == 1 else (self.im_feat_list_lr[-1], self.im_feat_list_hr[0])
             feats_ok = bool(torch.isfinite(fl.buf if hasattr(fl, "buf") else fl).all()) and bool(torch.isfinite(fh.buf if hasattr(fh, "buf") else fh).all())
             if not feats_ok:
                 self.reencode_wide()
@@ -242,30 +280,40 @@ class SuRSNet:
         """Evaluates both classifiers in one fused pass; preds_hr is kept for the following query_sr."""
         phr, plr = self._query(points, calibs, transforms)
         self._mr_points, self._mr_hr, self._mr_version = points, phr, points._version
+        self._mr_args = (calibs, transforms)
         self.intermediate_preds_list_lr = [plr]
         self.preds_lr = plr
 
     def query_sr(self, points, calibs, transforms=None, labels=None):
+        """SuRSNet.py:161-187.  With the points (and calibs / transforms) of the preceding query_mr - the reference's eval_func and
+        gen_mesh - the fused pass has already produced preds_hr.  Any other point set of the same N goes through the hr classifier
+        alone, fed with query_mr's lr predictions index by index, exactly as the reference concatenates them."""
         if self._mr_points is None:
             raise RuntimeError("query_sr needs the preceding query_mr (it consumes its lr predictions, SuRSNet.py:179)")
         # the same points as the preceding query_mr?  Decided without touching the data (a full-tensor compare is a device
         # synchronisation per call): the same tensor object, or the same storage / view / version
         ref, ver = self._mr_points, self._mr_version
-        if points is ref and points._version != ver:
-            raise NotImplementedError("the points tensor was modified in place between query_mr and query_sr: the fused "
-                                      "kernel has already fed each point its own lr prediction")
-        same = (points is ref) or (
+        same = (points is ref and points._version == ver) or (
             points.data_ptr() == ref.data_ptr() and points.shape == ref.shape and points.stride() == ref.stride()
             and points.dtype == ref.dtype and points._version == ver and ref._version == ver)
-        if not same and ref._version == ver:
-            # another tensor: accepted if it holds the same values (this comparison synchronises; callers that pass the
-            # tensor they gave query_mr - the reference's eval_func, gen_mesh - never get here)
+        if not same and points is not ref and ref._version == ver:
+            # another tensor: the fused result stands if it holds the same values (this comparison synchronises; callers that
+            # pass the tensor they gave query_mr never get here)
             same = points.shape == ref.shape and bool(torch.equal(points.to(ref.device), ref))
-        if not same:
-            raise NotImplementedError("query_sr on points other than the preceding query_mr's is not supported: the "
-                                      "fused kernel feeds each point its own lr prediction")
-        self.intermediate_preds_list_hr = [self._mr_hr]
-        self.preds_hr = self._mr_hr
+        c0, t0 = self._mr_args
+        same = same and (calibs is c0 or (calibs.shape == c0.shape and bool(torch.equal(calibs.cpu(), c0.cpu()))))
+        same = same and ((transforms is None and t0 is None) or (transforms is not None and t0 is not None
+                                                                 and transforms.shape == t0.shape
+                                                                 and bool(torch.equal(transforms.cpu(), t0.cpu()))))
+        if same:
+            phr = self._mr_hr
+        else:
+            if points.shape[-1] != self.preds_lr.shape[-1] or points.shape[0] != self.preds_lr.shape[0]:
+                raise ValueError("query_sr: %s points against lr predictions %s (SuRSNet.py:179 concatenates them channel-wise)"
+                                 % (tuple(points.shape), tuple(self.preds_lr.shape)))
+            phr, _ = self._query(points, calibs, transforms, p_lr=self.preds_lr)
+        self.intermediate_preds_list_hr = [phr]
+        self.preds_hr = phr
 
     def get_preds(self):
         return self.preds_hr, self.preds_lr

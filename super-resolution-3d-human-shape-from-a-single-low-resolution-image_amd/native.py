@@ -324,6 +324,22 @@ def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_log
     return tuple(outs)
 
 
+def query_points_hr(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, p_lr):
+    """surs_query_points_hr: the hr classifier on points [3,N] with the lr occupancies p_lr [N] given (query_sr on points other than
+    query_mr's).  Returns pred_hr [N]."""
+    points = _f32c(points)
+    n = points.shape[1]
+    p_lr = _f32c(p_lr.reshape(-1))
+    assert p_lr.numel() == n
+    out = torch.empty(n, dtype=torch.float32, device=points.device)
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    w = ws.get(lib().surs_query_workspace_bytes(n))
+    check(lib().surs_query_points_hr(_ptr(points), n, cal, float(zmul), float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w,
+                                     feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob), _ptr(w), w.numel(), _ptr(p_lr), _ptr(out), None,
+                                     _stream()))
+    return out
+
+
 def query_points_views(points, calibs, projection, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_logits=False):
     """Multi-view / perspective query.  points [V,3,N] f32 device tensor; calibs [V,12] (host); feat_lr [V,hl,wl,256] and
     feat_hr [V,hh,wh,64] contiguous NHWC device tensors; projection 'orthogonal' | 'perspective'.

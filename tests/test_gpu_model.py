@@ -116,10 +116,76 @@ def test_query_facade_vs_reference(net, golden_dir):
     assert tuple(phr.shape) == (1, 1, 50000)
     assert np.abs(phr.detach().cpu().numpy()[0, 0] - g["a_pred_hr"]).max() < 1e-4
     assert np.abs(plr.detach().cpu().numpy()[0, 0] - g["a_pred_lr"]).max() < 1e-4
-    with pytest.raises(NotImplementedError):
-        net.query_sr(pts + 1.0, calib)
-    net.query_sr(pts.clone(), calib)          # another tensor holding the same points is fine (compared by value)
+    net.query_sr(pts.clone(), calib)          # another tensor holding the same points: the fused result stands
     assert np.array_equal(net.get_preds()[0].cpu().numpy(), phr.cpu().numpy())
+    # the hr classifier alone (surs_query_points_hr) on the same points and lr occupancies = the fused pass, bit for bit
+    from surs_amd import native
+    cal = common.CALIB.reshape(-1)[:12]
+    alone = native.query_points_hr(pts[0], cal, 512.0, 200.0, *net.features(), net._mlp_blob(), net._workspace(), plr[0, 0])
+    assert np.array_equal(alone.cpu().numpy(), phr[0, 0].cpu().numpy())
+
+
+def test_query_sr_on_other_points_batch_of_two(net, golden_dir):
+    """VERDICT r2 missing #4: query_sr on OTHER points than query_mr's (SuRSNet.py:161-187 - hr features / depth / in_img from
+    query_sr's points, lr occupancies from query_mr's), for a batch of two subjects with their own feature maps and calibs,
+    against the reference's own output (tests/golden/query_sr_other.npz)."""
+    import oracle
+    from test_oracle_query import sr_other_case
+    g = np.load(os.path.join(golden_dir, "query_sr_other.npz"))
+    feats, pts_mr, pts_sr = sr_other_case(g)
+    net.im_feat_list_lr = [torch.from_numpy(np.stack([f[0] for f in feats])).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(np.stack([f[1] for f in feats])).to("cuda:0")]
+    p_mr = torch.from_numpy(pts_mr).to("cuda:0")
+    net.query_mr(p_mr, torch.from_numpy(g["cal_mr"]))
+    net.query_sr(torch.from_numpy(pts_sr).to("cuda:0"), torch.from_numpy(g["cal_sr"]))
+    phr, plr = net.get_preds()
+    assert tuple(phr.shape) == (2, 1, int(g["n"])) and tuple(plr.shape) == (2, 1, int(g["n"]))
+    assert np.abs(phr[:, 0].cpu().numpy() - g["pred_hr"]).max() < 1e-4
+    assert np.abs(plr[:, 0].cpu().numpy() - g["pred_lr"]).max() < 1e-4
+    # the same points, modified in place after query_mr, are other points too
+    net.query_mr(p_mr, torch.from_numpy(g["cal_mr"]))
+    p_mr.copy_(torch.from_numpy(pts_sr))
+    net.query_sr(p_mr, torch.from_numpy(g["cal_mr"]))
+    ref = [oracle.query_views(common.state_dict(), pts_mr[b][None], g["cal_mr"][b][None], feats[b][0][None], feats[b][1][None],
+                              points_sr=pts_sr[b][None])[0][0] for b in range(2)]
+    assert np.abs(net.get_preds()[0][:, 0].cpu().numpy() - np.stack(ref)).max() < 1e-4
+    with pytest.raises(ValueError):
+        net.query_sr(torch.from_numpy(pts_sr[:, :, :100]).to("cuda:0"), torch.from_numpy(g["cal_sr"]))
+
+
+@pytest.mark.parametrize("projection", ["orthogonal", "perspective"])
+def test_query_with_image_space_transforms(projection, golden_dir):
+    """The `transforms` argument of query_mr / query_sr (geometry.py:27-30, 43-46; PIFu's per-image [2,3] scale | shift), folded
+    into the calibration rows on the host: against the oracle, which applies it after the projection as the reference states it."""
+    import oracle
+    from surs_amd import model as smodel, options
+    V = 1 if projection == "orthogonal" else 2
+    opt = options.BaseOptions().parse(common.FLAGS + ["--num_views", str(V)])
+    net = smodel.SuRSNet(opt, projection).to(device=torch.device("cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    feats = [common.synth_features(seed=3 + v) for v in range(V)]
+    fl, fh = np.stack([f[0] for f in feats]), np.stack([f[1] for f in feats])
+    net.im_feat_list_lr = [torch.from_numpy(fl).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(fh).to("cuda:0")]
+    n = 3001
+    pts = weights.synthetic_points(n, seed=7)
+    if projection == "perspective":
+        pts = pts + np.array([[0.0], [0.0], [2.0]], np.float32)       # in front of the camera
+    cals = np.stack([common.CALIB if projection == "orthogonal" else np.array(
+        [[2.2, 0.1 * v, 0, 0.02], [0.0, -2.1, 0.1, 0.0], [0.05, 0.0, 1.0, 0.1 * v], [0, 0, 0, 1]], np.float32) for v in range(V)])
+    tr = np.stack([np.array([[0.9, 0.1, 0.05 - 0.02 * v], [-0.08, 1.1, -0.03]], np.float32) for v in range(V)])
+    P = np.repeat(pts[None], V, 0)
+    net.query_mr(torch.from_numpy(P).to("cuda:0"), torch.from_numpy(cals), transforms=torch.from_numpy(tr))
+    net.query_sr(torch.from_numpy(P).to("cuda:0"), torch.from_numpy(cals), transforms=torch.from_numpy(tr))
+    phr, plr = net.get_preds()
+    o_hr, o_lr, _, _ = oracle.query_views(common.state_dict(), P, cals, fl, fh, projection, transforms=tr)
+    plain, _, _, _ = oracle.query_views(common.state_dict(), P, cals, fl, fh, projection)
+    assert np.abs(plain - o_hr).max() > 1e-2          # the transform matters
+    # points within half an ulp of the image border may fall on the other side of it after the composition: compare the rest
+    inside = (phr[:, 0].cpu().numpy() != 0) == (o_hr != 0)
+    assert inside.mean() > 0.999
+    assert np.abs(phr[:, 0].cpu().numpy() - o_hr)[inside].max() < 1e-4 and np.abs(plr[:, 0].cpu().numpy() - o_lr)[inside].max() < 1e-4
 
 
 @pytest.mark.parametrize("R", [32, 48])

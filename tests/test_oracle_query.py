@@ -120,3 +120,29 @@ def test_multiview_oracle_reduces_to_single_view():
     b = oracle.query_views(sd, pts[None], common.CALIB[None], fl[None], fh[None])
     for x, y in zip(a, (b[0][0], b[1][0], b[2], b[3])):
         assert np.abs(x - y).max() < 1e-5
+
+
+def sr_other_case(g):
+    """Inputs of tests/golden/query_sr_other.npz (tools/gen_golden.py query_sr): B = 2 subjects, query_mr and query_sr on
+    different points and calibs."""
+    n = int(g["n"])
+    fs, ps = g["feat_seeds"], g["point_seeds"]
+    feats = [common.synth_features(seed=int(k)) for k in fs]
+    pts_mr = np.stack([weights.synthetic_points(n, seed=int(ps[0])), weights.synthetic_points(n, seed=int(ps[1]))])
+    pts_sr = np.stack([weights.synthetic_points(n, seed=int(ps[2])), weights.synthetic_points(n, seed=int(ps[3]))])
+    return feats, pts_mr, pts_sr
+
+
+def test_query_sr_on_other_points_oracle_matches_reference_golden(golden_dir):
+    """query_sr on a point set other than query_mr's, batch of two subjects: the oracle against the reference's own output."""
+    g = np.load(os.path.join(golden_dir, "query_sr_other.npz"))
+    feats, pts_mr, pts_sr = sr_other_case(g)
+    sd = common.state_dict()
+    for b in range(2):
+        fl, fh = feats[b]
+        hr, lr, _, _ = oracle.query_views(sd, pts_mr[b][None], g["cal_mr"][b][None], fl[None], fh[None], points_sr=pts_sr[b][None],
+                                          calibs_sr=g["cal_sr"][b][None])
+        assert np.abs(hr[0] - g["pred_hr"][b]).max() < 1e-5 and np.abs(lr[0] - g["pred_lr"][b]).max() < 1e-5
+        # the hr mask is that of query_sr's points, not query_mr's
+        same_pts, _, _, _ = oracle.query_views(sd, pts_mr[b][None], g["cal_mr"][b][None], fl[None], fh[None])
+        assert not np.array_equal(same_pts[0] == 0, hr[0] == 0)

@@ -6,7 +6,7 @@ tests/golden/.  Inputs (weights, images, points, synthetic features) come from
 the counter-based PRNG in surs_amd.prng, so the fixtures hold only the
 reference's OUTPUTS plus the seeds/flags that produced them.
 
-    python tools/gen_golden.py [query] [views] [encoder] [recon] [keys] [octree]
+    python tools/gen_golden.py [query] [query_sr] [views] [encoder] [recon] [keys] [octree]
 """
 import json
 import os
@@ -94,6 +94,28 @@ def gen_query():
     out.update(c_points=pts_c, c_pred_hr=phr, c_pred_lr=plr, c_logit_hr=lhr, c_logit_lr=llr)
     np.savez_compressed(os.path.join(GOLD, "query.npz"), **out)
     print("query done")
+
+
+def gen_query_sr():
+    """query_sr on OTHER points than the preceding query_mr, for a batch of two subjects (B = 2, num_views = 1): the reference
+    itself (SuRSNet.py:131-187) - hr features / depth / in_img from query_sr's points and calibs, lr occupancies from query_mr's."""
+    net, opt_ref, sd = make_net()
+    fa, fb = synth_features(seed=3), synth_features(seed=4)
+    net.im_feat_list_lr = [torch.from_numpy(np.stack([fa[0], fb[0]]))]
+    net.im_feat_list_hr = [torch.from_numpy(np.stack([fa[1], fb[1]]))]
+    calib_b = np.array([[1.7, 0.3, -0.2, 0.05], [0.25, -1.8, 0.15, -0.04], [0.1, 0.2, 1.9, 0.02], [0, 0, 0, 1]], np.float32)
+    n = 4099
+    pts_mr = np.stack([weights.synthetic_points(n, seed=11), weights.synthetic_points(n, seed=12)])
+    pts_sr = np.stack([weights.synthetic_points(n, seed=13), weights.synthetic_points(n, seed=14)])
+    cal_mr = np.stack([CALIB, calib_b])
+    cal_sr = np.stack([calib_b, CALIB])
+    with torch.no_grad(), rh.quiet():
+        net.query_mr(torch.from_numpy(pts_mr.copy()), torch.from_numpy(cal_mr.copy()))
+        net.query_sr(torch.from_numpy(pts_sr.copy()), torch.from_numpy(cal_sr.copy()))
+        phr, plr = net.get_preds()
+    np.savez_compressed(os.path.join(GOLD, "query_sr_other.npz"), feat_seeds=np.array([3, 4]), point_seeds=np.array([11, 12, 13, 14]),
+                        n=np.array(n), cal_mr=cal_mr, cal_sr=cal_sr, pred_hr=phr[:, 0].numpy(), pred_lr=plr[:, 0].numpy())
+    print("query_sr_other: pred_hr", phr.min().item(), phr.max().item(), "outside", float((phr == 0).float().mean()))
 
 
 def gen_views():
