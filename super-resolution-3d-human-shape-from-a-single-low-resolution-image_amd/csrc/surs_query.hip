@@ -599,7 +599,8 @@ struct GridArgs {
     const char *w1tx;      // the same as two f16 parts (kernel v8)
     const char *rfrag;     // per column and MLP: the affine part of layer 1 as A fragments [16 row tiles][64][8] (kernel v7)
     float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
-    unsigned *colctr;      // kernels v7 / v8: next column to hand out (zeroed before the launch)
+    unsigned *colctr;      // kernels v7 / v8: next column to hand out (zeroed before the launch); kernel v11: one counter per pass
+    int phase;             // kernel v11: 0 = both classifiers per tile, 1 = the lr classifier only, 2 = the hr classifier on vol_lr
     unsigned long long *kstat;   // profiling only: sum of kernel v7's residual k-steps (null otherwise)
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
@@ -1271,6 +1272,7 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
         a.w1tx = blob + h.w1tx;
         a.rfrag = nullptr;
         a.colctr = nullptr;
+        a.phase = 0;
         a.zmid = 0.0f;
         if (restated) {
             // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
@@ -1367,8 +1369,18 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
             SURS_HIP_CHECK(hipEventRecord(e0, st));
         }
         if (dtype == SURS_F32) {
-            if (kver32 == 11)
-                hipLaunchKernelGGL(grid_mlp_kernel_v11, dim3(grid), dim3(V11_THREADS), GRID11_LDS_BYTES, st, a);
+            if (kver32 == 11) {
+                // two passes over the batch (lr, then hr on the lr occupancies just written): each pass streams ONE classifier's
+                // split weights (2.6 MiB), which an XCD's 4 MiB L2 holds; both together do not fit and 8 % of the stream came from
+                // HBM.  Only with whole 64-voxel tiles (the hr pass reads its tile's lr occupancies back from vol_lr, which has no
+                // room for the voxels beyond the column's end that the one-pass form computes and classifies on); same bits.
+                static const int passes_env = getenv("SURS_GRID_F32_PASSES") ? atoi(getenv("SURS_GRID_F32_PASSES")) : 2;
+                const bool two = passes_env == 2 && rz % 64 == 0;
+                for (int ph = two ? 1 : 0; ph <= (two ? 2 : 0); ++ph) {
+                    a.phase = ph;
+                    hipLaunchKernelGGL(grid_mlp_kernel_v11, dim3(grid), dim3(V11_THREADS), GRID11_LDS_BYTES, st, a);
+                }
+            }
             else if (kver32 == 8)
                 hipLaunchKernelGGL(grid_mlp_kernel_v8, dim3(grid), dim3(256), GRID8_LDS_BYTES, st, a);
             else
