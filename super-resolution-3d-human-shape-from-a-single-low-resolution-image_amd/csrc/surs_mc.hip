@@ -44,6 +44,7 @@ namespace mc {
 // the Cython core defines FLT_EPSILON = np.spacing(1.0): DOUBLE epsilon (black-box verified, see oracle)
 #define MC_EPS 2.220446049250313e-16
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int CELLS_PER_BLOCK = 1024;
 constexpr int THREADS = 256;
 
@@ -56,6 +57,10 @@ struct Dims {
     long long q_begin, q_end;         // the same range as padded indices q = (z * cy + y) * prow + x
     int base_verts, base_faces;      // vertices / triangles produced by earlier ranges
     int zoff;                        // slab mode: index of the volume's plane 0 in the whole grid (0 = the grid's bottom)
+    // q / prow and row / cy by multiplication (fast_div): n / d = mulhi(n, m) >> s for every n < 2^31, with m = ceil(2^(32 + s) / d),
+    // s = ceil(log2 d) - 1 (error of m below d, times n below 2^(32 + s)); fastdiv = 0 (d = 1 or q_end >= 2^31): plain division
+    unsigned m_prow, s_prow, m_cy, s_cy;
+    int fastdiv;
 };
 
 struct Tiling {
@@ -410,25 +415,144 @@ struct CellList {
     unsigned short x[CELLS_PER_BLOCK];     // position of the cell in the block (padded index - block start)
     unsigned char index[CELLS_PER_BLOCK];  // its cube index
     int wave_count[4];
+    float wave_lo[4], wave_hi[4];   // the count pass: the waves' voxel minima / maxima
     int n;
 };
 
 __device__ __forceinline__ void decode_q(const Dims &d, long long q, int &x, int &y, int &z) {
     const unsigned q32 = (unsigned)q, pr = (unsigned)d.prow, cy = (unsigned)d.cy;
-    const unsigned row = q32 / pr;
+    unsigned row, zz;
+    if (d.fastdiv) {   // uniform
+        row = __umulhi(q32, d.m_prow) >> d.s_prow;
+        zz = __umulhi(row, d.m_cy) >> d.s_cy;
+    } else {
+        row = q32 / pr;
+        zz = row / cy;
+    }
     x = (int)(q32 - row * pr);
-    const unsigned zz = row / cy;
     y = (int)(row - zz * cy);
     z = (int)zz;
 }
 
+// wavefront reductions on the vector ALU's data-parallel primitives (row shifts inside the rows of 16 lanes, then the row
+// broadcasts): six dependent vector instructions, result in lane 63 - the shuffle form goes through the LDS crossbar once per step
+#define SURS_DPP_STEP(x, OP, ctrl, rmask)                                                                                         \
+    x = OP(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), ctrl,  \
+                                                                    rmask, 0xf, false)))
+__device__ __forceinline__ float wave_min_to_lane63(float x) {
+    SURS_DPP_STEP(x, fminf, 0x111, 0xf);   // row_shr:1
+    SURS_DPP_STEP(x, fminf, 0x112, 0xf);   // row_shr:2
+    SURS_DPP_STEP(x, fminf, 0x114, 0xf);   // row_shr:4
+    SURS_DPP_STEP(x, fminf, 0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row's minimum
+    SURS_DPP_STEP(x, fminf, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    SURS_DPP_STEP(x, fminf, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ float wave_max_to_lane63(float x) {
+    SURS_DPP_STEP(x, fmaxf, 0x111, 0xf);
+    SURS_DPP_STEP(x, fmaxf, 0x112, 0xf);
+    SURS_DPP_STEP(x, fmaxf, 0x114, 0xf);
+    SURS_DPP_STEP(x, fmaxf, 0x118, 0xf);
+    SURS_DPP_STEP(x, fmaxf, 0x142, 0xa);
+    SURS_DPP_STEP(x, fmaxf, 0x143, 0xc);
+    return x;
+}
+#undef SURS_DPP_STEP
+
 // phase 1 for the block starting at padded index q0: fills `list` (sweep order) and widens lo / hi by the block's voxels
-__device__ __forceinline__ void mc_scan_block(const float *__restrict__ vol, const Dims &d, float levelf, long long q0,
-                                              CellList &list, float &lo, float &hi, int *__restrict__ nan_flag = nullptr) {
+// Returns the number of listed cells (uniform).  FIRST: the workgroup has not used `list` before (no barrier in front of it);
+// MINMAX: each wave leaves its voxel minimum / maximum in list.wave_lo / wave_hi.  A block without listed cells - nearly all of a
+// body-sized field - returns after ONE barrier.
+template <bool FIRST, bool MINMAX>
+__device__ __forceinline__ int mc_scan_block(const float *__restrict__ vol, const Dims &d, float levelf, long long q0,
+                                             CellList &list, float &lo, float &hi, int *__restrict__ nan_flag = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long q = q0 + (long long)threadIdx.x * CELLS_PER_THREAD;
     unsigned idx[4] = {0, 0, 0, 0};
     int ncell = 0;
+    bool wave_empty = false;   // (uniform) known without looking at the lanes' cube indices: the rank arithmetic is skipped
+    if ((d.nx & 3) == 0) {
+        // Rows of whole 16-byte quads (prow == nx): the inside / outside decisions are made per VOXEL, as wavefront masks - a
+        // vector compare writes the 64 lanes' results into a scalar register pair, so bit L of m[k][j] is voxel j of lane L's quad
+        // in row k - and a cell's activity (its 8 corners not all on one side) is a handful of 64-bit scalar AND / ORs per quad
+        // position instead of ~ 30 vector instructions per cell.  The voxel after a lane's quad is the next lane's first (the mask
+        // shifted by one lane); only lane 63 reads it.  A wavefront without an active cell - nearly all of a body-sized field - is
+        // done here; otherwise the cube indices are assembled per lane as before.
+        const bool valid = q < d.q_end;
+        int x = 0, y = 0, z = 0;
+        const size_t sy = (size_t)d.nx, sz = (size_t)d.nx * d.ny;
+        if (valid) decode_q(d, q, x, y, z);
+        const float *p = vol + (valid ? (size_t)z * sz + (size_t)y * sy + x : (size_t)0);   // lanes past the range re-read voxels 0..3
+        ncell = valid ? max(0, min(4, d.cx - x)) : 0;
+        f32x4_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4_t *>(p + (k & 1) * sy + (k >> 1) * sz);
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane == 63 && ncell == 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = p[(k & 1) * sy + (k >> 1) * sz + 4];
+        }
+        // min / max / NaN: every voxel is in row 0 of some lane, except the last plane of axis 1 (row 1 at the last cell row) and
+        // of axis 0 (rows 2, 3 in the last cell layer of the volume).  An unordered compare of two values is true if either is a NaN.
+        if (valid) {
+            lo = fminf(lo, fminf(fminf(v[0][0], v[0][1]), fminf(v[0][2], v[0][3])));
+            hi = fmaxf(hi, fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[0][3])));
+        }
+        unsigned long long nanm = (__ballot(__builtin_isunordered(v[0][0], v[0][1])) | __ballot(__builtin_isunordered(v[0][2], v[0][3]))) &
+                                  __ballot(valid);
+        const bool ylast = valid && y == d.cy - 1, zlast = valid && z == d.cz - 1;
+        if (__ballot(ylast || zlast) != 0ull) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const bool use = (k == 1 && ylast) || (k == 2 && zlast) || (k == 3 && ylast && zlast);
+                if (use) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        lo = fminf(lo, v[k][j]);
+                        hi = fmaxf(hi, v[k][j]);
+                    }
+                }
+                nanm |= __ballot(use && (v[k][0] != v[k][0] || v[k][1] != v[k][1] || v[k][2] != v[k][2] || v[k][3] != v[k][3]));
+            }
+        }
+        // fminf / fmaxf skip NaNs: report them (an overflowed f16 activation of the fp32-grade sweep shows up so)
+        if (nanm != 0ull && nan_flag && lane == 0) atomicOr(nan_flag, 1);
+        unsigned long long m[4][5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[k][j] = __ballot(v[k][j] > levelf);
+            m[k][4] = (m[k][0] >> 1) | (__ballot(e[k] > levelf) & (1ull << 63));
+        }
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long all_in = ~0ull, some_in = 0ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                all_in &= m[k][i] & m[k][i + 1];
+                some_in |= m[k][i] | m[k][i + 1];
+            }
+            any |= some_in & ~all_in & __ballot(i < ncell);
+        }
+        wave_empty = any == 0ull;
+        if (any != 0ull) {
+            unsigned in[4];   // bit j of in[k]: voxel j of row k is inside
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                in[k] = (unsigned)((m[k][4] >> lane) & 1ull) << 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in[k] |= (v[k][j] > levelf ? 1u : 0u) << j;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned a0 = in[0] >> i, a1 = in[1] >> i, a2 = in[2] >> i, a3 = in[3] >> i;
+                idx[i] = (a0 & 1) | (a0 & 2) | ((a1 & 2) << 1) | ((a1 & 1) << 3) | ((a2 & 1) << 4) | ((a2 & 2) << 4) |
+                         ((a3 & 2) << 5) | ((a3 & 1) << 7);
+                if (i >= ncell) idx[i] = 0;
+            }
+        }
+    } else
     if (q < d.q_end) {
         int x, y, z;
         decode_q(d, q, x, y, z);
@@ -486,29 +610,40 @@ __device__ __forceinline__ void mc_scan_block(const float *__restrict__ vol, con
         }
     }
     // ranks in sweep order: lanes below (ballots over the bits of the per-thread count), waves below (LDS)
-    bool act[4];
-    int ta = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        act[i] = idx[i] != 0u && idx[i] != 255u;
-        ta += act[i];
-    }
+    bool act[4] = {false, false, false, false};
     const unsigned long long below = (1ull << lane) - 1ull;
     int pa = 0, wa = 0;
+    if (!wave_empty) {
+        int ta = 0;
 #pragma unroll
-    for (int bit = 0; bit < 3; ++bit) {
-        const unsigned long long m = __ballot((ta >> bit) & 1);
-        pa += __popcll(m & below) << bit;
-        wa += __popcll(m) << bit;
+        for (int i = 0; i < 4; ++i) {
+            act[i] = idx[i] != 0u && idx[i] != 255u;
+            ta += act[i];
+        }
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {
+            const unsigned long long m = __ballot((ta >> bit) & 1);
+            pa += __popcll(m & below) << bit;
+            wa += __popcll(m) << bit;
+        }
     }
-    __syncthreads();   // the previous block's list has been consumed
+    if (!FIRST) __syncthreads();   // the previous block's list has been consumed
+    if (MINMAX) {
+        const float wlo = wave_min_to_lane63(lo), whi = wave_max_to_lane63(hi);
+        if (lane == 63) {
+            list.wave_lo[wave] = wlo;
+            list.wave_hi[wave] = whi;
+        }
+    }
     if (lane == 0) list.wave_count[wave] = wa;
     __syncthreads();
     int base = pa;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
         if (w < wave) base += list.wave_count[w];
-    if (threadIdx.x == 0) list.n = list.wave_count[0] + list.wave_count[1] + list.wave_count[2] + list.wave_count[3];
+    const int n = list.wave_count[0] + list.wave_count[1] + list.wave_count[2] + list.wave_count[3];
+    if (n == 0) return 0;
+    if (threadIdx.x == 0) list.n = n;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (act[i]) {
@@ -517,6 +652,7 @@ __device__ __forceinline__ void mc_scan_block(const float *__restrict__ vol, con
             ++base;
         }
     __syncthreads();
+    return n;
 }
 
 // phase 2: list entry e -> its cell code and flat cell number (one entry per thread and round: the corner re-read and the
@@ -533,42 +669,52 @@ __device__ __forceinline__ unsigned mc_classify_entry(const float *__restrict__ 
 }
 
 __global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
-                                                           BlockSums *__restrict__ block_counts,
-                                                           float2 *__restrict__ block_minmax, int *__restrict__ nan_flag) {
+                                                           int nblocks, BlockSums *__restrict__ block_counts,
+                                                           float2 *__restrict__ block_minmax, int *__restrict__ nan_flag,
+                                                           uint2 *__restrict__ codes) {
     __shared__ CellList list;
     __shared__ int red[3][4];
-    __shared__ float redf[2][4];
-    const long long q0 = d.q_begin + (long long)blockIdx.x * CELLS_PER_BLOCK;
-    float lo = FLT_MAX, hi = -FLT_MAX;
-    mc_scan_block(vol, d, levelf, q0, list, lo, hi, nan_flag);
-    int nt_sum = 0, nv_sum = 0, na_sum = 0;
-    for (int e = threadIdx.x; e < list.n; e += THREADS) {
-        unsigned cell;
-        const unsigned code = mc_classify_entry(vol, d, level, q0, list, e, cell);
-        nt_sum += code_nt(code);
-        nv_sum += code_nv(code);
-        na_sum += 1;
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // one workgroup per block: a persistent form (4 096 workgroups walking runs of blocks, one barrier more per block) was 30 % slower -
+    // the blocks of a workgroup then run one after the other, each behind a full memory round trip
+    {
+        const int blk = (int)blockIdx.x;
+        const long long q0 = d.q_begin + (long long)blk * CELLS_PER_BLOCK;
+        float lo = FLT_MAX, hi = -FLT_MAX;
+        const int n = mc_scan_block<true, true>(vol, d, levelf, q0, list, lo, hi, nan_flag);
+        int nt_sum = 0, nv_sum = 0, na_sum = 0;
+        if (n != 0) {   // uniform
+            // the block's (cell, code) pairs go to the block's own 1024 slots of the scratch list, in sweep order: the emit pass
+            // reads them back instead of classifying the block's cells a second time.  (One shared cursor bumped with an atomic per
+            // block would pack them - and costs 0.26 ms at 512^3: 37 000 atomics on one address.)
+            for (int e = threadIdx.x; e < n; e += THREADS) {
+                unsigned cell;
+                const unsigned code = mc_classify_entry(vol, d, level, q0, list, e, cell);
+                codes[(size_t)blk * CELLS_PER_BLOCK + e] = make_uint2(cell, code);
+                nt_sum += code_nt(code);
+                nv_sum += code_nv(code);
+                na_sum += 1;
+            }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        nt_sum += __shfl_xor(nt_sum, o);
-        nv_sum += __shfl_xor(nv_sum, o);
-        na_sum += __shfl_xor(na_sum, o);
-        lo = fminf(lo, __shfl_xor(lo, o));
-        hi = fmaxf(hi, __shfl_xor(hi, o));
-    }
-    if (lane == 0) { red[0][wave] = nv_sum; red[1][wave] = nt_sum; red[2][wave] = na_sum; redf[0][wave] = lo; redf[1][wave] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        BlockSums bs;
-        bs.nv = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        bs.nt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        bs.na = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        bs.pad = 0;
-        block_counts[blockIdx.x] = bs;
-        block_minmax[blockIdx.x] = make_float2(fminf(fminf(redf[0][0], redf[0][1]), fminf(redf[0][2], redf[0][3])),
-                                               fmaxf(fmaxf(redf[1][0], redf[1][1]), fmaxf(redf[1][2], redf[1][3])));
+            for (int o = 32; o > 0; o >>= 1) {
+                nt_sum += __shfl_xor(nt_sum, o);
+                nv_sum += __shfl_xor(nv_sum, o);
+                na_sum += __shfl_xor(na_sum, o);
+            }
+            if (lane == 0) { red[0][wave] = nv_sum; red[1][wave] = nt_sum; red[2][wave] = na_sum; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            BlockSums bs = {0, 0, 0, 0};
+            if (n != 0) {
+                bs.nv = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+                bs.nt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+                bs.na = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+            }
+            block_counts[blk] = bs;
+            block_minmax[blk] = make_float2(fminf(fminf(list.wave_lo[0], list.wave_lo[1]), fminf(list.wave_lo[2], list.wave_lo[3])),
+                                            fmaxf(fmaxf(list.wave_hi[0], list.wave_hi[1]), fmaxf(list.wave_hi[2], list.wave_hi[3])));
+        }
     }
 }
 
@@ -690,19 +836,17 @@ __global__ __launch_bounds__(THREADS) void mc_emit_kernel(const float *__restric
     __shared__ int wsum[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
-    // a workgroup walks a contiguous run of blocks and skips the empty ones (launching one workgroup per block costs more
-    // than the whole pass when a few per cent of the blocks have a surface)
-    const int per = (nblocks + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int b_end = min(nblocks, ((int)blockIdx.x + 1) * per);
-    for (int blk = (int)blockIdx.x * per; blk < b_end; ++blk) {
+    // a workgroup walks every gridDim.x-th block and skips the empty ones (launching one workgroup per block costs more than the
+    // whole pass when a few per cent of the blocks have a surface; contiguous runs of blocks left the workgroups whose run lies
+    // on the surface with all the work, one block after the other)
+    for (int blk = (int)blockIdx.x; blk < nblocks; blk += (int)gridDim.x) {
         if (block_counts[blk].na == 0) continue;   // uniform over the workgroup
         const long long q0 = d.q_begin + (long long)blk * CELLS_PER_BLOCK;
         float lo = 0.f, hi = 0.f;
-        mc_scan_block(vol, d, levelf, q0, list, lo, hi);
+        const int n = mc_scan_block<false, false>(vol, d, levelf, q0, list, lo, hi);
         const BlockSums lo_ = local_offsets[blk], go = group_offsets[blk / SCAN_GROUP];
         int carry_v = d.base_verts + go.nv + lo_.nv, carry_t = d.base_faces + go.nt + lo_.nt;
         const int a0 = go.na + lo_.na;   // list entries are the block's active cells, in order
-        const int n = list.n;
         for (int e0 = 0; e0 < n; e0 += THREADS) {   // rounds of 256 entries, one per thread
             const int e = e0 + (int)threadIdx.x;
             unsigned code = 0u, cell = 0u;
@@ -737,6 +881,51 @@ __global__ __launch_bounds__(THREADS) void mc_emit_kernel(const float *__restric
             }
         }
         // (the next block's mc_scan_block starts with a barrier: wsum and the list are free by then)
+    }
+}
+
+// Pass 3 as it normally runs: the active cells of a block were classified - and their codes stored - by the count pass; one WAVE per
+// block with active cells puts them in sweep order with their running vertex / triangle numbers.  No barrier, no LDS, no look at
+// the volume.  (mc_emit_kernel above, which classifies again, remains for fields where more than half of the cells are active: the
+// scratch list then overlaps the sorted one.)
+__global__ __launch_bounds__(THREADS) void mc_emit_list_kernel(Dims d, int nblocks, const BlockSums *__restrict__ block_counts,
+                                                               const BlockSums *__restrict__ local_offsets,
+                                                               const BlockSums *__restrict__ group_offsets,
+                                                               const uint2 *__restrict__ codes, ActiveCell *__restrict__ alist) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int blk = (int)blockIdx.x * 4 + wave; blk < nblocks; blk += (int)gridDim.x * 4) {
+        const BlockSums bc = block_counts[blk];
+        if (bc.na == 0) continue;   // uniform over the wave
+        const BlockSums lo_ = local_offsets[blk], go = group_offsets[blk / SCAN_GROUP];
+        int carry_v = d.base_verts + go.nv + lo_.nv, carry_t = d.base_faces + go.nt + lo_.nt;
+        const int a0 = go.na + lo_.na;
+        for (int e0 = 0; e0 < bc.na; e0 += 64) {
+            const int e = e0 + lane;
+            uint2 cc = make_uint2(0u, 0u);
+            if (e < bc.na) cc = codes[(size_t)blk * CELLS_PER_BLOCK + e];
+            const int tv = code_nv(cc.y), tt = code_nt(cc.y);
+            int pv = 0, pt = 0, wv = 0, wt = 0;   // prefixes inside the wave, the wave's totals
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit) {   // a cell creates at most 13 vertices, 12 triangles
+                const unsigned long long mv = __ballot((tv >> bit) & 1), mt = __ballot((tt >> bit) & 1);
+                pv += __popcll(mv & below) << bit;
+                wv += __popcll(mv) << bit;
+                pt += __popcll(mt & below) << bit;
+                wt += __popcll(mt) << bit;
+            }
+            if (e < bc.na) {
+                ActiveCell ac;
+                ac.cell = cc.x;
+                ac.code = cc.y;
+                ac.vid0 = carry_v + pv;
+                ac.tri0 = carry_t + pt;
+                alist[(size_t)(a0 + e)] = ac;
+            }
+            carry_v += wv;
+            carry_t += wt;
+        }
     }
 }
 
@@ -963,7 +1152,10 @@ extern "C" size_t surs_mc_workspace_bytes(int n0, int n1, int n2) {
     if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
     size_t off[5];
     const long long ncells = (long long)(n0 - 1) * (n1 - 1) * (n2 - 1);
-    return mc_ws_layout(n0, n1, n2, off) + align_up((size_t)ncells * sizeof(ActiveCell), 256);
+    // the active-cell list (worst case: every cell); the count pass's codes use its upper half, 1024 slots per block of PADDED cells
+    const size_t nb = (size_t)mc_nblocks((long long)(n0 - 1) * (n1 - 1) * ((n2 - 1 + 3) / 4 * 4));
+    const size_t slots = nb * CELLS_PER_BLOCK;
+    return mc_ws_layout(n0, n1, n2, off) + align_up((size_t)ncells * 8 + (slots > (size_t)ncells ? slots : (size_t)ncells) * 8, 256);
 }
 
 // One contiguous range of cells in sweep order, [cell_begin, cell_end): classify, scan, and - unless count_only -
@@ -991,6 +1183,20 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     SURS_REQUIRE(cell_begin % per_layer == 0 && cell_end % per_layer == 0, "cell range must consist of whole layers");
     d.q_begin = cell_begin / d.cx * d.prow;
     d.q_end = cell_end / d.cx * d.prow;
+    {
+        auto magic = [](unsigned dv, unsigned &m, unsigned &sh) {   // dv >= 2
+            unsigned L = 0;
+            while ((1ull << L) < dv) ++L;
+            sh = L - 1;
+            m = (unsigned)(((1ull << (31 + L)) + dv - 1) / dv);
+        };
+        d.fastdiv = d.prow >= 2 && d.cy >= 2 && (long long)d.cz * d.cy * d.prow < (1ll << 31);
+        d.m_prow = d.s_prow = d.m_cy = d.s_cy = 0;
+        if (d.fastdiv) {
+            magic((unsigned)d.prow, d.m_prow, d.s_prow);
+            magic((unsigned)d.cy, d.m_cy, d.s_cy);
+        }
+    }
     SURS_REQUIRE((long long)d.cz * d.cy * d.prow < (1ll << 32), "volume too large");
     const int nb = mc_nblocks(d.q_end - d.q_begin);
     static DeviceOnce fast_table;
@@ -1020,7 +1226,10 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     if ((double)levelf > level) levelf = nextafterf(levelf, -INFINITY);
     int *nan_flag = totals + 3;
     SURS_HIP_CHECK(hipMemsetAsync(nan_flag, 0, sizeof(int), st));
-    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, levelf, bcounts, bminmax, nan_flag);
+    // the count pass's (cell, code) pairs, 1024 slots per block: the upper half of the worst-case active-cell list (8 of 16 bytes
+    // per cell) and the row padding behind it (surs_mc_workspace_bytes)
+    uint2 *codes = (uint2 *)(ws + fixed + (size_t)d.ncells * 8);
+    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, levelf, nb, bcounts, bminmax, nan_flag, codes);
     SURS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(ng), dim3(1024), 0, st, bcounts, boffs, nb, gcounts, bminmax, gminmax);
     SURS_LAUNCH_CHECK();
@@ -1043,7 +1252,13 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     if (count_only || nactive == 0) return 0;
     if (run->n_verts > cap_verts || run->n_faces > cap_faces)
         return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
-    hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 4096 ? nb : 4096), dim3(THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs, goffs, alist);
+    static const int emit_reclassify = getenv("SURS_MC_EMIT_RECLASSIFY") ? atoi(getenv("SURS_MC_EMIT_RECLASSIFY")) : 0;   // tests
+    if (2ll * nactive > d.ncells || emit_reclassify)   // the sorted list would run into the count pass's codes: classify again
+        hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 16384 ? nb : 16384), dim3(THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs,
+                           goffs, alist);
+    else
+        hipLaunchKernelGGL(mc_emit_list_kernel, dim3(ceil_div(nb, 4) < 4096 ? ceil_div(nb, 4) : 4096), dim3(THREADS), 0, st, d, nb, bcounts,
+                           boffs, goffs, codes, alist);
     SURS_LAUNCH_CHECK();
     const int ab = ceil_div(nactive, THREADS);
     hipLaunchKernelGGL(mc_vertex_kernel, dim3(ab), dim3(THREADS), 0, st, vol, d, level, alist, nactive, evid, verts, normals,
