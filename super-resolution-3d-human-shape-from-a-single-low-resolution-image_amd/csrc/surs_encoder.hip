@@ -326,6 +326,22 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
         for (int k = 0; k < NWI; ++k) pre_w[pb][k] = *reinterpret_cast<const f32x4 *>(wsplit + (w_src[k] + (unsigned)ch * w_step));
     };
+    // the same loads in slices, one per tap of the multiply loop: a wave's 15 loads take ~ 1 000 cycles to issue (1 KiB each through
+    // the one texture-address unit the four waves share, all four at the same point of the chunk) - a twelfth of the kernel when
+    // they were issued in one burst in front of the MFMAs; between the taps' MFMAs they cost nothing
+    constexpr int FT = T > 4 ? T - 3 : T;   // ... of the first taps, so that the last loads have the rest of the loop to arrive
+    constexpr int NFI = NPI + NWI, FPT = (NFI + FT - 1) / FT;
+    auto fetch_slice = [&](int ch, int pb, int tap) {
+#pragma unroll
+        for (int q = 0; q < FPT; ++q) {
+            const int k = tap * FPT + q;
+            if (k < NPI)
+                pre_x[pb][k < NPI ? k : 0] = *reinterpret_cast<const f32x4 *>(a.x + (px_src[k < NPI ? k : 0] + (unsigned)(ch * CK)));
+            else if (k < NFI)
+                pre_w[pb][k < NFI ? k - NPI : 0] =
+                    *reinterpret_cast<const f32x4 *>(wsplit + (w_src[k < NFI ? k - NPI : 0] + (unsigned)ch * w_step));
+        }
+    };
     auto stage = [&](int ch, int pb) {
         const int c0 = ch * CK;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -368,8 +384,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         CSTAMP(0);
         __syncthreads();
         CSTAMP(1);
-        if (ch + PD < nch) fetch(ch + PD, pb);   // into the buffer this chunk has just been staged from
-        __builtin_amdgcn_sched_barrier(0);   // the loads are issued HERE, not sunk to their use behind the MFMAs
+        const bool more = ch + PD < nch;   // (uniform) the next fetch goes into the buffer this chunk has just been staged from
         CSTAMP(2);
         const int kh = lane >> 5, li = lane & 31;
         // operands of tap t + 1 are read from LDS while tap t multiplies (register double buffer): without it every tap
@@ -395,7 +410,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         for (int tap = 0; tap < T; ++tap) {
             const int cur = tap & 1;
             if (tap + 1 < T) ldtap(tap + 1, cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);   // the next tap's reads are in flight before this tap's MFMAs start
+            if (more) fetch_slice(ch + PD, pb, tap);
+            __builtin_amdgcn_sched_barrier(0);   // the next tap's reads and this tap's slice of the prefetch are in flight before its MFMAs start
             // the partial products that matter, smallest first: (x part, w part); six of three parts, three of two
             constexpr int NPROD = NP == 3 ? 6 : 3;
             constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
@@ -610,6 +626,89 @@ static int launch_conv1x1_x2(const ConvArgs &a, const unsigned short *wsplit, hi
     return 0;
 }
 
+// ---------------------------------------------------------------- 3x3 convolutions with 3 input or 3 output channels (direct, fp32 FMA)
+// The first and the last convolution of the super-resolution net at 1024^2 (3 -> 32 and 32 -> 3): 864 multiply-adds per pixel, far
+// too thin for a 32 x 32 x k matrix tile (the MFMA kernel pads 3 channels to 16 / 64 and took 230 us each: 24 TFLOP/s).  EIGHT lanes
+// share a pixel, each with 4 of the 32 wide channels, so that the 128-byte side of every pixel is one coalesced access (one lane per
+// pixel ran at the rate of its 128-byte-strided accesses: 160 - 550 us).  Weights (the packed [tap][cin_pad][cout_pad] image of
+// surs_conv_pack_weights) in LDS; fp32 FMAs, taps in order.  Zero padding; bias, LeakyReLU, residual as in conv_kernel; no fused
+// GroupNorm (not on the path).
+__global__ __launch_bounds__(256) void conv3x3_3to32_kernel(ConvArgs a) {   // cin == 3, cout == 32
+    __shared__ __attribute__((aligned(16))) float ws[27 * 32];   // [tap * 3 + c][32]
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+        const int j = i & 31, tc = i >> 5;
+        ws[i] = a.wp[((size_t)(tc / 3) * a.cin_pad + tc % 3) * a.cout_pad + j];
+    }
+    __syncthreads();
+    const unsigned t = blockIdx.x * 256u + threadIdx.x, pix = t >> 3;
+    const int g = (int)(t & 7u);   // output channels 4 g .. 4 g + 3
+    if (pix >= (unsigned)a.ho * a.wo) return;
+    const int oy = (int)(pix / (unsigned)a.wo), ox = (int)(pix - (unsigned)oy * a.wo);
+    f32x4 acc = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        const bool ok = iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+        const float *px = a.x + ((size_t)(ok ? iy : 0) * a.w + (ok ? ix : 0)) * a.x_ld;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = ok ? px[c] : 0.f;
+            const f32x4 wr = *reinterpret_cast<const f32x4 *>(&ws[(tap * 3 + c) * 32 + 4 * g]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v, wr[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (a.act == 1) acc[j] = acc[j] > 0.f ? acc[j] : a.slope * acc[j];
+        if (a.res) acc[j] += a.res[(size_t)pix * a.res_ld + 4 * g + j];
+    }
+    *reinterpret_cast<f32x4 *>(a.y + (size_t)pix * a.y_ld + 4 * g) = acc;
+}
+
+__global__ __launch_bounds__(256) void conv3x3_32to3_kernel(ConvArgs a) {   // cin == 32, cout <= 4
+    __shared__ __attribute__((aligned(16))) float ws[9 * 32 * 4];   // [tap * 32 + c][4]
+    for (int i = threadIdx.x; i < 9 * 32 * 4; i += 256) {
+        const int j = i & 3, tc = i >> 2;
+        ws[i] = a.wp[((size_t)(tc >> 5) * a.cin_pad + (tc & 31)) * a.cout_pad + j];   // (cout_pad >= 64: columns >= cout are zero)
+    }
+    __syncthreads();
+    const unsigned t = blockIdx.x * 256u + threadIdx.x, pix = t >> 3;
+    const int g = (int)(t & 7u);   // input channels 4 g .. 4 g + 3
+    const bool live = pix < (unsigned)a.ho * a.wo;   // (the lanes of a pixel stay together: they exchange partial sums below)
+    const unsigned pc = live ? pix : 0u;
+    const int oy = (int)(pc / (unsigned)a.wo), ox = (int)(pc - (unsigned)oy * a.wo);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        const bool ok = iy >= 0 && iy < a.h && ix >= 0 && ix < a.w;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)(ok ? iy : 0) * a.w + (ok ? ix : 0)) * a.x_ld + 4 * g);
+        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 wr = *reinterpret_cast<const f32x4 *>(&ws[(tap * 32 + 4 * g + k) * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(v[k], wr[j], acc[j]);
+        }
+    }
+    // the eight partial sums of a pixel: a butterfly over the lane bits 0..2 (every lane ends with the same total)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += __shfl_xor(acc[j], o);
+    if (live && g < a.cout) {
+        float r = acc[0];
+        if (g == 1) r = acc[1];
+        if (g == 2) r = acc[2];
+        if (g == 3) r = acc[3];
+        r += a.bias ? a.bias[g] : 0.f;
+        if (a.act == 1) r = r > 0.f ? r : a.slope * r;
+        if (a.res) r += a.res[(size_t)pix * a.res_ld + g];
+        a.y[(size_t)pix * a.y_ld + g] = r;
+    }
+}
+
 // ---------------------------------------------------------------- GroupNorm coefficients
 // two launches: (1) GN_SPLIT workgroups reduce a pixel slice each - ALL channels of it, so that the NHWC rows are read whole and
 // coalesced (16 bytes per thread): double sums of x and x^2 per thread and channel quad, folded per group in a fixed order; (2)
@@ -776,6 +875,109 @@ __global__ void add3_kernel(const float *__restrict__ a, int a_ld, const float *
     y[pix * y_ld + k] = t;
 }
 
+// ---- 16-byte forms of the same kernels (one thread = one pixel x 4 consecutive channels; the same operations per element in the same
+// order, so the same bits): used when the channel count, every row pitch and every base address are multiples of 4 floats.  The scalar
+// forms above ran at 0.1 - 1.4 TB/s (one 4-byte access per thread, 64-bit divisions per element).
+
+__global__ __launch_bounds__(256) void avgpool2_vec4_kernel(const float *__restrict__ x, int h, int w, int c, int x_ld,
+                                                            float *__restrict__ y, int y_ld) {
+    const int wo = w / 2, c4 = c / 4;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)(h / 2) * wo * c4) return;
+    const unsigned pix = i / c4, q = i - pix * c4, oy = pix / wo, ox = pix - oy * wo;
+    const float *p = x + ((size_t)(2 * oy) * w + 2 * ox) * x_ld + 4 * q;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + x_ld);
+    const f32x4 cc = *reinterpret_cast<const f32x4 *>(p + (size_t)w * x_ld), dd = *reinterpret_cast<const f32x4 *>(p + (size_t)w * x_ld + x_ld);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (a[k] + b[k] + cc[k] + dd[k]) * 0.25f;
+    *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = r;
+}
+
+__global__ __launch_bounds__(256) void bicubic_up2_vec4_kernel(const float *__restrict__ x, int h, int w, int c, int x_ld,
+                                                               int align_corners, const float *__restrict__ addend, int add_ld,
+                                                               float *__restrict__ y, int y_ld) {
+    const int ho = 2 * h, wo = 2 * w, c4 = c / 4;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)ho * wo * c4) return;
+    const unsigned pix = i / c4, q = i - pix * c4;
+    const int oy = (int)(pix / wo), ox = (int)(pix - (unsigned)oy * wo);
+    const float sy = align_corners ? (ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f) : 0.5f;
+    const float sx = align_corners ? (wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f) : 0.5f;
+    const float ry = align_corners ? sy * (float)oy : sy * ((float)oy + 0.5f) - 0.5f;
+    const float rx = align_corners ? sx * (float)ox : sx * ((float)ox + 0.5f) - 0.5f;
+    const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+    float cy[4], cx[4];
+    cubic_coeffs(ry - (float)iy, cy);
+    cubic_coeffs(rx - (float)ix, cx);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = min(max(iy - 1 + a, 0), h - 1);
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int xx = min(max(ix - 1 + b, 0), w - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(x + ((size_t)yy * w + xx) * x_ld + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] += cx[b] * v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += cy[a] * r[k];
+    }
+    if (addend) {
+        const f32x4 ad = *reinterpret_cast<const f32x4 *>(addend + (size_t)pix * add_ld + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = ad[k] + acc[k];
+    }
+    *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = acc;
+}
+
+// one thread = one INPUT pixel x 16 consecutive input channels = 4 output channels of its 2 x 2 output pixels
+__global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *__restrict__ x, int h, int w, int c4, int x_ld, float slope,
+                                                                  float *__restrict__ y, int y_ld) {
+    const int g = c4 / 16, wo = 2 * w;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)h * w * g) return;
+    const unsigned pix = i / g, q = i - pix * g, iy = pix / w, ix = pix - iy * w;
+    const float *p = x + (size_t)pix * x_ld + 16 * q;
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4 *>(p + 4 * k);   // v[k][2 dy + dx]: output channel 4 q + k
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            f32x4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = v[k][2 * dy + dx];
+                r[k] = t > 0.f ? t : slope * t;
+            }
+            *reinterpret_cast<f32x4 *>(y + ((size_t)(2 * iy + dy) * wo + 2 * ix + dx) * y_ld + 4 * q) = r;
+        }
+}
+
+__global__ __launch_bounds__(256) void add3_vec4_kernel(const float *__restrict__ a, int a_ld, const float *__restrict__ b, int b_ld,
+                                                        const float *__restrict__ c, int c_ld, unsigned hw, int ch,
+                                                        float *__restrict__ y, int y_ld) {
+    const int c4 = ch / 4;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= hw * (unsigned)c4) return;
+    const unsigned pix = i / c4, q = i - pix * c4;
+    const f32x4 va = *reinterpret_cast<const f32x4 *>(a + (size_t)pix * a_ld + 4 * q);
+    const f32x4 vb = *reinterpret_cast<const f32x4 *>(b + (size_t)pix * b_ld + 4 * q);
+    f32x4 t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = va[k] + vb[k];
+    if (c) {
+        const f32x4 vc = *reinterpret_cast<const f32x4 *>(c + (size_t)pix * c_ld + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] += vc[k];
+    }
+    *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = t;
+}
+
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int c, size_t hw, float *__restrict__ y, int y_ld) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hw * c) return;
@@ -799,6 +1001,7 @@ using namespace surs;
 using namespace surs::enc;
 
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+static inline bool vec4_fits(const void *p, int ld) { return (reinterpret_cast<size_t>(p) & 15) == 0 && (ld & 3) == 0; }
 
 extern "C" int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld, const float *wpacked, const float *bias,
                                 float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
@@ -819,6 +1022,20 @@ extern "C" int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld,
     a.act = act; a.slope = slope;
     a.res = residual; a.res_ld = res_ld;
     hipStream_t st = as_stream(stream);
+    if (ksize == 3 && stride == 1 && !in_scale && (long long)a.ho * a.wo < (1ll << 28)) {
+        const unsigned gx8 = (unsigned)(((long long)a.ho * a.wo * 8 + 255) / 256);   // eight lanes per pixel
+        if (cin == 3 && cout == 32 && y_ld % 4 == 0 && (reinterpret_cast<size_t>(y) & 15) == 0 &&
+            (!bias || (reinterpret_cast<size_t>(bias) & 15) == 0)) {
+            hipLaunchKernelGGL(conv3x3_3to32_kernel, dim3(gx8), dim3(256), 0, st, a);
+            SURS_LAUNCH_CHECK();
+            return 0;
+        }
+        if (cout <= 4 && cin == 32 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+            hipLaunchKernelGGL(conv3x3_32to3_kernel, dim3(gx8), dim3(256), 0, st, a);
+            SURS_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (ksize == 1) return launch_conv<1, 1, 8>(a, st);
     if (stride == 1) return launch_conv<3, 1, 8>(a, st);
     return launch_conv<3, 2, 4>(a, st);
@@ -852,7 +1069,8 @@ extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_
                                    void *stream) {
     SURS_REQUIRE(x && wsplit && y, "null argument");
     SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
-    SURS_REQUIRE((ksize == 3 || ksize == 1) && stride == 1, "the split-f16 kernels are built for 3x3 and 1x1, stride 1");
+    SURS_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1),
+                 "the split-f16 kernels are built for 3x3 (stride 1, 2) and 1x1 (stride 1)");
     SURS_REQUIRE(cin % 16 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0,
                  "the split-f16 kernels need cin %% 16 == 0 and 16-byte aligned pixels");
     SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
@@ -861,11 +1079,14 @@ extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_
     a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
     a.wp = nullptr; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
     a.bias = bias;
-    a.y = y; a.ho = h; a.wo = w; a.cout = cout; a.y_ld = y_ld;
+    a.y = y; a.ho = (h + 2 * (ksize / 2) - ksize) / stride + 1; a.wo = (w + 2 * (ksize / 2) - ksize) / stride + 1; a.cout = cout; a.y_ld = y_ld;
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.act = act; a.slope = slope;
     a.res = residual; a.res_ld = res_ld;
     if (ksize == 1) return launch_conv1x1_x2(a, (const unsigned short *)wsplit, as_stream(stream));
+    // stride 2 (the three down-sampling convolutions of the super-resolution net): the 4-row x 32-channel tile, whose 9 x 65 pixel
+    // patch fits the LDS
+    if (stride == 2) return launch_conv_x3_cfg<3, 2, 4, 32, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
     return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
@@ -933,8 +1154,12 @@ extern "C" int surs_scale_shift_act(const float *x, int hw, int c, int x_ld, con
 
 extern "C" int surs_avgpool2(const float *x, int h, int w, int c, int x_ld, float *y, int y_ld, void *stream) {
     SURS_REQUIRE(x && y && h >= 2 && w >= 2, "bad argument");
-    hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for((size_t)(h / 2) * (w / 2) * c)), dim3(256), 0, as_stream(stream), x, h, w, c,
-                       x_ld, y, y_ld);
+    if (c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (size_t)(h / 2) * (w / 2) * (c / 4) < (1ull << 32))
+        hipLaunchKernelGGL(avgpool2_vec4_kernel, dim3(blocks_for((size_t)(h / 2) * (w / 2) * (c / 4))), dim3(256), 0, as_stream(stream), x,
+                           h, w, c, x_ld, y, y_ld);
+    else
+        hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for((size_t)(h / 2) * (w / 2) * c)), dim3(256), 0, as_stream(stream), x, h, w, c,
+                           x_ld, y, y_ld);
     SURS_LAUNCH_CHECK();
     return 0;
 }
@@ -942,8 +1167,13 @@ extern "C" int surs_avgpool2(const float *x, int h, int w, int c, int x_ld, floa
 extern "C" int surs_bicubic_up2(const float *x, int h, int w, int c, int x_ld, int align_corners, const float *addend,
                                 int add_ld, float *y, int y_ld, void *stream) {
     SURS_REQUIRE(x && y && h > 0 && w > 0, "bad argument");
-    hipLaunchKernelGGL(bicubic_up2_kernel, dim3(blocks_for((size_t)4 * h * w * c)), dim3(256), 0, as_stream(stream), x, h, w, c, x_ld,
-                       align_corners, addend, add_ld, y, y_ld);
+    if (c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (!addend || vec4_fits(addend, add_ld)) &&
+        (size_t)4 * h * w * (c / 4) < (1ull << 32))
+        hipLaunchKernelGGL(bicubic_up2_vec4_kernel, dim3(blocks_for((size_t)4 * h * w * (c / 4))), dim3(256), 0, as_stream(stream), x, h,
+                           w, c, x_ld, align_corners, addend, add_ld, y, y_ld);
+    else
+        hipLaunchKernelGGL(bicubic_up2_kernel, dim3(blocks_for((size_t)4 * h * w * c)), dim3(256), 0, as_stream(stream), x, h, w, c, x_ld,
+                           align_corners, addend, add_ld, y, y_ld);
     SURS_LAUNCH_CHECK();
     return 0;
 }
@@ -951,8 +1181,12 @@ extern "C" int surs_bicubic_up2(const float *x, int h, int w, int c, int x_ld, i
 extern "C" int surs_pixel_shuffle2(const float *x, int h, int w, int c4, int x_ld, float slope, float *y, int y_ld,
                                    void *stream) {
     SURS_REQUIRE(x && y && c4 % 4 == 0, "bad argument");
-    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(blocks_for((size_t)4 * h * w * (c4 / 4))), dim3(256), 0, as_stream(stream), x, h, w,
-                       c4, x_ld, slope, y, y_ld);
+    if (c4 % 16 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (size_t)h * w * (c4 / 16) < (1ull << 32))
+        hipLaunchKernelGGL(pixel_shuffle2_vec4_kernel, dim3(blocks_for((size_t)h * w * (c4 / 16))), dim3(256), 0, as_stream(stream), x, h,
+                           w, c4, x_ld, slope, y, y_ld);
+    else
+        hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(blocks_for((size_t)4 * h * w * (c4 / 4))), dim3(256), 0, as_stream(stream), x, h, w,
+                           c4, x_ld, slope, y, y_ld);
     SURS_LAUNCH_CHECK();
     return 0;
 }
@@ -960,8 +1194,13 @@ extern "C" int surs_pixel_shuffle2(const float *x, int h, int w, int c4, int x_l
 extern "C" int surs_add3(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch,
                          float *y, int y_ld, void *stream) {
     SURS_REQUIRE(a && b && y, "bad argument");
-    hipLaunchKernelGGL(add3_kernel, dim3(blocks_for((size_t)hw * ch)), dim3(256), 0, as_stream(stream), a, a_ld, b, b_ld, c, c_ld,
-                       (size_t)hw, ch, y, y_ld);
+    if (ch % 4 == 0 && vec4_fits(a, a_ld) && vec4_fits(b, b_ld) && (!c || vec4_fits(c, c_ld)) && vec4_fits(y, y_ld) &&
+        (size_t)hw * (ch / 4) < (1ull << 32))
+        hipLaunchKernelGGL(add3_vec4_kernel, dim3(blocks_for((size_t)hw * (ch / 4))), dim3(256), 0, as_stream(stream), a, a_ld, b, b_ld,
+                           c, c_ld, (unsigned)hw, ch, y, y_ld);
+    else
+        hipLaunchKernelGGL(add3_kernel, dim3(blocks_for((size_t)hw * ch)), dim3(256), 0, as_stream(stream), a, a_ld, b, b_ld, c, c_ld,
+                           (size_t)hw, ch, y, y_ld);
     SURS_LAUNCH_CHECK();
     return 0;
 }

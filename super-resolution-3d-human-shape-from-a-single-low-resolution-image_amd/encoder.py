@@ -8,6 +8,8 @@ Mirrors, layer for layer:
 torch.cat is never materialised: producers write into channel slices of the concatenated tensor.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import native
@@ -124,12 +126,42 @@ def conv_block(W, prefix, x):
     return native.add3(out, x, out=out)
 
 
+_side_streams = {}
+
+
+def _side_stream(level):
+    """The stream the low-resolution branch of hourglass level `level` runs on, one per (device, calling stream, level): two
+    encoders running side by side (gen_mesh_pipelined) do not share them."""
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream, level)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=cur.device)
+    return st
+
+
 def hourglass(W, prefix, depth, x):
+    """HourGlass._forward (HGFilters.py:29-74).  The two branches of a level are independent until their sum: the low-resolution
+    one (pool -> ConvBlock -> [next level] -> ConvBlock; maps of 128^2 and 64^2 whose kernels fill a fraction of the chip) runs on
+    a side stream beside the full-resolution ConvBlock.  Buffers cross streams only at the fork and the join, both ordered by
+    events; a side stream's next use starts by waiting for the calling stream, i.e. after every reader of what it freed."""
+    fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0"
+
     def fwd(level, inp):
-        up1 = conv_block(W, prefix + "b1_%d." % level, inp)
-        low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp))
-        low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1)
-        low3 = conv_block(W, prefix + "b3_%d." % level, low2)
+        def low_branch():
+            low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp))
+            low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1)
+            return conv_block(W, prefix + "b3_%d." % level, low2)
+        if fork:
+            cur, side = torch.cuda.current_stream(), _side_stream(level)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                low3 = low_branch()
+            up1 = conv_block(W, prefix + "b1_%d." % level, inp)
+            cur.wait_stream(side)
+        else:
+            up1 = conv_block(W, prefix + "b1_%d." % level, inp)
+            low3 = low_branch()
         return native.bicubic_up2(low3, True, addend=up1)   # up1 + up2
     return fwd(depth, x)
 

@@ -149,9 +149,12 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
     if out is None:
         out = Img(ho, wo, cw.cout, device=x.buf.device)
     assert (out.h, out.w, out.c) == (ho, wo, cw.cout)
-    x3 = cw.w3 is not None and stride == 1 and x.c % 16 == 0 and x.ld % 4 == 0 and (x.buf.data_ptr() + 4 * x.off) % 16 == 0
+    # 3 output channels (the image head of the super-resolution net): the direct fp32 kernel behind surs_conv2d_nhwc, not a matrix tile
+    thin = cw.k == 3 and stride == 1 and in_scale is None and cw.cout <= 4 and cw.cin == 32
+    x3 = (cw.w3 is not None and not thin and (stride == 1 or (stride == 2 and cw.k == 3)) and x.c % 16 == 0 and x.ld % 4 == 0
+          and (x.buf.data_ptr() + 4 * x.off) % 16 == 0)
     w3, parts = cw.split_image() if x3 else (None, 0)
-    x3 = x3 and w3 is not None
+    x3 = x3 and w3 is not None and (stride == 1 or parts == 2)
     fn, wt = ((lib().surs_conv2d_nhwc_x3 if parts == 3 else lib().surs_conv2d_nhwc_x2), w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
     check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
