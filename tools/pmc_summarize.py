@@ -61,7 +61,12 @@ def one(prec):
     hit, miss = rows("pmc_l2_" + prec, "TCC_HIT_sum"), rows("pmc_l2_" + prec, "TCC_MISS_sum")
     gui = rows("pmc_clk_" + prec, "GRBM_GUI_ACTIVE")
     mfma = keep("pmc_mfma_" + prec, "SQ_VALU_MFMA_BUSY_CYCLES", "%s_pmc_mfma_busy_%s.csv" % (TAG, prec))
-    f_kb, w_kb = mean(fetch), mean(write)
+    # the fp32-grade kernel runs a batch in two passes (lr, then hr): the figures below are per BATCH = the sum of its launches
+    # (tools/gpu_grid_once.py: 3 sweeps x 16 batches)
+    passes = max(1, round(len(fetch) / 48.0)) if fetch else 1
+    mean_b = lambda rs: (mean(rs) * passes) if rs else None
+    dur_b = lambda rs: (dur_ms(rs) * passes) if rs else None
+    f_kb, w_kb = mean_b(fetch), mean_b(write)
     n = PRODUCTS[prec]
     weights = 2 * 42 * 32768 * (2 if prec == "fp32" else 1)     # the packed weight stream once (fp32: hi + lo parts)
     tiles, ks = ksteps(prec)
@@ -80,11 +85,12 @@ def one(prec):
         "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0 if f_kb is not None and w_kb is not None else None,
         "l2_hit_rate": (mean(hit) / (mean(hit) + mean(miss))) if hit and miss else None,
         "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
+        "launches_per_batch": passes,
         "effective_clock_ghz": (mean(gui) / 8.0 / (dur_ms(gui) * 1e-3) * 1e-9) if gui else None,
-        "avg_launch_ms_under_pmc": dur_ms(fetch),
+        "avg_launch_ms_under_pmc": dur_b(fetch),
         # SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipes were busy, summed over the chip's 1024 SIMDs (32 per
         # v_mfma_f32_32x32x16_*); the denominator is the launch's shader cycles (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs
-        "mfma_busy_cycles_per_launch": mean(mfma) if mfma else None,
+        "mfma_busy_cycles_per_launch": mean_b(mfma) if mfma else None,
         "mfma_busy_fraction": (mean(mfma) / (mean(gui) / 8.0 * 1024.0)) if mfma and gui else None,
         "mfma_busy_cycles_expected": expected,   # MFMAs issued x 32 cycles
         "layer1_residual_ksteps_per_tile_mlp": (ks / tiles) if tiles else None,
