@@ -106,3 +106,47 @@ def test_nan_in_the_volume_is_reported():
             native.marching_cubes_lewiner(bad, 0.5, native.Workspace(dev))
     v2, f2, _, _ = native.marching_cubes_lewiner(vol, 0.5, ws)     # the workspace is usable afterwards
     assert torch.equal(v, v2) and torch.equal(f, f2)
+
+
+@pytest.mark.parametrize("shape", [(40, 40, 40), (23, 36, 52), (20, 24, 30)])
+def test_both_emit_paths_against_the_oracle(mc, shape):
+    """The emit pass has two forms: it normally sorts the cell codes the count pass stored (smooth field below: a few per
+    cent of the cells are active), and classifies the active cells again where more than half of the cells are active and the sorted
+    list would overlap the stored codes (white noise: ~99 %).  Both against the oracle (the C restatement pinned to scikit-image),
+    faces / vertices / values bit for bit; (.., 30): nx % 4 != 0, the scalar-row form of the count pass."""
+    import oracle
+    rng = np.random.RandomState(5)
+    noise = rng.rand(*shape).astype(np.float32)
+    ax = [np.linspace(-1, 1, n, dtype=np.float32) for n in shape]
+    z, y, x = np.meshgrid(*ax, indexing="ij")
+    smooth = (1.0 / (1.0 + np.exp(9.0 * (np.sqrt(x * x + 1.3 * y * y + 0.8 * z * z) - 0.55)))).astype(np.float32)
+    for vol, min_active in ((noise, 0.5), (smooth, 0.0)):
+        ov, of, on, oval = oracle.marching_cubes_lewiner(vol, 0.5)
+        v, f, n, val = mc(vol, 0.5)
+        ncells = (shape[0] - 1) * (shape[1] - 1) * (shape[2] - 1)
+        assert len(of) > min_active * ncells       # (every active cell has at least one triangle)
+        assert np.array_equal(f, of) and np.array_equal(v, ov) and np.array_equal(val, oval)
+        assert np.abs(n - on).max() < 1e-4
+
+
+def test_emit_reclassify_switch_gives_the_same_mesh():
+    """SURS_MC_EMIT_RECLASSIFY=1 forces the re-classifying emit pass on a field that would take the stored codes: same mesh."""
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import mc_volumes
+from surs_amd import native
+dev = native.require_gpu()
+v, f, n, val = native.marching_cubes_lewiner(torch.from_numpy(mc_volumes.blob(96)).to(dev), 0.5, native.Workspace(dev))
+h = hashlib.sha256(); h.update(v.cpu().numpy().tobytes()); h.update(f.cpu().numpy().tobytes()); h.update(val.cpu().numpy().tobytes())
+print("digest", h.hexdigest(), len(v), len(f))
+""" % (os.path.abspath(os.path.join(os.path.dirname(__file__), "..")), os.path.abspath(os.path.dirname(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, SURS_MC_EMIT_RECLASSIFY=flag)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("digest")][0])
+    assert outs[0] == outs[1] and int(outs[0].split()[-1]) > 1000
