@@ -273,7 +273,8 @@ def test_multiview_single_view_equals_plain_query(setup):
 
 
 def test_restated_layer1_kernel_is_closer_to_fp32_than_dense_kernel(setup):
-    """Column kernel v7 (default) against v3 (dense layer 1) and the fp32-grade sweep (v5) on the same grid: v7's affine part
+    """Column kernel v7 (layer 1 restated; the default v10 is its eight-wave form, bit-identical: test_restated_kernels_match_dense_kernel,
+    tests/test_gpu_fullvolume.py) against v3 (dense layer 1) and the fp32-grade sweep on the same grid: v7's affine part
     of layer 1 is fp32-grade, so its logits sit closer to the fp32 sweep than v3's in the mean, and it reproduces its own bits.
     Also a sweep whose z tiles span the whole depth range (R = 24: most channels change branch inside the tile, ten chunks)
     and the profile counter of the residual k-steps."""
