@@ -353,7 +353,7 @@ __device__ __forceinline__ void count_cell(const Tiling &t, unsigned own, int &n
 }
 
 // ---------------------------------------------------------------- passes 1 and 3: classify (count) and classify again (emit)
-// A block = 1024 sweep-consecutive cells, a thread = 4 consecutive cells.  Inside one grid row (the common case) the four
+// A block = 1024 sweep-consecutive cells, a thread = 8 consecutive cells (two quads).  Inside one grid row (the common case) the four
 // cells share their corner rows: 4 rows x 5 consecutive floats instead of 4 x 8 scattered loads, each voxel compared with
 // the level once.  Pass 1 (count) only sums vertices / triangles / active cells and min / max per block: nothing is written
 // per cell.  After the scan, pass 3 (emit) runs the same classification again - but only in blocks that have active cells
@@ -368,8 +368,10 @@ struct ActiveCell {
     int vid0, tri0;
 };
 
-constexpr int CELLS_PER_THREAD = CELLS_PER_BLOCK / THREADS;
-static_assert(CELLS_PER_THREAD == 4, "mc_scan_block handles four cells per thread");
+// the classification passes (count, re-classifying emit): two waves per 1024-cell block, eight cells = two quads per thread
+constexpr int SCAN_THREADS = 128, SCAN_WAVES = SCAN_THREADS / 64;
+constexpr int CELLS_PER_THREAD = CELLS_PER_BLOCK / SCAN_THREADS;
+static_assert(CELLS_PER_THREAD % 4 == 0, "mc_scan_block handles whole quads of cells per thread");
 
 // Cube indices whose MC33 case needs no face / interior test (cases 1, 2, 5, 8, 9, 11, 14: every cell of a smooth surface)
 // resolve through a 256-entry table filled once per device: the cell code without its vertex count, and the set of edges
@@ -414,8 +416,8 @@ __device__ __forceinline__ unsigned classify_cell(const double *v, int index, un
 struct CellList {
     unsigned short x[CELLS_PER_BLOCK];     // position of the cell in the block (padded index - block start)
     unsigned char index[CELLS_PER_BLOCK];  // its cube index
-    int wave_count[4];
-    float wave_lo[4], wave_hi[4];   // the count pass: the waves' voxel minima / maxima
+    int wave_count[SCAN_WAVES];
+    float wave_lo[SCAN_WAVES], wave_hi[SCAN_WAVES];   // the count pass: the waves' voxel minima / maxima
     int n;
 };
 
@@ -436,28 +438,40 @@ __device__ __forceinline__ void decode_q(const Dims &d, long long q, int &x, int
 
 // wavefront reductions on the vector ALU's data-parallel primitives (row shifts inside the rows of 16 lanes, then the row
 // broadcasts): six dependent vector instructions, result in lane 63 - the shuffle form goes through the LDS crossbar once per step
-#define SURS_DPP_STEP(x, OP, ctrl, rmask)                                                                                         \
-    x = OP(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), ctrl,  \
-                                                                    rmask, 0xf, false)))
+// (v_min_f32 / v_max_f32 with the DPP modifier on the first source: one instruction per step; lanes without a source lane - bound_ctrl
+//  off - keep their value.  Written through the builtins every step was a move, two canonicalising maxima and the minimum.)
 __device__ __forceinline__ float wave_min_to_lane63(float x) {
-    SURS_DPP_STEP(x, fminf, 0x111, 0xf);   // row_shr:1
-    SURS_DPP_STEP(x, fminf, 0x112, 0xf);   // row_shr:2
-    SURS_DPP_STEP(x, fminf, 0x114, 0xf);   // row_shr:4
-    SURS_DPP_STEP(x, fminf, 0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds the row's minimum
-    SURS_DPP_STEP(x, fminf, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
-    SURS_DPP_STEP(x, fminf, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+    asm("s_nop 1\n\t"   // (a VGPR written by the instruction before must not be read through DPP for two wait states)
+        "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"   // lane 15 of every row holds the row's minimum
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"   // into rows 1 and 3
+        "s_nop 1\n\t"
+        "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"         // into rows 2 and 3
+        : "+v"(x));
     return x;
 }
 __device__ __forceinline__ float wave_max_to_lane63(float x) {
-    SURS_DPP_STEP(x, fmaxf, 0x111, 0xf);
-    SURS_DPP_STEP(x, fmaxf, 0x112, 0xf);
-    SURS_DPP_STEP(x, fmaxf, 0x114, 0xf);
-    SURS_DPP_STEP(x, fmaxf, 0x118, 0xf);
-    SURS_DPP_STEP(x, fmaxf, 0x142, 0xa);
-    SURS_DPP_STEP(x, fmaxf, 0x143, 0xc);
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(x));
     return x;
 }
-#undef SURS_DPP_STEP
 
 // phase 1 for the block starting at padded index q0: fills `list` (sweep order) and widens lo / hi by the block's voxels
 // Returns the number of listed cells (uniform).  FIRST: the workgroup has not used `list` before (no barrier in front of it);
@@ -466,115 +480,138 @@ __device__ __forceinline__ float wave_max_to_lane63(float x) {
 template <bool FIRST, bool MINMAX>
 __device__ __forceinline__ int mc_scan_block(const float *__restrict__ vol, const Dims &d, float levelf, long long q0,
                                              CellList &list, float &lo, float &hi, int *__restrict__ nan_flag = nullptr) {
+    constexpr int NQ = CELLS_PER_THREAD / 4;   // quads of four cells per thread, consecutive in the padded index
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long q = q0 + (long long)threadIdx.x * CELLS_PER_THREAD;
-    unsigned idx[4] = {0, 0, 0, 0};
-    int ncell = 0;
+    unsigned idx[CELLS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < CELLS_PER_THREAD; ++i) idx[i] = 0;
     bool wave_empty = false;   // (uniform) known without looking at the lanes' cube indices: the rank arithmetic is skipped
     if ((d.nx & 3) == 0) {
         // Rows of whole 16-byte quads (prow == nx): the inside / outside decisions are made per VOXEL, as wavefront masks - a
-        // vector compare writes the 64 lanes' results into a scalar register pair, so bit L of m[k][j] is voxel j of lane L's quad
-        // in row k - and a cell's activity (its 8 corners not all on one side) is a handful of 64-bit scalar AND / ORs per quad
-        // position instead of ~ 30 vector instructions per cell.  The voxel after a lane's quad is the next lane's first (the mask
-        // shifted by one lane); only lane 63 reads it.  A wavefront without an active cell - nearly all of a body-sized field - is
-        // done here; otherwise the cube indices are assembled per lane as before.
-        const bool valid = q < d.q_end;
-        int x = 0, y = 0, z = 0;
+        // vector compare writes the 64 lanes' results into a scalar register pair, so bit L of m[h][k][j] is voxel j of lane L's
+        // quad h in row k - and a cell's activity (its 8 corners not all on one side) is a handful of 64-bit scalar AND / ORs per
+        // quad position instead of ~ 30 vector instructions per cell.  The voxel behind a lane's first quad is its second quad's
+        // first, the one behind its last quad the next lane's first (the mask shifted by one lane; only lane 63 reads it).  A
+        // wavefront without an active cell - nearly all of a body-sized field - is done here; otherwise the cube indices are
+        // assembled per lane.  (Two quads per lane: the per-wave work - decode, reductions, ranks, barrier - is spread over 512
+        // cells; the pass is bound by instruction issue, vector and scalar together)
         const size_t sy = (size_t)d.nx, sz = (size_t)d.nx * d.ny;
-        if (valid) decode_q(d, q, x, y, z);
-        const float *p = vol + (valid ? (size_t)z * sz + (size_t)y * sy + x : (size_t)0);   // lanes past the range re-read voxels 0..3
-        ncell = valid ? max(0, min(4, d.cx - x)) : 0;
-        f32x4_t v[4];
+        bool valid[NQ];
+        int y[NQ], z[NQ], ncell[NQ];
+        f32x4_t v[NQ][4];
+        const float *plast = vol;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4_t *>(p + (k & 1) * sy + (k >> 1) * sz);
+        for (int h = 0; h < NQ; ++h) {
+            const long long qh = q + 4 * h;
+            valid[h] = qh < d.q_end;
+            int x = 0;
+            y[h] = z[h] = 0;
+            if (valid[h]) decode_q(d, qh, x, y[h], z[h]);
+            const float *p = vol + (valid[h] ? (size_t)z[h] * sz + (size_t)y[h] * sy + x : (size_t)0);   // past the range: voxels 0..3 again
+            ncell[h] = valid[h] ? max(0, min(4, d.cx - x)) : 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[h][k] = *reinterpret_cast<const f32x4_t *>(p + (k & 1) * sy + (k >> 1) * sz);
+            plast = p;
+        }
         float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane == 63 && ncell == 4) {
+        if (lane == 63 && ncell[NQ - 1] == 4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] = p[(k & 1) * sy + (k >> 1) * sz + 4];
+            for (int k = 0; k < 4; ++k) e[k] = plast[(k & 1) * sy + (k >> 1) * sz + 4];
         }
-        // min / max / NaN: every voxel is in row 0 of some lane, except the last plane of axis 1 (row 1 at the last cell row) and
+        // min / max / NaN: every voxel is in row 0 of some quad, except the last plane of axis 1 (row 1 at the last cell row) and
         // of axis 0 (rows 2, 3 in the last cell layer of the volume).  An unordered compare of two values is true if either is a NaN.
-        if (valid) {
-            lo = fminf(lo, fminf(fminf(v[0][0], v[0][1]), fminf(v[0][2], v[0][3])));
-            hi = fmaxf(hi, fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[0][3])));
-        }
-        unsigned long long nanm = (__ballot(__builtin_isunordered(v[0][0], v[0][1])) | __ballot(__builtin_isunordered(v[0][2], v[0][3]))) &
-                                  __ballot(valid);
-        const bool ylast = valid && y == d.cy - 1, zlast = valid && z == d.cz - 1;
-        if (__ballot(ylast || zlast) != 0ull) {
+        unsigned long long nanm = 0ull;
 #pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                const bool use = (k == 1 && ylast) || (k == 2 && zlast) || (k == 3 && ylast && zlast);
-                if (use) {
+        for (int h = 0; h < NQ; ++h) {
+            if (valid[h]) {
+                lo = fminf(lo, fminf(fminf(v[h][0][0], v[h][0][1]), fminf(v[h][0][2], v[h][0][3])));
+                hi = fmaxf(hi, fmaxf(fmaxf(v[h][0][0], v[h][0][1]), fmaxf(v[h][0][2], v[h][0][3])));
+            }
+            nanm |= (__ballot(__builtin_isunordered(v[h][0][0], v[h][0][1])) | __ballot(__builtin_isunordered(v[h][0][2], v[h][0][3]))) &
+                    __ballot(valid[h]);
+            const bool ylast = valid[h] && y[h] == d.cy - 1, zlast = valid[h] && z[h] == d.cz - 1;
+            if (__ballot(ylast || zlast) != 0ull) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        lo = fminf(lo, v[k][j]);
-                        hi = fmaxf(hi, v[k][j]);
+                for (int k = 1; k < 4; ++k) {
+                    const bool use = (k == 1 && ylast) || (k == 2 && zlast) || (k == 3 && ylast && zlast);
+                    if (use) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            lo = fminf(lo, v[h][k][j]);
+                            hi = fmaxf(hi, v[h][k][j]);
+                        }
                     }
+                    nanm |= __ballot(use && (v[h][k][0] != v[h][k][0] || v[h][k][1] != v[h][k][1] || v[h][k][2] != v[h][k][2] ||
+                                             v[h][k][3] != v[h][k][3]));
                 }
-                nanm |= __ballot(use && (v[k][0] != v[k][0] || v[k][1] != v[k][1] || v[k][2] != v[k][2] || v[k][3] != v[k][3]));
             }
         }
         // fminf / fmaxf skip NaNs: report them (an overflowed f16 activation of the fp32-grade sweep shows up so)
         if (nanm != 0ull && nan_flag && lane == 0) atomicOr(nan_flag, 1);
-        unsigned long long m[4][5];
+        // voxel COLUMNS (the four rows of one quad position): all inside / some inside; column 4 NQ = the voxel behind the last quad
+        unsigned long long nxt[4];        // its four rows, per lane (bit L: the voxel behind lane L's last quad)
+        unsigned long long call[4 * NQ + 1], csome[4 * NQ + 1];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int h = 0; h < NQ; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[k][j] = __ballot(v[k][j] > levelf);
-            m[k][4] = (m[k][0] >> 1) | (__ballot(e[k] > levelf) & (1ull << 63));
-        }
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long m0 = __ballot(v[h][0][j] > levelf), m1 = __ballot(v[h][1][j] > levelf),
+                                         m2 = __ballot(v[h][2][j] > levelf), m3 = __ballot(v[h][3][j] > levelf);
+                call[4 * h + j] = (m0 & m1) & (m2 & m3);
+                csome[4 * h + j] = (m0 | m1) | (m2 | m3);
+                if (h == 0 && j == 0) { nxt[0] = m0 >> 1; nxt[1] = m1 >> 1; nxt[2] = m2 >> 1; nxt[3] = m3 >> 1; }
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nxt[k] |= __ballot(e[k] > levelf) & (1ull << 63);
+        call[4 * NQ] = (nxt[0] & nxt[1]) & (nxt[2] & nxt[3]);
+        csome[4 * NQ] = (nxt[0] | nxt[1]) | (nxt[2] | nxt[3]);
+        // cell i of quad h = columns 4 h + i and 4 h + i + 1 (a quad whose fourth cell exists lies in one row with its successor)
         unsigned long long any = 0ull;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned long long all_in = ~0ull, some_in = 0ull;
+        for (int h = 0; h < NQ; ++h)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                all_in &= m[k][i] & m[k][i + 1];
-                some_in |= m[k][i] | m[k][i + 1];
-            }
-            any |= some_in & ~all_in & __ballot(i < ncell);
-        }
+            for (int i = 0; i < 4; ++i)
+                any |= (csome[4 * h + i] | csome[4 * h + i + 1]) & ~(call[4 * h + i] & call[4 * h + i + 1]) & __ballot(i < ncell[h]);
         wave_empty = any == 0ull;
         if (any != 0ull) {
-            unsigned in[4];   // bit j of in[k]: voxel j of row k is inside
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                in[k] = (unsigned)((m[k][4] >> lane) & 1ull) << 4;
+            for (int h = 0; h < NQ; ++h) {
+                unsigned in[4];   // bit j of in[k]: voxel j of row k (of quad h and the voxel behind it) is inside
 #pragma unroll
-                for (int j = 0; j < 4; ++j) in[k] |= (v[k][j] > levelf ? 1u : 0u) << j;
-            }
+                for (int k = 0; k < 4; ++k) {
+                    in[k] = (h + 1 < NQ) ? ((v[h + 1 < NQ ? h + 1 : h][k][0] > levelf ? 1u : 0u) << 4)
+                                         : ((unsigned)((nxt[k] >> lane) & 1ull) << 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned a0 = in[0] >> i, a1 = in[1] >> i, a2 = in[2] >> i, a3 = in[3] >> i;
-                idx[i] = (a0 & 1) | (a0 & 2) | ((a1 & 2) << 1) | ((a1 & 1) << 3) | ((a2 & 1) << 4) | ((a2 & 2) << 4) |
-                         ((a3 & 2) << 5) | ((a3 & 1) << 7);
-                if (i >= ncell) idx[i] = 0;
+                    for (int j = 0; j < 4; ++j) in[k] |= (v[h][k][j] > levelf ? 1u : 0u) << j;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned a0 = in[0] >> i, a1 = in[1] >> i, a2 = in[2] >> i, a3 = in[3] >> i;
+                    unsigned ci = (a0 & 1) | (a0 & 2) | ((a1 & 2) << 1) | ((a1 & 1) << 3) | ((a2 & 1) << 4) | ((a2 & 2) << 4) |
+                                  ((a3 & 2) << 5) | ((a3 & 1) << 7);
+                    if (i >= ncell[h]) ci = 0;
+                    idx[4 * h + i] = ci;
+                }
             }
         }
-    } else
-    if (q < d.q_end) {
-        int x, y, z;
-        decode_q(d, q, x, y, z);
-        ncell = max(0, min(4, d.cx - x));
-        if (ncell > 0) {
+    } else {
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            const long long qh = q + 4 * h;
+            if (qh >= d.q_end) continue;
+            int x, y, z;
+            decode_q(d, qh, x, y, z);
+            const int ncell = max(0, min(4, d.cx - x));
+            if (ncell <= 0) continue;
             const size_t sy = (size_t)d.nx, sz = (size_t)d.nx * d.ny;
             const float *p = vol + (size_t)z * sz + (size_t)y * sy + x;
             float r[4][5];   // rows (y, z), (y+1, z), (y, z+1), (y+1, z+1)
-            if ((d.nx & 3) == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 v = *reinterpret_cast<const float4 *>(p + (k & 1) * sy + (k >> 1) * sz);
-                    r[k][0] = v.x; r[k][1] = v.y; r[k][2] = v.z; r[k][3] = v.w;
-                    r[k][4] = ncell == 4 ? p[(k & 1) * sy + (k >> 1) * sz + 4] : v.w;
-                }
-            } else {
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) r[k][j] = p[(k & 1) * sy + (k >> 1) * sz + min(j, ncell)];
-            }
-            // min / max: every voxel is covered by row 0 of some thread, except the last plane of axis 1 (row 1 when y is the
+                for (int j = 0; j < 5; ++j) r[k][j] = p[(k & 1) * sy + (k >> 1) * sz + min(j, ncell)];
+            // min / max: every voxel is covered by row 0 of some quad, except the last plane of axis 1 (row 1 when y is the
             // last cell row) and of axis 0 (rows 2, 3 when z is the last cell layer of the volume)
             const bool ylast = y == d.cy - 1, zlast = z == d.cz - 1;
 #pragma unroll
@@ -603,25 +640,28 @@ __device__ __forceinline__ int mc_scan_block(const float *__restrict__ vol, cons
             for (int i = 0; i < 4; ++i) {
                 // corners v0..v7 = (x,y,z) (x+1,y,z) (x+1,y+1,z) (x,y+1,z) (x,y,z+1) (x+1,y,z+1) (x+1,y+1,z+1) (x,y+1,z+1)
                 const unsigned a0 = in[0] >> i, a1 = in[1] >> i, a2 = in[2] >> i, a3 = in[3] >> i;
-                idx[i] = (a0 & 1) | (a0 & 2) | ((a1 & 2) << 1) | ((a1 & 1) << 3) | ((a2 & 1) << 4) | ((a2 & 2) << 4) |
-                         ((a3 & 2) << 5) | ((a3 & 1) << 7);
-                if (i >= ncell) idx[i] = 0;
+                unsigned ci = (a0 & 1) | (a0 & 2) | ((a1 & 2) << 1) | ((a1 & 1) << 3) | ((a2 & 1) << 4) | ((a2 & 2) << 4) |
+                              ((a3 & 2) << 5) | ((a3 & 1) << 7);
+                if (i >= ncell) ci = 0;
+                idx[4 * h + i] = ci;
             }
         }
     }
     // ranks in sweep order: lanes below (ballots over the bits of the per-thread count), waves below (LDS)
-    bool act[4] = {false, false, false, false};
+    bool act[CELLS_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < CELLS_PER_THREAD; ++i) act[i] = false;
     const unsigned long long below = (1ull << lane) - 1ull;
     int pa = 0, wa = 0;
     if (!wave_empty) {
         int ta = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < CELLS_PER_THREAD; ++i) {
             act[i] = idx[i] != 0u && idx[i] != 255u;
             ta += act[i];
         }
 #pragma unroll
-        for (int bit = 0; bit < 3; ++bit) {
+        for (int bit = 0; bit < 4; ++bit) {   // ta <= 8
             const unsigned long long m = __ballot((ta >> bit) & 1);
             pa += __popcll(m & below) << bit;
             wa += __popcll(m) << bit;
@@ -637,15 +677,16 @@ __device__ __forceinline__ int mc_scan_block(const float *__restrict__ vol, cons
     }
     if (lane == 0) list.wave_count[wave] = wa;
     __syncthreads();
-    int base = pa;
+    int base = pa, n = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < SCAN_WAVES; ++w) {
         if (w < wave) base += list.wave_count[w];
-    const int n = list.wave_count[0] + list.wave_count[1] + list.wave_count[2] + list.wave_count[3];
+        n += list.wave_count[w];
+    }
     if (n == 0) return 0;
     if (threadIdx.x == 0) list.n = n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CELLS_PER_THREAD; ++i)
         if (act[i]) {
             list.x[base] = (unsigned short)(threadIdx.x * CELLS_PER_THREAD + i);
             list.index[base] = (unsigned char)idx[i];
@@ -661,19 +702,25 @@ __device__ __forceinline__ unsigned mc_classify_entry(const float *__restrict__ 
                                                       const CellList &list, int e, unsigned &cell) {
     int x, y, z;
     decode_q(d, q0 + list.x[e], x, y, z);
+    cell = (unsigned)(((long long)z * d.cy + y) * d.cx + x);
+    const int index = (int)list.index[e];
+    const unsigned own = owned_mask(x, y, z + d.zoff);
+    // the cases that need no face / interior test - every cell of a smooth surface - are settled by the cube index alone: the
+    // corner values (8 scattered loads, converted to double) are fetched for the ambiguous cases only
+    const unsigned fast = g_fast_code[index];
+    if (fast != 0u) return fast | ((unsigned)__popc(g_fast_seen[index] & own) << 4);
     Cell c;
     float lo = 0.f, hi = 0.f;
     load_cell(vol, d, x, y, z, level, c, lo, hi);
-    cell = (unsigned)(((long long)z * d.cy + y) * d.cx + x);
-    return classify_cell(c.v, (int)list.index[e], owned_mask(x, y, z + d.zoff));
+    return classify_cell(c.v, index, own);
 }
 
-__global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
+__global__ __launch_bounds__(SCAN_THREADS) void mc_count_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
                                                            int nblocks, BlockSums *__restrict__ block_counts,
                                                            float2 *__restrict__ block_minmax, int *__restrict__ nan_flag,
                                                            uint2 *__restrict__ codes) {
     __shared__ CellList list;
-    __shared__ int red[3][4];
+    __shared__ int red[3][SCAN_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // one workgroup per block: a persistent form (4 096 workgroups walking runs of blocks, one barrier more per block) was 30 % slower -
     // the blocks of a workgroup then run one after the other, each behind a full memory round trip
@@ -687,7 +734,7 @@ __global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restri
             // the block's (cell, code) pairs go to the block's own 1024 slots of the scratch list, in sweep order: the emit pass
             // reads them back instead of classifying the block's cells a second time.  (One shared cursor bumped with an atomic per
             // block would pack them - and costs 0.26 ms at 512^3: 37 000 atomics on one address.)
-            for (int e = threadIdx.x; e < n; e += THREADS) {
+            for (int e = threadIdx.x; e < n; e += SCAN_THREADS) {
                 unsigned cell;
                 const unsigned code = mc_classify_entry(vol, d, level, q0, list, e, cell);
                 codes[(size_t)blk * CELLS_PER_BLOCK + e] = make_uint2(cell, code);
@@ -696,7 +743,7 @@ __global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restri
                 na_sum += 1;
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+            for (int o = 32; o > 0; o >>= 1) {   // (LDS atomics of the classifying lanes instead: the same on a smooth field, 1.4x slower on noise)
                 nt_sum += __shfl_xor(nt_sum, o);
                 nv_sum += __shfl_xor(nv_sum, o);
                 na_sum += __shfl_xor(na_sum, o);
@@ -706,14 +753,15 @@ __global__ __launch_bounds__(THREADS) void mc_count_kernel(const float *__restri
         }
         if (threadIdx.x == 0) {
             BlockSums bs = {0, 0, 0, 0};
-            if (n != 0) {
-                bs.nv = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-                bs.nt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-                bs.na = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+            float blo = list.wave_lo[0], bhi = list.wave_hi[0];
+#pragma unroll
+            for (int w = 0; w < SCAN_WAVES; ++w) {
+                if (n != 0) { bs.nv += red[0][w]; bs.nt += red[1][w]; bs.na += red[2][w]; }
+                blo = fminf(blo, list.wave_lo[w]);
+                bhi = fmaxf(bhi, list.wave_hi[w]);
             }
             block_counts[blk] = bs;
-            block_minmax[blk] = make_float2(fminf(fminf(list.wave_lo[0], list.wave_lo[1]), fminf(list.wave_lo[2], list.wave_lo[3])),
-                                            fmaxf(fmaxf(list.wave_hi[0], list.wave_hi[1]), fmaxf(list.wave_hi[2], list.wave_hi[3])));
+            block_minmax[blk] = make_float2(blo, bhi);
         }
     }
 }
@@ -827,13 +875,13 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const BlockSums *__restri
 // Only blocks with active cells do any work.  A thread's four cells are consecutive in sweep order, so the rank of an
 // active cell is (active cells of the lanes below, by wavefront ballots over the per-thread counts) + (its rank inside the
 // thread); the running vertex / triangle numbers likewise, as sums of popcounts of per-bit ballots (no shuffles).
-__global__ __launch_bounds__(THREADS) void mc_emit_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
+__global__ __launch_bounds__(SCAN_THREADS) void mc_emit_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
                                                           int nblocks, const BlockSums *__restrict__ block_counts,
                                                           const BlockSums *__restrict__ local_offsets,
                                                           const BlockSums *__restrict__ group_offsets,
                                                           ActiveCell *__restrict__ alist) {
     __shared__ CellList list;
-    __shared__ int wsum[2][4];
+    __shared__ int wsum[2][SCAN_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long below = (1ull << lane) - 1ull;
     // a workgroup walks every gridDim.x-th block and skips the empty ones (launching one workgroup per block costs more than the
@@ -847,7 +895,7 @@ __global__ __launch_bounds__(THREADS) void mc_emit_kernel(const float *__restric
         const BlockSums lo_ = local_offsets[blk], go = group_offsets[blk / SCAN_GROUP];
         int carry_v = d.base_verts + go.nv + lo_.nv, carry_t = d.base_faces + go.nt + lo_.nt;
         const int a0 = go.na + lo_.na;   // list entries are the block's active cells, in order
-        for (int e0 = 0; e0 < n; e0 += THREADS) {   // rounds of 256 entries, one per thread
+        for (int e0 = 0; e0 < n; e0 += SCAN_THREADS) {   // rounds of 128 entries, one per thread
             const int e = e0 + (int)threadIdx.x;
             unsigned code = 0u, cell = 0u;
             if (e < n) code = mc_classify_entry(vol, d, level, q0, list, e, cell);
@@ -866,7 +914,7 @@ __global__ __launch_bounds__(THREADS) void mc_emit_kernel(const float *__restric
             __syncthreads();
             int run_v = carry_v + pv, run_t = carry_t + pt;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < SCAN_WAVES; ++w) {
                 if (w < wave) { run_v += wsum[0][w]; run_t += wsum[1][w]; }
                 carry_v += wsum[0][w];
                 carry_t += wsum[1][w];
@@ -1229,7 +1277,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     // the count pass's (cell, code) pairs, 1024 slots per block: the upper half of the worst-case active-cell list (8 of 16 bytes
     // per cell) and the row padding behind it (surs_mc_workspace_bytes)
     uint2 *codes = (uint2 *)(ws + fixed + (size_t)d.ncells * 8);
-    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(THREADS), 0, st, vol, d, level, levelf, nb, bcounts, bminmax, nan_flag, codes);
+    hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, vol, d, level, levelf, nb, bcounts, bminmax, nan_flag, codes);
     SURS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(ng), dim3(1024), 0, st, bcounts, boffs, nb, gcounts, bminmax, gminmax);
     SURS_LAUNCH_CHECK();
@@ -1254,7 +1302,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
         return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
     static const int emit_reclassify = getenv("SURS_MC_EMIT_RECLASSIFY") ? atoi(getenv("SURS_MC_EMIT_RECLASSIFY")) : 0;   // tests
     if (2ll * nactive > d.ncells || emit_reclassify)   // the sorted list would run into the count pass's codes: classify again
-        hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 16384 ? nb : 16384), dim3(THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs,
+        hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 16384 ? nb : 16384), dim3(SCAN_THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs,
                            goffs, alist);
     else
         hipLaunchKernelGGL(mc_emit_list_kernel, dim3(ceil_div(nb, 4) < 4096 ? ceil_div(nb, 4) : 4096), dim3(THREADS), 0, st, d, nb, bcounts,
