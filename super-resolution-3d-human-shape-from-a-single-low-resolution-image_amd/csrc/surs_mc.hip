@@ -404,15 +404,15 @@ __device__ __forceinline__ unsigned classify_cell(const double *v, int index, un
 }
 
 // Threads walk a PADDED cell index q = row * prow + x (row = z * cy + y, prow = cx rounded up to a multiple of 4; cells with
-// x >= cx do not exist): monotone in the sweep order, a thread's four cells q .. q+3 lie in one row and start at x % 4 == 0,
-// so with nx % 4 == 0 each corner row is one aligned 16-byte load plus one float.
+// x >= cx do not exist): monotone in the sweep order, a thread's cells come in quads q .. q+3 that lie in one row and start at
+// x % 4 == 0, so with nx % 4 == 0 each corner row of a quad is one aligned 16-byte load.
 //
-// Both passes run in two phases.  Phase 1 streams: every thread reads the corner rows of its four cells, decides
-// inside / outside per voxel with one float compare (levelf = the largest float <= level: for a float f, f > levelf is
-// exactly (double)f - level > 0), forms the four cube indices and appends the cells the surface crosses, in sweep order,
-// to a list in LDS (wavefront ballots for the ranks).  Phase 2 works on that list with all lanes busy: thread t takes the
-// entries 4t .. 4t+3, re-reads their corners (L1 / L2 hits) and classifies them (MC33 tests in double).  A block without
-// surface - nearly every block of a body-sized field - ends after phase 1.
+// Both passes run in two phases.  Phase 1 streams: every thread reads the corner rows of its two quads, inside / outside is
+// decided per voxel with one float compare (levelf = the largest float <= level: for a float f, f > levelf is exactly
+// (double)f - level > 0), and the cells the surface crosses are appended, in sweep order, to a list in LDS with their cube
+// indices (wavefront ballots for the ranks).  Phase 2 works on that list with all lanes busy: one entry per thread and round,
+// classified from the cube index alone or - the ambiguous MC33 cases - after re-reading the corners (tests in double).  A block
+// without surface - nearly every block of a body-sized field - ends after phase 1.
 struct CellList {
     unsigned short x[CELLS_PER_BLOCK];     // position of the cell in the block (padded index - block start)
     unsigned char index[CELLS_PER_BLOCK];  // its cube index
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(1024) void mc_scan_kernel(const BlockSums *__restri
 }
 
 // ---------------------------------------------------------------- pass 3: emit the active cells in sweep order
-// Only blocks with active cells do any work.  A thread's four cells are consecutive in sweep order, so the rank of an
+// Only blocks with active cells do any work.  A thread's eight cells are consecutive in sweep order, so the rank of an
 // active cell is (active cells of the lanes below, by wavefront ballots over the per-thread counts) + (its rank inside the
 // thread); the running vertex / triangle numbers likewise, as sums of popcounts of per-bit ballots (no shuffles).
 __global__ __launch_bounds__(SCAN_THREADS) void mc_emit_kernel(const float *__restrict__ vol, Dims d, double level, float levelf,
