@@ -990,6 +990,15 @@ __device__ __forceinline__ void edge_slot(int e, int x, int y, int z, int &axis,
     vz = z + min(dz0, dz1);
 }
 
+// the content of MCL_EDGE_DX / DY / DZ as arithmetic: axis and lower end of each cell edge, five bits per edge
+constexpr unsigned long long MC_EDGE_PACK = 0x538c28e2b00a0a0ull;   // edge e: bits 5e.. = axis (2 bits) | min dx | min dy | min dz
+__device__ __forceinline__ size_t edge_slot_index(int e, int x, int y, int z, size_t nvox, int ny, int nx) {
+    const unsigned v = e == 12 ? 3u : (unsigned)((MC_EDGE_PACK >> (5 * e)) & 31ull);   // centre vertex: table 3, the cell's own voxel
+    const unsigned axis = v & 3u;
+    const int vx = x + (int)((v >> 2) & 1u), vy = y + (int)((v >> 3) & 1u), vz = z + (int)((v >> 4) & 1u);
+    return (size_t)axis * nvox + ((size_t)vz * ny + vy) * nx + vx;
+}
+
 // ---------------------------------------------------------------- pass 4a: vertices, one thread per active cell
 __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restrict__ vol, Dims d, double level,
                                                             const ActiveCell *__restrict__ alist, int nactive,
@@ -1008,39 +1017,58 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
     load_cell(vol, d, x, y, z, level, cell, lo, hi);
     const Tiling t = decode_cell(ac.code);
     const unsigned own = owned_mask(x, y, z + d.zoff);
+    // The cell's triangle row is read in one go (all bytes at once, predicated) and reduced by arithmetic to the edges whose vertex
+    // this cell creates, in order of first appearance (4 bits each); only those take the loop with the double-precision
+    // interpolation.  Walking the row one byte at a time put a memory latency in front of every corner; the edge tables are
+    // arithmetic (MC_EDGE_PACK, the ring structure of the corner numbers) and the corner values are picked by selects, not by
+    // indexing a local array (which lived in scratch memory).
+    const int n3 = 3 * t.nt;
+    int eb[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) eb[i] = i < n3 ? (int)t.row[i] : 0;
+    unsigned seen = 0, cnt = 0;
+    unsigned long long lst = 0ull;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const unsigned bit = 1u << eb[i];
+        const bool fresh = i < n3 && !(seen & bit);
+        seen |= fresh ? bit : 0u;
+        const bool mine = fresh && (own & bit);
+        lst |= mine ? ((unsigned long long)eb[i] << (4 * cnt)) : 0ull;
+        cnt += mine ? 1u : 0u;
+    }
+    const double *v = cell.v;
+    auto pick = [&](int k) {   // v[k] without a dynamically indexed array
+        const double a0 = (k & 1) ? v[1] : v[0], a1 = (k & 1) ? v[3] : v[2], a2 = (k & 1) ? v[5] : v[4], a3 = (k & 1) ? v[7] : v[6];
+        const double b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2;
+        return (k & 4) ? b1 : b0;
+    };
     int vid = ac.vid0;
-    unsigned seen = 0;
-    for (int i = 0; i < 3 * t.nt; ++i) {
-        const int e = t.row[i];
-        if (seen & (1u << e)) continue;
-        seen |= 1u << e;
-        if (!(own & (1u << e))) continue;
+    for (unsigned j = 0; j < cnt; ++j) {
+        const int e = (int)((lst >> (4 * j)) & 15ull);
         double px, py, pz;
         if (e == 12) {
             const int cx[8] = {0, 1, 1, 0, 0, 1, 1, 0}, cy[8] = {0, 0, 1, 1, 0, 0, 1, 1}, cz[8] = {0, 0, 0, 0, 1, 1, 1, 1};
             double fx = 0, fy = 0, fz = 0, ff = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const double w = 1.0 / (MC_EPS + fabs(cell.v[k]));
+                const double w = 1.0 / (MC_EPS + fabs(v[k]));
                 fx += cx[k] * w; fy += cy[k] * w; fz += cz[k] * w; ff += w;
             }
             px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)(z + d.zoff) + fz / ff;
         } else {
-            const int dx1 = MCL_EDGE_DX[2 * e], dx2 = MCL_EDGE_DX[2 * e + 1];
-            const int dy1 = MCL_EDGE_DY[2 * e], dy2 = MCL_EDGE_DY[2 * e + 1];
-            const int dz1 = MCL_EDGE_DZ[2 * e], dz2 = MCL_EDGE_DZ[2 * e + 1];
-            // corner number of (dx,dy,dz): v0..v7 = (0,0,0)(1,0,0)(1,1,0)(0,1,0)(0,0,1)(1,0,1)(1,1,1)(0,1,1)
-            const int k1 = dz1 * 4 + (dy1 ? (dx1 ? 2 : 3) : (dx1 ? 1 : 0));
-            const int k2 = dz2 * 4 + (dy2 ? (dx2 ? 2 : 3) : (dx2 ? 1 : 0));
-            const double w1 = 1.0 / (MC_EPS + fabs(cell.v[k1])), w2 = 1.0 / (MC_EPS + fabs(cell.v[k2]));
+            // corners of edge e: 0..3 the ring of the lower face, 4..7 of the upper face, 8..11 the verticals; corner k sits at
+            // (dx, dy, dz) = (((k + 1) >> 1) & 1, (k >> 1) & 1, k >> 2): v0..v7 = (0,0,0)(1,0,0)(1,1,0)(0,1,0)(0,0,1)(1,0,1)(1,1,1)(0,1,1)
+            const int k1 = e < 8 ? (e & 4) + (e & 3) : e - 8, k2 = e < 8 ? (e & 4) + ((e + 1) & 3) : e - 4;
+            const int dx1 = ((k1 + 1) >> 1) & 1, dy1 = (k1 >> 1) & 1, dz1 = k1 >> 2;
+            const int dx2 = ((k2 + 1) >> 1) & 1, dy2 = (k2 >> 1) & 1, dz2 = k2 >> 2;
+            const double w1 = 1.0 / (MC_EPS + fabs(pick(k1))), w2 = 1.0 / (MC_EPS + fabs(pick(k2)));
             double fx = 0, fy = 0, fz = 0, ff = 0;
             fx += (double)dx1 * w1; fy += (double)dy1 * w1; fz += (double)dz1 * w1; ff += w1;
             fx += (double)dx2 * w2; fy += (double)dy2 * w2; fz += (double)dz2 * w2; ff += w2;
             px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)(z + d.zoff) + fz / ff;
         }
-        int axis, vx, vy, vz;
-        edge_slot(e, x, y, z, axis, vx, vy, vz);
-        evid[(size_t)axis * nvox + ((size_t)vz * d.ny + vy) * d.nx + vx] = vid;
+        evid[edge_slot_index(e, x, y, z, nvox, d.ny, d.nx)] = vid;
         if (vid < cap_verts) {
             // output order (axis0, axis1, axis2) = (z, y, x)
             verts[3 * (size_t)vid + 0] = (float)pz;
@@ -1129,6 +1157,39 @@ __global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restric
             faces[3 * (size_t)tri + 0] = vid[2];
             faces[3 * (size_t)tri + 1] = vid[1];
             faces[3 * (size_t)tri + 2] = vid[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- pass 4b without normals / values (what gen_mesh asks for)
+// mc_face_kernel walks a cell's triangle list one corner at a time: table byte -> six bytes of the edge tables -> vertex id, three
+// dependent memory latencies per corner and up to 36 corners - a latency chain, which is what the pass costs (one thread per active
+// cell, everything resident at once).  Here the chain is four loads deep whatever the cell: all bytes of the triangle row at once
+// (predicated), the lattice slot of every corner by arithmetic (MC_EDGE_PACK: axis and lower end of each cell edge, five bits per
+// edge - the content of MCL_EDGE_DX / DY / DZ), all vertex ids at once, then the stores.
+__global__ __launch_bounds__(THREADS) void mc_face_ids_kernel(Dims d, const ActiveCell *__restrict__ alist, int nactive,
+                                                              const int *__restrict__ evid, int *__restrict__ faces, int cap_faces) {
+    const int a = blockIdx.x * THREADS + threadIdx.x;
+    if (a >= nactive) return;
+    const ActiveCell ac = alist[a];
+    const size_t nvox = (size_t)d.nx * d.ny * d.nz;
+    int x, y, z;
+    cell_xyz(d, (long long)ac.cell, x, y, z);
+    const Tiling t = decode_cell(ac.code);
+    const int n3 = 3 * t.nt;
+    int e[36], vid[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) e[i] = i < n3 ? (int)t.row[i] : 0;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) vid[i] = i < n3 ? evid[edge_slot_index(e[i], x, y, z, nvox, d.ny, d.nx)] : 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int tri = ac.tri0 + i;
+        if (i < t.nt && tri < cap_faces) {
+            // rows reversed (gradient_direction='descent')
+            faces[3 * (size_t)tri + 0] = vid[3 * i + 2];
+            faces[3 * (size_t)tri + 1] = vid[3 * i + 1];
+            faces[3 * (size_t)tri + 2] = vid[3 * i + 0];
         }
     }
 }
@@ -1312,8 +1373,11 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     hipLaunchKernelGGL(mc_vertex_kernel, dim3(ab), dim3(THREADS), 0, st, vol, d, level, alist, nactive, evid, verts, normals,
                        values, cap_verts);
     SURS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mc_face_kernel, dim3(ab), dim3(THREADS), 0, st, vol, d, level, alist, nactive, evid, faces, normals, values,
-                       cap_verts, cap_faces);
+    if (!normals && !values)
+        hipLaunchKernelGGL(mc_face_ids_kernel, dim3(ab), dim3(THREADS), 0, st, d, alist, nactive, evid, faces, cap_faces);
+    else
+        hipLaunchKernelGGL(mc_face_kernel, dim3(ab), dim3(THREADS), 0, st, vol, d, level, alist, nactive, evid, faces, normals, values,
+                           cap_verts, cap_faces);
     SURS_LAUNCH_CHECK();
     return 0;
 }
