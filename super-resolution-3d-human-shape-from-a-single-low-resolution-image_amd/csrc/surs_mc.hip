@@ -1082,28 +1082,62 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------- pass 4b: faces, values, normal accumulation
+// The row, the lattice slots and the vertex ids are fetched as in mc_face_ids_kernel below (all at once); the contributions to
+// `values` and to the normals are then added once per DISTINCT edge of the cell, times the number of corners of its triangles that
+// sit on that edge - not once per corner: the contribution of a corner depends on its edge only, and a cell's triangles share their
+// edges (two to three corners per edge), so this is a third of the float atomics (seven per corner before: one max, six adds - the
+// pass is bound by them).  Float sums in another order than the compiled core's: within the 1e-4 the normals are held to.
 __global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restrict__ vol, Dims d, double level,
                                                           const ActiveCell *__restrict__ alist, int nactive,
                                                           const int *__restrict__ evid, int *__restrict__ faces,
                                                           float *__restrict__ normals, float *__restrict__ values,
                                                           int cap_verts, int cap_faces) {
-    const int a = blockIdx.x * THREADS + threadIdx.x;
+    __shared__ int lvid[13][THREADS];             // per thread: the vertex ids of the cell's distinct edges, in order of appearance
+    __shared__ unsigned char ledge[13][THREADS];  // and the edges
+    const int a = blockIdx.x * THREADS + threadIdx.x, tid = threadIdx.x;
     if (a >= nactive) return;
     const ActiveCell ac = alist[a];
     const size_t nvox = (size_t)d.nx * d.ny * d.nz;
     int x, y, z;
     cell_xyz(d, (long long)ac.cell, x, y, z);
     const Tiling t = decode_cell(ac.code);
-    const int tri0 = ac.tri0;
+    const int n3 = 3 * t.nt;
     Cell cell;
-    for (int k = 0; k < 8; ++k) cell.v[k] = 0.0;
-    if (normals || values) {   // the corner values are only needed for these
-        float lo = 0, hi = 0;
-        load_cell(vol, d, x, y, z, level, cell, lo, hi);
+    float lo_ = 0, hi_ = 0;
+    load_cell(vol, d, x, y, z, level, cell, lo_, hi_);
+    int e[36], vid[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) e[i] = i < n3 ? (int)t.row[i] : 0;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) vid[i] = i < n3 ? evid[edge_slot_index(e[i], x, y, z, nvox, d.ny, d.nx)] : 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int tri = ac.tri0 + i;
+        if (i < t.nt && tri < cap_faces) {
+            // rows reversed (gradient_direction='descent')
+            faces[3 * (size_t)tri + 0] = vid[3 * i + 2];
+            faces[3 * (size_t)tri + 1] = vid[3 * i + 1];
+            faces[3 * (size_t)tri + 2] = vid[3 * i + 0];
+        }
+    }
+    // corners per edge (a nibble each) and the distinct edges with their vertex ids
+    unsigned long long per_edge = 0ull;
+    unsigned seen = 0, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const unsigned bit = 1u << e[i];
+        per_edge += i < n3 ? (1ull << (4 * e[i])) : 0ull;
+        if (i < n3 && !(seen & bit)) {
+            seen |= bit;
+            lvid[cnt][tid] = vid[i];
+            ledge[cnt][tid] = (unsigned char)e[i];
+            ++cnt;
+        }
     }
     const double *v = cell.v;
     // per-cell quantities for values / normals (see oracle/mc_oracle.c for the black-box verified quirks)
     double vlo = 0.0, vhi = 0.0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) { if (v[k] > vhi) vhi = v[k]; if (v[k] < vlo) vlo = v[k]; }
     const float vrange = (float)(vhi - vlo);
     const double g[8][3] = {
@@ -1111,9 +1145,21 @@ __global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restric
         {v[3] - v[2], v[1] - v[2], v[2] - v[6]}, {v[3] - v[2], v[0] - v[3], v[3] - v[7]},
         {v[4] - v[5], v[4] - v[7], v[0] - v[4]}, {v[4] - v[5], v[5] - v[6], v[1] - v[5]},
         {v[7] - v[6], v[5] - v[6], v[2] - v[6]}, {v[7] - v[6], v[4] - v[7], v[3] - v[7]}};
+    auto pickv = [&](int k) {   // v[k], g[k][ax] without dynamically indexed arrays (they would live in scratch memory)
+        const double a0 = (k & 1) ? v[1] : v[0], a1 = (k & 1) ? v[3] : v[2], a2 = (k & 1) ? v[5] : v[4], a3 = (k & 1) ? v[7] : v[6];
+        const double b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2;
+        return (k & 4) ? b1 : b0;
+    };
+    auto pickg = [&](int k, int ax) {
+        const double a0 = (k & 1) ? g[1][ax] : g[0][ax], a1 = (k & 1) ? g[3][ax] : g[2][ax], a2 = (k & 1) ? g[5][ax] : g[4][ax],
+                     a3 = (k & 1) ? g[7][ax] : g[6][ax];
+        const double b0 = (k & 2) ? a1 : a0, b1 = (k & 2) ? a3 : a2;
+        return (k & 4) ? b1 : b0;
+    };
     double c12g[3] = {0, 0, 0};
     if (normals) {
         double gy = 0, gz = 0;
+#pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double w = 1.0 / (MC_EPS + fabs(v[k]));
             gy += w * g[k][1];
@@ -1121,42 +1167,27 @@ __global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restric
         }
         c12g[0] = gz; c12g[1] = gy; c12g[2] = 0.0;  // quirk of the compiled core: (Gz, Gy, 0)
     }
-    for (int i = 0; i < t.nt; ++i) {
-        int vid[3];
-        for (int j = 0; j < 3; ++j) {
-            const int e = t.row[3 * i + j];
-            int axis, vx, vy, vz;
-            edge_slot(e, x, y, z, axis, vx, vy, vz);
-            vid[j] = evid[(size_t)axis * nvox + ((size_t)vz * d.ny + vy) * d.nx + vx];
-            if (vid[j] < cap_verts) {
-                if (values) atomicMax(reinterpret_cast<int *>(values) + vid[j], __float_as_int(vrange));
-                if (normals) {
-                    float *n = normals + 3 * (size_t)vid[j];
-                    if (e == 12) {
-                        atomicAdd(n + 0, (float)c12g[0]); atomicAdd(n + 1, (float)c12g[1]); atomicAdd(n + 2, (float)c12g[2]);
-                    } else {
-                        const int dx1 = MCL_EDGE_DX[2 * e], dx2 = MCL_EDGE_DX[2 * e + 1];
-                        const int dy1 = MCL_EDGE_DY[2 * e], dy2 = MCL_EDGE_DY[2 * e + 1];
-                        const int dz1 = MCL_EDGE_DZ[2 * e], dz2 = MCL_EDGE_DZ[2 * e + 1];
-                        const int i1 = dz1 * 4 + dy1 * 2 + dx1, i2 = dz2 * 4 + dy2 * 2 + dx2;  // xyz-bit index
-                        const int k1 = dz1 * 4 + (dy1 ? (dx1 ? 2 : 3) : (dx1 ? 1 : 0));
-                        const int k2 = dz2 * 4 + (dy2 ? (dx2 ? 2 : 3) : (dx2 ? 1 : 0));
-                        const double w1 = 1.0 / (MC_EPS + fabs(v[k1])), w2 = 1.0 / (MC_EPS + fabs(v[k2]));
-                        // the core indexes its corner-number gradient table with the xyz-bit index (quirk)
-                        for (int ax = 0; ax < 3; ++ax) {
-                            atomicAdd(n + ax, (float)(g[i1][ax] * w1));
-                            atomicAdd(n + ax, (float)(g[i2][ax] * w2));
-                        }
-                    }
-                }
+    for (unsigned j = 0; j < cnt; ++j) {
+        const int ed = (int)ledge[j][tid], vj = lvid[j][tid];
+        if (vj >= cap_verts) continue;
+        const float mult = (float)((per_edge >> (4 * ed)) & 15ull);   // corners of the cell's triangles on this edge
+        if (values) atomicMax(reinterpret_cast<int *>(values) + vj, __float_as_int(vrange));
+        if (normals) {
+            float *n = normals + 3 * (size_t)vj;
+            if (ed == 12) {
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) atomicAdd(n + ax, mult * (float)c12g[ax]);
+            } else {
+                // corners of edge ed (see mc_vertex_kernel); the core indexes its corner-number gradient table with the xyz-bit
+                // index of the corner (quirk)
+                const int k1 = ed < 8 ? (ed & 4) + (ed & 3) : ed - 8, k2 = ed < 8 ? (ed & 4) + ((ed + 1) & 3) : ed - 4;
+                const int i1 = (k1 >> 2) * 4 + ((k1 >> 1) & 1) * 2 + (((k1 + 1) >> 1) & 1);
+                const int i2 = (k2 >> 2) * 4 + ((k2 >> 1) & 1) * 2 + (((k2 + 1) >> 1) & 1);
+                const double w1 = 1.0 / (MC_EPS + fabs(pickv(k1))), w2 = 1.0 / (MC_EPS + fabs(pickv(k2)));
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax)
+                    atomicAdd(n + ax, mult * ((float)(pickg(i1, ax) * w1) + (float)(pickg(i2, ax) * w2)));
             }
-        }
-        const int tri = tri0 + i;
-        if (tri < cap_faces) {
-            // rows reversed (gradient_direction='descent')
-            faces[3 * (size_t)tri + 0] = vid[2];
-            faces[3 * (size_t)tri + 1] = vid[1];
-            faces[3 * (size_t)tri + 2] = vid[0];
         }
     }
 }
