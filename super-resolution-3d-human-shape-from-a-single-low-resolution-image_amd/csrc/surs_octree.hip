@@ -15,16 +15,41 @@
 namespace surs {
 namespace oct {
 
-// lattice points of stride reso that are dirty -> idx[] (unordered append), count
+// lattice points of stride reso that are dirty -> idx[] (unordered append), count.  One atomic per WAVE (the dirty lanes counted by
+// a ballot, every lane's slot = the wave's base + its rank among them): at the last level of a 512^3 sweep five million lattice
+// points are dirty, and one atomic each on the one counter took 7 ms of a 150 ms reconstruction.  32-bit index arithmetic where the
+// lattice has fewer than 2^32 points.
 __global__ void select_kernel(const unsigned char *__restrict__ dirty, int R, int reso, long long *__restrict__ idx,
                               int *__restrict__ count, int cap) {
     const int n = (R + reso - 1) / reso;
+    const long long total = (long long)n * n * n;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)n * n * n) return;
-    const int k = (int)(t % n), j = (int)((t / n) % n), i = (int)(t / ((long long)n * n));
-    const long long f = ((long long)(i * reso) * R + (long long)(j * reso)) * R + (long long)(k * reso);
-    if (dirty[f]) {
-        const int slot = atomicAdd(count, 1);
+    bool hit = false;
+    long long f = 0;
+    if (t < total) {
+        int i, j, k;
+        if (total < (1ll << 32)) {
+            const unsigned t32 = (unsigned)t, un = (unsigned)n;
+            const unsigned q = t32 / un;
+            k = (int)(t32 - q * un);
+            i = (int)(q / un);
+            j = (int)(q - (unsigned)i * un);
+        } else {
+            k = (int)(t % n);
+            j = (int)((t / n) % n);
+            i = (int)(t / ((long long)n * n));
+        }
+        f = ((long long)(i * reso) * R + (long long)(j * reso)) * R + (long long)(k * reso);
+        hit = dirty[f] != 0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, leader);
+    if (hit) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
         if (slot < cap) idx[slot] = f;
     }
 }
