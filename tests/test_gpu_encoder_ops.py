@@ -35,6 +35,11 @@ def _chw(img):
     (512, 512, 8, 8, 3, 1, True),     # bott2 at the smallest size
     (32, 3, 20, 20, 3, 1, True),      # last: cout 3
     (32, 128, 256, 256, 3, 1, True),  # 512 workgroups of 8 rows x 64 channels: the big tile of the split-bf16 kernel
+    (32, 64, 33, 47, 3, 2, True),     # stride 2 on the split-f16 kernel, odd sizes (ragged tiles, the last row / column padded)
+    (16, 32, 18, 22, 3, 2, False),
+    (3, 32, 5, 130, 3, 1, False),     # direct 3 -> 32 kernel: eight lanes per pixel, pixel count not a multiple of 32
+    (32, 3, 7, 9, 3, 1, False),       # direct 32 -> 3 kernel
+    (6, 32, 12, 12, 3, 1, True),      # neither: the fp32 MFMA kernel
 ])
 def test_conv(env, cin, cout, h, w, k, stride, bias):
     nat, orc = env["native"], env["oracle"]
@@ -88,6 +93,15 @@ def test_pool_bicubic_shuffle_add(env):
     assert np.array_equal(_chw(nat.add3(X, _img(env, y))), x + y)
     t = torch.from_numpy(x[None]).to(env["dev"])
     assert np.array_equal(_chw(nat.Img.from_nchw(t)), x)
+    # channel counts that are not multiples of 4 / 16 take the scalar forms of the same kernels: same results
+    x3 = prng.uniform("p3", 6, (3, 10, 14), -1, 1)
+    X3 = _img(env, x3)
+    assert np.array_equal(_chw(nat.avgpool2(X3)), orc.avg_pool2(x3))
+    assert common.rel_err(_chw(nat.bicubic_up2(X3, False)), orc.bicubic_up2(x3, False)) < 1e-6
+    y3 = prng.uniform("q3", 7, (3, 10, 14), -1, 1)
+    assert np.array_equal(_chw(nat.add3(X3, _img(env, y3))), x3 + y3)
+    x8 = prng.uniform("p8", 8, (8, 6, 10), -1, 1)
+    assert np.array_equal(_chw(nat.pixel_shuffle2(_img(env, x8), 0.2)), orc.lrelu(orc.pixel_shuffle2(x8), 0.2))
 
 
 @pytest.mark.parametrize("parts", [2, 3])
