@@ -1000,8 +1000,11 @@ extern "C" int surs_profile_read_ksteps(double *tile_mlps, double *ksteps) {
 
 // grid batches: the general fp32 mode evaluates GRID_BATCH voxels per pass; column mode COL_BATCH columns per pass
 static const long long GRID_BATCH = 65536;
+// (32 768 columns = 64 planes of a 512^3 grid per launch of the column kernel: half as many gaps - per-batch gather, GEMMs, fragment
+//  packing - as with 16 384, 1 - 1.4 % of a reconstruction, when the streamed extraction ends on a taper of small slabs:
+//  mesh_util.reconstruction_streamed; 65 536 gains nothing more)
 #ifndef SURS_COL_BATCH
-#define SURS_COL_BATCH 16384
+#define SURS_COL_BATCH 32768
 #endif
 static const long long COL_BATCH = SURS_COL_BATCH;
 

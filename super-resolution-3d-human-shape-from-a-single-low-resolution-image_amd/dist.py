@@ -254,7 +254,7 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     try:
         # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
         import os
-        planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
+        planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "32768")) // R)
         sweep = torch.cuda.current_stream(dev)
         done = []
         kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws)   # (probes the whole grid: every rank the same)

@@ -136,9 +136,12 @@ def meshes_from_volumes(net, vols, mat, level=0.5, want_normals=True):
     return out
 
 
+SLAB_COLUMNS = 32768   # the library's COL_BATCH (csrc/surs_query.hip): columns per launch of the column kernel
+
+
 def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, want_normals=True, timing=None,
                             planes=None, features=None, after_enqueue=None):
-    """Dense reconstruction with the mesh extraction pipelined into the sweep: the sweep writes the volumes 16 384 columns
+    """Dense reconstruction with the mesh extraction pipelined into the sweep: the sweep writes the volumes 32 768 columns
     (whole axis-0 planes) per launch; after every launch the cell layers that have become final are extracted
     (surs_mc_lewiner_range: Lewiner's sweep has axis 0 outermost, so their vertex / face numbers are final too) and their
     vertices and faces travel to the host under the next launches.  Same outputs as eval_volumes + meshes_from_volumes.
@@ -163,13 +166,30 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
     vl = torch.empty_like(vh)
     streams = [native.MeshStream(ws, 0, vh, mat[:3].reshape(-1), 0.5, want_normals),
                native.MeshStream(ws, 1, vl, mat[:3].reshape(-1), 0.5, want_normals)]
-    planes = planes or max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)   # default: one launch of the column kernel per slab
+    if planes is None and os.environ.get("SURS_SLAB_COLUMNS"):
+        planes = max(1, int(os.environ["SURS_SLAB_COLUMNS"]) // R)   # equal slabs of that many columns (timing experiments)
     # the whole sweep is enqueued first (no host synchronisation in it), with an event behind every slab ...
     sweep = torch.cuda.current_stream(dev)
     done = []
     kern = native.grid_kernel_for(R, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws)
-    for i0 in range(0, R, planes):
-        i1 = min(R, i0 + planes)
+    if planes:
+        sched = [(i0, min(R, i0 + planes)) for i0 in range(0, R, planes)]
+    else:
+        # one launch of the column kernel per slab (the library's COL_BATCH = 32 768 columns = 64 planes at 512^3), and the last
+        # slab's planes as a taper (5/8, 1/4, 1/8 of it): what follows the sweep - extraction and copies of the last slab's meshes -
+        # shrinks with it (mesh tail 1.3 -> 0.65 ms at 512^3)
+        big = max(1, SLAB_COLUMNS // R)
+        cuts, a = [], 0
+        while R - a > big:
+            cuts.append(big)
+            a += big
+        rem = R - a
+        cuts += [c for c in (rem * 5 // 8, rem // 4, rem - rem * 5 // 8 - rem // 4) if c > 0] if rem >= 8 else [rem]
+        sched, a = [], 0
+        for c in cuts:
+            sched.append((a, a + c))
+            a += c
+    for i0, i1 in sched:
         try:
             native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1],
                               kernel=kern)

@@ -12,6 +12,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 PRODUCTS = {"bf16": 1, "fp32": 3}
+COLS = 32768                      # columns per batch of the column kernel (the library's COL_BATCH)
+BATCHES = 512 * 512 // COLS       # batches per 512^3 sweep
+QUERIES = COLS * 512              # queries per batch
 
 
 def rows(sub, counter):
@@ -63,7 +66,7 @@ def one(prec):
     mfma = keep("pmc_mfma_" + prec, "SQ_VALU_MFMA_BUSY_CYCLES", "%s_pmc_mfma_busy_%s.csv" % (TAG, prec))
     # the fp32-grade kernel runs a batch in two passes (lr, then hr): the figures below are per BATCH = the sum of its launches
     # (tools/gpu_grid_once.py: 3 sweeps x 16 batches)
-    passes = max(1, round(len(fetch) / 48.0)) if fetch else 1
+    passes = max(1, round(len(fetch) / (3.0 * BATCHES))) if fetch else 1
     mean_b = lambda rs: (mean(rs) * passes) if rs else None
     dur_b = lambda rs: (dur_ms(rs) * passes) if rs else None
     f_kb, w_kb = mean_b(fetch), mean_b(write)
@@ -74,12 +77,12 @@ def one(prec):
     # bf16 (v7, 128-voxel tile): 16 per k-step, 256 + 64; fp32-grade (v8, 64-voxel tile): 8 affine, 24 per k-step, 384 + 96
     if tiles:
         per_wave = (16 * tiles + 16 * ks + 320 * tiles) if prec != "fp32" else (8 * tiles + 24 * ks + 480 * tiles)
-        expected = per_wave * 4 * 32 / 16.0      # 4 waves, 32 cycles per MFMA, 16 launches per sweep
+        expected = per_wave * 4 * 32 / float(BATCHES)      # 4 waves, 32 cycles per MFMA, per batch
     else:
-        expected = 8388608 * 2752512 * n / 32768 * 32   # dense layer 1 (v3 / v5)
+        expected = QUERIES * 2752512 * n / 32768 * 32   # dense layer 1 (v3 / v5)
     return {
         "kernel": fetch[0]["Kernel_Name"] if fetch else None,
-        "launch": "16384 columns x 512 voxels = 8388608 queries (R=512), tools/gpu_grid_once.py 512 " + prec,
+        "launch": "%d columns x 512 voxels = %d queries (R=512), tools/gpu_grid_once.py 512 %s" % (COLS, QUERIES, prec),
         "fetch_size_kb_raw_per_launch": f_kb,
         "write_size_kb_per_launch": w_kb,
         "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0 if f_kb is not None and w_kb is not None else None,
@@ -96,9 +99,9 @@ def one(prec):
         "layer1_residual_ksteps_per_tile_mlp": (ks / tiles) if tiles else None,
         # compulsory bytes of one launch: the two output fields (2 x 4 B per voxel) and the weight stream once; the
         # per-column constants (CC_PAD floats per column) and masks are the sweep's own intermediate, listed separately
-        "algorithmic_bytes_per_launch": 8388608 * 8 + weights,
-        "column_constant_bytes_per_launch": 16384 * 2944 * 4 + 16384 * 4,
-        "affine_fragment_bytes_per_launch": 16384 * 32768 if tiles else 0,   # kernels v7 / v8: [column][MLP][16][64][8] 16-bit
+        "algorithmic_bytes_per_launch": QUERIES * 8 + weights,
+        "column_constant_bytes_per_launch": COLS * 2944 * 4 + COLS * 4,
+        "affine_fragment_bytes_per_launch": COLS * 32768 if tiles else 0,   # kernels v7 / v8: [column][MLP][16][64][8] 16-bit
     }
 
 
@@ -118,7 +121,7 @@ def sq(prec):
         w = out["SQ_WAVE_CYCLES"]
         out["fraction_of_wave_cycles"] = {k: out[k] / w for k in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
                                                                    "SQ_WAIT_INST_LDS") if k in out}
-    out["note"] = ("rocprofv3 --pmc over tools/gpu_grid_once.py 512 %s, averages per launch of 16384 columns x 512 voxels; SQ_* cycle "
+    out["note"] = ("rocprofv3 --pmc over tools/gpu_grid_once.py 512 %s, averages per launch of 32768 columns x 512 voxels; SQ_* cycle "
                    "counters are in units of 4 clocks, summed over the resident waves" % prec)
     return out
 
