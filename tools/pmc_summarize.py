@@ -86,6 +86,8 @@ def one(prec):
         "fetch_size_kb_raw_per_launch": f_kb,
         "write_size_kb_per_launch": w_kb,
         "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0 if f_kb is not None and w_kb is not None else None,
+        # the same per 16 384 columns = 8 388 608 queries, the batch of rounds 1 - 3a (what VERDICT r2 item 6 measured: 19.3 GB for v8)
+        "hbm_bytes_per_16384_columns": (2.0 * f_kb + w_kb) * 1024.0 * 16384.0 / COLS if f_kb is not None and w_kb is not None else None,
         "l2_hit_rate": (mean(hit) / (mean(hit) + mean(miss))) if hit and miss else None,
         "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
         "launches_per_batch": passes,
