@@ -145,7 +145,11 @@ def hourglass(W, prefix, depth, x):
     one (pool -> ConvBlock -> [next level] -> ConvBlock; maps of 128^2 and 64^2 whose kernels fill a fraction of the chip) runs on
     a side stream beside the full-resolution ConvBlock.  Buffers cross streams only at the fork and the join, both ordered by
     events; a side stream's next use starts by waiting for the calling stream, i.e. after every reader of what it freed."""
-    fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0"
+    # (only for an encoder that runs on the device's default stream: gen_mesh_pipelined runs the next subject's encoder on a second
+    #  stream under the current sweep, where two more streams of small kernels cost the sweep more than they save - 6.6 against 7.4
+    #  subjects/s at 512^3)
+    cur0 = torch.cuda.current_stream()
+    fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0" and cur0.cuda_stream == torch.cuda.default_stream(cur0.device).cuda_stream
 
     def fwd(level, inp):
         def low_branch():
