@@ -194,7 +194,10 @@ def main():
                 r["pmc"] = {"source": "profiles/pmc_summary.json (separate rocprofv3 --pmc passes, not this run)",
                             "lib_sha256_profiled": summary.get("lib_sha256"), "matches_this_library": same}
                 if entry and same:
-                    r["traffic"] = entry.get("hbm_bytes_per_launch")
+                    # per launch like `achieved`: the counters were collected on full batches (entry["queries_per_launch"]); the
+                    # streamed reconstruction ends on a few shorter launches, so its average launch is smaller
+                    scale = k_pts / float(entry["queries_per_launch"]) if entry.get("queries_per_launch") else 1.0
+                    r["traffic"] = entry.get("hbm_bytes_per_launch") * scale if entry.get("hbm_bytes_per_launch") is not None else None
                     r["mfma_busy_fraction_pmc"] = entry.get("mfma_busy_fraction")
             except Exception:
                 pass

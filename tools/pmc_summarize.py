@@ -91,6 +91,7 @@ def one(prec):
         "l2_hit_rate": (mean(hit) / (mean(hit) + mean(miss))) if hit and miss else None,
         "scratch_bytes_per_lane": int(fetch[0]["Scratch_Size"]) if fetch else None,
         "launches_per_batch": passes,
+        "queries_per_launch": QUERIES,
         "effective_clock_ghz": (mean(gui) / 8.0 / (dur_ms(gui) * 1e-3) * 1e-9) if gui else None,
         "avg_launch_ms_under_pmc": dur_b(fetch),
         # SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipes were busy, summed over the chip's 1024 SIMDs (32 per
