@@ -254,7 +254,9 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     try:
         # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
         import os
-        planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "32768")) // R)
+        # (16 384 columns per launch here, half of what one GPU sweeps per launch: a rank of eight holds 64 planes of a 512^3 grid,
+        #  and with one launch its marching cubes would all follow the sweep instead of running under its second half)
+        planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
         sweep = torch.cuda.current_stream(dev)
         done = []
         kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws)   # (probes the whole grid: every rank the same)
