@@ -8,7 +8,7 @@ seeded random-init weights; `value` is queries per second over the whole job.
         bench.py --gpus N --steps K --warmup W
 
 `--precision bf16` (default: what BASELINE configs[2] names) | `fp16` (configs[4]) | `fp32` (the parity-grade sweep:
-column kernel v8, split-f16 operands, logits within 1e-4 of the reference).  At N=1 the line also carries
+column kernel v11, split-f16 operands, logits within 1e-4 of the reference).  At N=1 the line also carries
 `config.fp32_mode` - the same step timed in fp32 - and `config.precision_acceptance` - what the reduced precisions do to
 the field and the meshes at full size against the fp32 sweep (tools/precision_report.py; asserted in
 tests/test_gpu_precision.py).
@@ -116,7 +116,7 @@ def main():
             net.filter_lr(f_lr)
             ev[1].record()
             if slab:
-                m = sdist.reconstruction_sharded(o, net, calib, R, b_min, b_max, want_normals=False, timing=ev[2])
+                m = sdist.reconstruction_sharded(o, net, calib, R, b_min, b_max, want_normals=False, timing=ev[2], copy_out=False)
             else:
                 # the product path of reconstruction(): marching cubes and the mesh copies pipelined into the sweep (from
                 # the second reconstruction on: the first one sizes the mesh buffers); ev[2] = end of the sweep's last launch
@@ -145,7 +145,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         launches, kms, kpts, ktiles, ksteps = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
-        lib.surs_profile_read_ksteps(C.byref(ktiles), C.byref(ksteps))   # (column kernel v7: data-dependent layer-1 k-steps)
+        lib.surs_profile_read_ksteps(C.byref(ktiles), C.byref(ksteps))   # (column kernels v10 / v11: data-dependent layer-1 k-steps)
         lib.surs_profile_read(C.byref(launches), C.byref(kms), C.byref(kpts))
         lib.surs_profile_enable(0)
         if world > 1:
@@ -161,7 +161,7 @@ def main():
         nprod = PRODUCTS[prec]
         alg = k_pts * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         # what the matrix pipe executes per query: the dense cores of layers 1-3 (column-constant reduction, A.4); with column
-        # kernel v7 layer 1 is one affine k-step + the measured residual k-steps (16 channels x 512 rows each) instead of 64
+        # kernels v10 / v11: layer 1 is one affine k-step + the measured residual k-steps (16 channels x 512 rows each) instead of 64
         # (the affine k-step is one product per MAC also in the fp32-grade kernel)
         flop_exec = FLOP_EXECUTED * nprod if kavg is None else 2 * (2 * (512 * 256 + 256 * 128) * nprod + (kavg * nprod + 1.0) * 16 * 512 * 2)
         exe = k_pts * flop_exec / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
@@ -317,7 +317,7 @@ def main():
                                                                for s in ("to_ref", "from_ref")}}
                                  for t in ("hr", "lr")} for p in ("bf16", "fp16")}
                 acc[name]["sweep_s"] = rep["sweep_s"]
-            acc["reference"] = "fp32-grade sweep (column kernel v8) on the same features and weights, 512^3"
+            acc["reference"] = "fp32-grade sweep (column kernel v11) on the same features and weights, 512^3"
             acc["why_bf16"] = ("BASELINE configs[2] names bf16: fp32's exponent range, no activation can overflow; fp16 (configs[4]) is "
                                "8x tighter at 0.93x the rate but saturates at 65504 - `--precision fp16` / `fp32` select the others")
             extras["precision_acceptance"] = acc

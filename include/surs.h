@@ -137,8 +137,7 @@ int surs_set_operand_split_local(int parts);
 
 /* Column kernel of surs_query_grid, process-wide (A/B comparisons and regression tests; a per-call choice goes through
  * surs_query_grid_opt): 0 = default (or the SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL environment variables); reduced precision
- * 3 (dense layer 1), 7, 10 (layer 1 restated along the column, four / eight waves); fp32-grade 5 (dense), 8, 11 (restated, four /
- * eight waves) - DESIGN.md section 4.1. */
+ * 3 (dense layer 1), 10 (layer 1 restated along the column); fp32-grade 5 (dense), 11 (restated) - DESIGN.md section 4. */
 int surs_set_grid_kernel(int version);
 
 /* How many of the 1024 layer-0 channels the default column kernels (layer 1 restated along the column) would
@@ -199,8 +198,8 @@ int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const flo
 size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype);
 
 /* The same sweep with per-call choices instead of process-wide ones (nothing global is read for a field that is set, nothing
- * global is written): `kernel` = column-kernel version (0 = the process setting / default; reduced precision 3, 7, 10;
- * fp32-grade 5, 8, 11 - DESIGN.md 4.1), `operand_parts` = operand split of the fp32-grade GEMMs behind the sweep (0 = process
+ * global is written): `kernel` = column-kernel version (0 = the process setting / default; reduced precision 3, 10;
+ * fp32-grade 5, 11 - DESIGN.md 4), `operand_parts` = operand split of the fp32-grade GEMMs behind the sweep (0 = process
  * setting, 2 = two f16 parts, 3 = three bf16 parts).  opt == NULL behaves as surs_query_grid.  Safe to call from several host
  * threads on different streams. */
 typedef struct SursGridOptions {
@@ -224,6 +223,20 @@ int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double *mat, const
  *   surs_f64_to_f32        the cast marching_cubes_lewiner applies to its input */
 int surs_octree_select(const unsigned char *dirty, int R, int reso, long long *idx, int cap, int *count_dev, int *count_host,
                        void *stream);
+/* select + evaluate + scatter of one level in ONE call, on the sweep's fp32-grade COLUMN kernel (axis-aligned orthographic sweeps:
+ * the lattice points of stride `reso` form columns along axis 2 that share their image position, so the per-column constants
+ * and the restated layer 1 of surs_query_grid apply with the z items of a column `reso` voxels apart).  A z tile of 64 lattice
+ * points is evaluated iff it holds a dirty lattice point; only the dirty points are written (sdf = value, dirty = 0), i.e. exactly
+ * the points lib/sdf.py:68-74 evaluates.  A lattice point's value is a function of the point and of `reso` alone (its tile is
+ * evaluated whole), not of which other points are dirty.  kmid: axis-2 voxel index where the kernel takes its per-column
+ * LeakyReLU branches (R / 2; any value gives the same function up to rounding).  counts (HOST, nullable): [0] dirty lattice
+ * points evaluated, [1] lattice columns that held them.  Synchronises the stream once.  SURS_E_UNSUPPORTED for a general
+ * calibration: use the three calls above and below. */
+int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid, const double *mat,
+                              const float *calib, float zmul, float zdiv, const float *feat_lr, int hl, int wl,
+                              const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,
+                              long long *counts, void *stream);
+size_t surs_octree_columns_workspace_bytes(int R);
 int surs_query_grid_indexed(const long long *idx, int n, int ry, int rz, const double *mat, const float *calib, float zmul,
                             float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
                             const void *mlp_blob, void *workspace, size_t workspace_bytes, float *pred_hr, float *pred_lr,

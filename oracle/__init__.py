@@ -383,12 +383,14 @@ def reconstruction_dense(sd, feat_lr, feat_hr, calib, res, b_min, b_max, load_si
     return out
 
 
-def eval_grid_octree(res, b_min, b_max, eval_func, threshold=0.05, init_resolution=64, trace=None):
+def eval_grid_octree(res, b_min, b_max, eval_func, threshold=0.05, init_resolution=64, trace=None, index_func=None):
     """eval_grid_octree (/root/reference/lib/sdf.py:55-120), vectorised per level instead of the reference's Python
     triple loop.  The cell walk is order independent (a cell writes only its own block; the corners it reads are the
     min-corners of cells later in the loop order), so deciding all cells of a level from the arrays as evaluated and
     then applying the fills gives the same arrays - tests/test_oracle_octree.py checks that against the reference's
-    loop.  eval_func(points[3,n] float64) -> (hr[n], lr[n]).  Keeps the shared-`dirty` quirk.
+    loop.  eval_func(points[3,n] float64) -> (hr[n], lr[n]); or index_func(reso, ii, jj, kk) -> (hr[n], lr[n]) on the voxel
+    indices of the same points (tests that drive the walk with the product's own evaluator, whose rounding may depend on the
+    level).  Keeps the shared-`dirty` quirk.
     Returns float64 (sdf_hr, sdf_lr) of shape [res]*3."""
     R = res
     bmin, bmax = np.asarray(b_min, np.float64), np.asarray(b_max, np.float64)
@@ -401,8 +403,11 @@ def eval_grid_octree(res, b_min, b_max, eval_func, threshold=0.05, init_resoluti
         grid_mask[0:R:reso, 0:R:reso, 0:R:reso] = True
         test = np.logical_and(grid_mask, dirty)
         ii, jj, kk = np.nonzero(test)
-        pts = np.stack([scale[0] * ii + bmin[0], scale[1] * jj + bmin[1], scale[2] * kk + bmin[2]])
-        hr, lr = eval_func(pts)
+        if index_func is not None:
+            hr, lr = index_func(reso, ii, jj, kk)
+        else:
+            pts = np.stack([scale[0] * ii + bmin[0], scale[1] * jj + bmin[1], scale[2] * kk + bmin[2]])
+            hr, lr = eval_func(pts)
         sdf_hr[test], sdf_lr[test] = hr, lr
         dirty[test] = False
         if reso <= 1:

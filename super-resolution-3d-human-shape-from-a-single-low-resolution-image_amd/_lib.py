@@ -81,6 +81,9 @@ _SIGS = {
     "surs_octree_select": (C.c_int, [_vp, _i, _i, _vp, _i, _vp, C.POINTER(C.c_int), _vp]),
     "surs_query_grid_indexed": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "surs_octree_scatter": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "surs_octree_level_columns": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz,
+                                            C.POINTER(C.c_longlong), _vp]),
+    "surs_octree_columns_workspace_bytes": (_sz, [_i]),
     "surs_octree_workspace_bytes": (_sz, [_i, _i]),
     "surs_octree_cells": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_double, _vp, _sz, _vp]),
     "surs_f64_to_f32": (C.c_int, [_vp, _vp, C.c_longlong, _vp]),

@@ -42,10 +42,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 struct PointSource {
     // mode 0: explicit points [3][n] (ld = n_total);  mode 1: grid voxels, flat index base+t, z fastest;
-    // mode 2: grid columns, flat column index base+t = i*ry + j (k = 0);  mode 3: grid voxels listed in idx[t]
+    // mode 2: grid columns, flat column index base+t = i*ry + j (k = 0);  mode 3: grid voxels listed in idx[t];
+    // mode 4: grid columns listed in cols[t] (column index i*ry + j, k = 0): the octree levels' lattice columns
     int mode;
     const float *pts;
     const long long *idx;
+    const int *cols;
     long long ld;
     long long base;
     int ry, rz;
@@ -61,7 +63,7 @@ __device__ __forceinline__ void make_point(const PointSource &s, long long t, fl
         py = s.pts[s.ld + t];
         pz = s.pts[2 * s.ld + t];
     } else {
-        long long f = (s.mode == 3) ? s.idx[t] : s.base + t;
+        long long f = (s.mode == 3) ? s.idx[t] : (s.mode == 4 ? (long long)s.cols[t] : s.base + t);
         double i, j, k;
         if (s.mode == 1 || s.mode == 3) {
             k = (double)(f % s.rz);
@@ -605,6 +607,10 @@ struct GridArgs {
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
     int ncols, rz;
+    // lattice sweeps (the octree levels, surs_octree_level_columns): a column's rz items are the voxels k * zstride, and only the
+    // z tiles whose bit is set in tilemask[column] are evaluated (null: all of them).  Dense sweeps: zstride 1, tilemask null.
+    int zstride;
+    const unsigned *tilemask;
     double z0, dz;  // world z of voxel k = (float)(dz*k + z0)
     float c22, c23;  // Z(k) = c23 + c22 * z(k)   (calib[2][0] = calib[2][1] = 0 in column mode)
     float zmul, zdiv;
@@ -622,9 +628,8 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 
 #include "surs_grid_v3.inc"
 #include "surs_grid_v5.inc"
-#include "surs_grid_v7.inc"
+#include "surs_grid_restated.inc"
 #include "surs_grid_v10.inc"
-#include "surs_grid_v8.inc"
 #include "surs_grid_v11.inc"
 
 // Column kernel v7's per-column affine part, step 1: the vectors g . a0, g . w0z (lr) and g . a0, g . w0z, g . w0p (hr) of a
@@ -721,10 +726,10 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 #define SURS_DEFAULT_GRID_F32_KERNEL 11
 #endif
 static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
-static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 7 || v == 10 || v == 5 || v == 8 || v == 11; }
+static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 10 || v == 5 || v == 11; }
 extern "C" int surs_set_grid_kernel(int version) {
     SURS_REQUIRE(grid_kernel_known(version),
-                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3, 7 or 10, fp32-grade 5, 8 or 11");
+                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3 or 10, fp32-grade 5 or 11");
     g_grid_kernel_override = version;
     return 0;
 }
@@ -1047,9 +1052,6 @@ static int grid_set_attributes() {
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v3<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID3_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, GRID5_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v7<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID7_LDS_BYTES));
-    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v8, hipFuncAttributeMaxDynamicSharedMemorySize, GRID8_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v11, hipFuncAttributeMaxDynamicSharedMemorySize, GRID11_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
@@ -1155,7 +1157,7 @@ extern "C" int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double 
     if (opt) {
         kernel = opt->kernel;
         parts = opt->operand_parts;
-        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 7, 10 (reduced precision), 5, 8, 11 (fp32-grade)");
+        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 10 (reduced precision), 5, 11 (fp32-grade)");
         SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "SursGridOptions.operand_parts: 0, 2 or 3");
     }
     // the operand split is read deep inside the launch helpers: scoped to this call and this thread, the process setting
@@ -1174,6 +1176,252 @@ extern "C" int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat
                                float *vol_lr, void *stream) {
     return query_grid_impl(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, hl, wl, feat_hr, hh, wh, mlp_blob, dtype, workspace,
                            workspace_bytes, vol_hr, vol_lr, 0, stream);
+}
+
+// What every column batch of one sweep shares (dense sweeps: query_grid_impl; lattice sweeps: surs_octree_level_columns).
+namespace {
+struct ColumnSweep {
+    hipStream_t st;
+    const char *blob;
+    MlpBlobHeader h;
+    int dtype;            // SURS_F32 / SURS_BF16 / SURS_F16
+    int kver, kver32;     // column kernel of the reduced precisions / of SURS_F32
+    bool restated;
+    const float *feat_lr; int hl, wl;
+    const float *feat_hr; int hh, wh;
+    const double *mat; const float *calib; float zmul, zdiv;
+    void *workspace;
+    int cus;
+    int kmid;             // axis-2 voxel index at which the restated kernels take the per-column LeakyReLU branches g_c
+};
+}  // namespace
+
+// Column kernel of a sweep.  Reduced precision: 10 (default) = layer 1 restated along the column as a per-column affine part +
+// the residuals of the channels whose LeakyReLU branch changes inside the z tile, eight waves per workgroup; 3 = dense layer 1
+// (what the host asks for on fields that list most channels; differs from 10 by a few 16-bit roundings of layer 0).  fp32-grade
+// (SURS_F32): 11 (default: restated, eight waves) or 5 (dense).  Precedence: the call's SursGridOptions.kernel, then
+// surs_set_grid_kernel, then SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL, then the default.
+static void resolve_column_kernels(int kernel_call, int &kver, int &kver32) {
+    static int kver_env = -1;
+    if (kver_env < 0) {
+        const char *e = getenv("SURS_GRID_KERNEL");
+        const int v = e ? atoi(e) : 0;
+        kver_env = (v == 3 || v == 10) ? v : SURS_DEFAULT_GRID_KERNEL;
+    }
+    static int kver32_env = -1;
+    if (kver32_env < 0) {
+        const char *e = getenv("SURS_GRID_F32_KERNEL");
+        const int v = e ? atoi(e) : 0;
+        kver32_env = (v == 5 || v == 11) ? v : SURS_DEFAULT_GRID_F32_KERNEL;
+    }
+    const auto is32 = [](int v) { return v == 5 || v == 11; };
+    kver = kver_env;
+    kver32 = kver32_env;
+    if (g_grid_kernel_override) (is32(g_grid_kernel_override) ? kver32 : kver) = g_grid_kernel_override;
+    if (kernel_call) (is32(kernel_call) ? kver32 : kver) = kernel_call;
+}
+
+static int device_cus() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) return prop.multiProcessorCount;
+    return 256;
+}
+
+// One batch of nc <= COL_BATCH columns described by src (mode 2: consecutive columns from src.base; mode 4: listed columns):
+// gather + column constants, the restated kernels' per-column affine part, then the column kernel over `items` z items per column
+// (voxels k * zstride; only the z tiles flagged in tilemask[column] when that is given).  vol_*: [nc][items].
+static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long long nc, int items, int zstride,
+                            const unsigned *tilemask, float *vol_hr, float *vol_lr, bool trace_this) {
+    hipStream_t st = cs.st;
+    const char *blob = cs.blob;
+    const MlpBlobHeader &h = cs.h;
+    const int dtype = cs.dtype, kver = cs.kver, kver32 = cs.kver32;
+    const bool restated = cs.restated;
+    const double *mat = cs.mat;
+    const float *calib = cs.calib;
+    void *workspace = cs.workspace;
+    float *F = (float *)workspace;
+    float *CC = F + (size_t)C0PAD * COL_BATCH;
+    float *cmask = CC + (size_t)CC_PAD * COL_BATCH;
+    int rc = 0;
+    const long long ncp = (long long)ceil_div(nc, 256) * 256;   // <= COL_BATCH; rows nc.. of CC are never read
+    const int parts = split_parts();
+    if ((rc = column_constants(st, src, nc, ncp, cs.feat_lr, cs.hl, cs.wl, cs.feat_hr, cs.hh, cs.wh, blob, h, F, CC, cmask))) return rc;
+    GridArgs a;
+    a.cc = CC;
+    a.colmask = cmask;
+    a.zvec = (const float *)(blob + h.zvec);
+    a.core = blob + h.core;
+    a.corex = blob + h.corex;
+    a.b1frag = blob + h.b1frag;
+    a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
+    a.w1t = blob + h.w1t;
+    a.w1tx = blob + h.w1tx;
+    a.rfrag = nullptr;
+    a.colctr = nullptr;
+    a.phase = 0;
+    a.zmid = 0.0f;
+    a.zstride = zstride;
+    a.tilemask = tilemask;
+    if (restated) {
+        // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
+        if ((rc = g3_set_attributes())) return rc;
+        char *v7 = (char *)workspace + col_base_bytes(COL_BATCH);
+        unsigned short *g_lr = (unsigned short *)v7, *g_hr = g_lr + (size_t)COL_BATCH * 2 * D1 * 3;
+        float *r_lr = (float *)(v7 + col_v7_image_bytes(COL_BATCH)), *r_hr = r_lr + (size_t)COL_BATCH * 2 * D2;
+        float *zero_bias = r_hr + (size_t)COL_BATCH * 3 * D2;
+        SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4 + 256, st));   // + the column counter behind it
+        a.colctr = (unsigned *)(zero_bias + D2);
+        {
+            const float zw = (float)(mat[10] * (double)cs.kmid + mat[11]);
+            a.zmid = (calib[11] + calib[10] * zw) * cs.zmul / cs.zdiv;
+        }
+        const long long part_lr = 2LL * ncp * D1, part_hr = 3LL * ncp * D1;
+        const dim3 pg((unsigned)(ncp / 64), D1 / 64);
+        // operand parts of this GEMM: the sweep's split (two f16 / three bf16 parts: fp32 grade) for the fp32-grade and the f16
+        // kernel; ONE f16 part for the bf16 kernel - 11 significant bits, 8x what bf16 gives the rest of the classifier, a third
+        // of the MFMA work, no measurable change of the bf16 sweep's error (SURS_R_PARTS=0: the split's parts there too)
+        static const int r_parts_env = getenv("SURS_R_PARTS") ? atoi(getenv("SURS_R_PARTS")) : 1;
+        const int rparts = (dtype == SURS_BF16 && r_parts_env == 1) ? 1 : parts;
+        if (rparts == 1)
+            hipLaunchKernelGGL(colsum_prepare_kernel<1>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
+                               g_lr, part_lr, g_hr, part_hr);
+        else if (rparts == 2)
+            hipLaunchKernelGGL(colsum_prepare_kernel<2>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
+                               g_lr, part_lr, g_hr, part_hr);
+        else
+            hipLaunchKernelGGL(colsum_prepare_kernel<3>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
+                               g_lr, part_lr, g_hr, part_hr);
+        SURS_LAUNCH_CHECK();
+        for (int m = 0; m < 2; ++m) {
+            const int nvec = m ? 3 : 2;
+            const long long npm = (long long)nvec * ncp;
+            SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
+            const int nb256 = (int)(npm / 256);
+            float *R = m ? r_hr : r_lr;
+            if (rparts == 1)   // (the first part of the two-part weight image is f16(w))
+                hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 1>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 1),
+                                   st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
+                                   (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
+            else if (rparts == 2)
+                hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 2>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 2),
+                                   st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
+                                   (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
+            else
+                hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256),
+                                   st, (const unsigned short *)(blob + h.wt3[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
+                                   (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
+            SURS_LAUNCH_CHECK();
+        }
+        {
+            const unsigned fb = (unsigned)ceil_div(nc * 32, 4);
+            if (dtype == SURS_BF16)   // (the fp32-grade kernel's fragments are f16 parts)
+                hipLaunchKernelGGL(colsum_frag_kernel<SURS_BF16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
+            else
+                hipLaunchKernelGGL(colsum_frag_kernel<SURS_F16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
+            SURS_LAUNCH_CHECK();
+        }
+        a.rfrag = v7;
+    }
+    a.vol_hr = vol_hr;
+    a.vol_lr = vol_lr;
+    a.ncols = (int)nc;
+    a.rz = items;
+    a.z0 = mat[11];
+    a.dz = mat[10];
+    a.c22 = calib[10];
+    a.c23 = calib[11];
+    a.zmul = cs.zmul;
+    a.zdiv = cs.zdiv;
+    const unsigned grid = (unsigned)((nc < cs.cus) ? nc : cs.cus);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool prof;
+    a.kstat = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        prof = g_prof.on && !tilemask;   // (the bench's per-launch figures are those of dense sweeps)
+        if (prof && restated) {
+            int dev = 0;
+            SURS_HIP_CHECK(hipGetDevice(&dev));
+            unsigned long long *&ctr = g_prof.kstat[dev];
+            if (!ctr) {
+                SURS_HIP_CHECK(hipMalloc((void **)&ctr, sizeof(unsigned long long)));
+                SURS_HIP_CHECK(hipMemset(ctr, 0, sizeof(unsigned long long)));
+            }
+            a.kstat = ctr;
+            g_prof.tiles += 2.0 * (double)nc * (dtype == SURS_F32 ? (items + 63) / 64 : (items + 127) / 128);
+        }
+    }
+    if (prof) {
+        SURS_HIP_CHECK(hipEventCreate(&e0));
+        SURS_HIP_CHECK(hipEventCreate(&e1));
+        SURS_HIP_CHECK(hipEventRecord(e0, st));
+    }
+    if (dtype == SURS_F32) {
+        if (kver32 == 11) {
+            // two passes over the batch (lr, then hr on the lr occupancies just written): each pass streams ONE classifier's
+            // split weights (2.6 MiB), which an XCD's 4 MiB L2 holds; both together do not fit and 8 % of the stream came from
+            // HBM.  Only with whole 64-voxel tiles (the hr pass reads its tile's lr occupancies back from vol_lr, which has no
+            // room for the voxels beyond the column's end that the one-pass form computes and classifies on); same bits.
+            static const int passes_env = getenv("SURS_GRID_F32_PASSES") ? atoi(getenv("SURS_GRID_F32_PASSES")) : 2;
+            const bool two = passes_env == 2 && items % 64 == 0;
+            for (int ph = two ? 1 : 0; ph <= (two ? 2 : 0); ++ph) {
+                a.phase = ph;
+                hipLaunchKernelGGL(grid_mlp_kernel_v11, dim3(grid), dim3(V11_THREADS), GRID11_LDS_BYTES, st, a);
+            }
+        } else
+            hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
+    } else if (kver == 10) {
+        if (dtype == SURS_BF16)
+            hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_BF16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_F16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
+    } else {
+        if (dtype == SURS_BF16)
+            hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
+    }
+    SURS_LAUNCH_CHECK();
+#ifdef SURS_V3_TRACE
+    if (trace_this && getenv("SURS_V3_TRACE")) {
+        unsigned long long t[64];
+        SURS_HIP_CHECK(hipStreamSynchronize(st));
+        SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
+        for (int m = 0; m < 2; ++m) {
+            fprintf(stderr, "v3 trace MLP %d:", m);
+            for (int i = 1; i < 10; ++i) fprintf(stderr, " %llu", t[16 * m + i] - t[16 * m + i - 1]);
+            fprintf(stderr, "  total %llu\n", t[16 * m + 9] - t[16 * m]);
+            if (restated) {
+                fprintf(stderr, "   v7 layer 1 (since start): init issued %llu, list %llu, chunk 0: gathered %llu, residuals %llu, barrier %llu, mfma+barrier %llu; listed %llu\n",
+                        t[16 * m + 10] - t[16 * m], t[16 * m + 1] - t[16 * m], t[16 * m + 11] - t[16 * m], t[16 * m + 12] - t[16 * m],
+                        t[16 * m + 13] - t[16 * m], t[16 * m + 14] - t[16 * m], t[48 + m]);
+            }
+        }
+        fprintf(stderr, "v3 trace between MLPs: %llu\n", t[16] - t[9]);
+        const double cyc = (double)(t[42] - t[40]), us = (double)(t[43] - t[41]) / 100.0;
+        const int tile = dtype == SURS_F32 ? 64 : 128;
+        fprintf(stderr, "workgroup 0: %.0f cycles in %.1f us = %.3f GHz; %.0f cycles per %d-point tile\n", cyc, us,
+                cyc / us * 1e-3, cyc / ((double)((nc + grid - 1) / grid) * ((items + tile - 1) / tile)), tile);
+    }
+#else
+    (void)trace_this;
+#endif
+    if (prof) {
+        SURS_HIP_CHECK(hipEventRecord(e1, st));
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        g_prof.ev.emplace_back(e0, e1);
+        g_prof.pts.push_back((double)nc * items);
+    }
+    return 0;
+}
+
+// column mode needs: projected X,Y independent of k; world z a function of k only
+static bool sweep_has_columns(const double *mat, const float *calib) {
+    const float cX = (float)(calib[0] * mat[2] + calib[1] * mat[6] + calib[2] * mat[10]);
+    const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
+    return !(cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f);
 }
 
 static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, const float *calib, float zmul,
@@ -1197,11 +1445,7 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
     for (int i = 0; i < 12; ++i) src.mat[i] = mat[i];
     fill_calib(src, calib, zmul, zdiv);
     const char *blob = (const char *)mlp_blob;
-
-    // column mode needs: projected X,Y independent of k; world z a function of k only
-    const float cX = (float)(calib[0] * mat[2] + calib[1] * mat[6] + calib[2] * mat[10]);
-    const float cY = (float)(calib[4] * mat[2] + calib[5] * mat[6] + calib[6] * mat[10]);
-    const bool columns = !(cX != 0.0f || cY != 0.0f || mat[8] != 0.0 || mat[9] != 0.0 || calib[8] != 0.0f || calib[9] != 0.0f);
+    const bool columns = sweep_has_columns(mat, calib);
 
     if (dtype == SURS_F32 && !(columns && grid_f32_use_columns() && !force_gemm)) {
         // general calibration: every voxel is its own point, the five layers are GEMMs on the split-bf16 layer kernels
@@ -1223,216 +1467,25 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
         return fail(SURS_E_UNSUPPORTED,
                     "column kernel needs an axis-aligned orthographic sweep (X,Y independent of k); use SURS_F32");
     const long long ncols = (long long)(i1 - i0) * ry;
-    float *F = (float *)workspace;
-    float *CC = F + (size_t)C0PAD * COL_BATCH;
-    float *cmask = CC + (size_t)CC_PAD * COL_BATCH;
-    int cus = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    // Column kernel of this sweep.  Reduced precision: 10 (default) = layer 1 restated along the column as a per-column affine
-    // part + the residuals of the channels whose LeakyReLU branch changes inside the z tile, eight waves per workgroup; 7 = the
-    // same arithmetic on four waves (its regression reference); 3 = dense layer 1 (what the host asks for on fields that list most
-    // channels; differs from 7 / 10 by a few 16-bit roundings of layer 0).  fp32-grade (SURS_F32): 11 (default: restated, eight
-    // waves), 8 (the same on four waves) or 5 (dense).  Precedence: the call's SursGridOptions.kernel, then surs_set_grid_kernel, then SURS_GRID_KERNEL /
-    // SURS_GRID_F32_KERNEL, then the default.
-    static int kver_env = -1;
-    if (kver_env < 0) {
-        const char *e = getenv("SURS_GRID_KERNEL");
-        const int v = e ? atoi(e) : 0;
-        kver_env = (v == 3 || v == 7 || v == 10) ? v : SURS_DEFAULT_GRID_KERNEL;
-    }
-    static int kver32_env = -1;
-    if (kver32_env < 0) {
-        const char *e = getenv("SURS_GRID_F32_KERNEL");
-        const int v = e ? atoi(e) : 0;
-        kver32_env = (v == 5 || v == 8 || v == 11) ? v : SURS_DEFAULT_GRID_F32_KERNEL;
-    }
-    const auto is32 = [](int v) { return v == 5 || v == 8 || v == 11; };
-    int kver = kver_env, kver32 = kver32_env;
-    if (g_grid_kernel_override) (is32(g_grid_kernel_override) ? kver32 : kver) = g_grid_kernel_override;
-    if (kernel_call) (is32(kernel_call) ? kver32 : kver) = kernel_call;
-    const bool restated = dtype == SURS_F32 ? (kver32 == 8 || kver32 == 11) : (kver == 7 || kver == 10);
+    ColumnSweep cs;
+    cs.st = st;
+    cs.blob = blob;
+    cs.h = h;
+    cs.dtype = dtype;
+    resolve_column_kernels(kernel_call, cs.kver, cs.kver32);
+    cs.restated = dtype == SURS_F32 ? cs.kver32 == 11 : cs.kver == 10;
+    cs.feat_lr = feat_lr; cs.hl = hl; cs.wl = wl;
+    cs.feat_hr = feat_hr; cs.hh = hh; cs.wh = wh;
+    cs.mat = mat; cs.calib = calib; cs.zmul = zmul; cs.zdiv = zdiv;
+    cs.workspace = workspace;
+    cs.cus = device_cus();
+    cs.kmid = rz / 2;
     if ((rc = grid_set_attributes())) return rc;
     src.mode = 2;
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
         const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
-        const long long ncp = (long long)ceil_div(nc, 256) * 256;   // <= COL_BATCH; rows nc.. of CC are never read
         src.base = (long long)i0 * ry + c0;
-        const int parts = split_parts();
-        if ((rc = column_constants(st, src, nc, ncp, feat_lr, hl, wl, feat_hr, hh, wh, blob, h, F, CC, cmask))) return rc;
-        GridArgs a;
-        a.cc = CC;
-        a.colmask = cmask;
-        a.zvec = (const float *)(blob + h.zvec);
-        a.core = blob + h.core;
-        a.corex = blob + h.corex;
-        a.b1frag = blob + h.b1frag;
-        a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
-        a.w1t = blob + h.w1t;
-        a.w1tx = blob + h.w1tx;
-        a.rfrag = nullptr;
-        a.colctr = nullptr;
-        a.phase = 0;
-        a.zmid = 0.0f;
-        if (restated) {
-            // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
-            if ((rc = g3_set_attributes())) return rc;
-            char *v7 = (char *)workspace + col_base_bytes(COL_BATCH);
-            unsigned short *g_lr = (unsigned short *)v7, *g_hr = g_lr + (size_t)COL_BATCH * 2 * D1 * 3;
-            float *r_lr = (float *)(v7 + col_v7_image_bytes(COL_BATCH)), *r_hr = r_lr + (size_t)COL_BATCH * 2 * D2;
-            float *zero_bias = r_hr + (size_t)COL_BATCH * 3 * D2;
-            SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4 + 256, st));   // + the column counter behind it
-            a.colctr = (unsigned *)(zero_bias + D2);
-            {
-                const float zw = (float)(mat[10] * (double)(rz / 2) + mat[11]);
-                a.zmid = (calib[11] + calib[10] * zw) * zmul / zdiv;
-            }
-            const long long part_lr = 2LL * ncp * D1, part_hr = 3LL * ncp * D1;
-            const dim3 pg((unsigned)(ncp / 64), D1 / 64);
-            // operand parts of this GEMM: the sweep's split (two f16 / three bf16 parts: fp32 grade) for the fp32-grade and the f16
-            // kernel; ONE f16 part for the bf16 kernel - 11 significant bits, 8x what bf16 gives the rest of the classifier, a third
-            // of the MFMA work, no measurable change of the bf16 sweep's error (SURS_R_PARTS=0: the split's parts there too)
-            static const int r_parts_env = getenv("SURS_R_PARTS") ? atoi(getenv("SURS_R_PARTS")) : 1;
-            const int rparts = (dtype == SURS_BF16 && r_parts_env == 1) ? 1 : parts;
-            if (rparts == 1)
-                hipLaunchKernelGGL(colsum_prepare_kernel<1>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
-                                   g_lr, part_lr, g_hr, part_hr);
-            else if (rparts == 2)
-                hipLaunchKernelGGL(colsum_prepare_kernel<2>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
-                                   g_lr, part_lr, g_hr, part_hr);
-            else
-                hipLaunchKernelGGL(colsum_prepare_kernel<3>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
-                                   g_lr, part_lr, g_hr, part_hr);
-            SURS_LAUNCH_CHECK();
-            for (int m = 0; m < 2; ++m) {
-                const int nvec = m ? 3 : 2;
-                const long long npm = (long long)nvec * ncp;
-                SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
-                const int nb256 = (int)(npm / 256);
-                float *R = m ? r_hr : r_lr;
-                if (rparts == 1)   // (the first part of the two-part weight image is f16(w))
-                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 1>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 1),
-                                       st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
-                                       (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
-                else if (rparts == 2)
-                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 2>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 2),
-                                       st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
-                                       (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
-                else
-                    hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256),
-                                       st, (const unsigned short *)(blob + h.wt3[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
-                                       (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
-                SURS_LAUNCH_CHECK();
-            }
-            {
-                const unsigned fb = (unsigned)ceil_div(nc * 32, 4);
-                if (dtype == SURS_BF16)   // (the fp32-grade kernel's fragments are f16 parts)
-                    hipLaunchKernelGGL(colsum_frag_kernel<SURS_BF16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
-                else
-                    hipLaunchKernelGGL(colsum_frag_kernel<SURS_F16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
-                SURS_LAUNCH_CHECK();
-            }
-            a.rfrag = v7;
-        }
-        a.vol_hr = vol_hr + (size_t)c0 * rz;
-        a.vol_lr = vol_lr + (size_t)c0 * rz;
-        a.ncols = (int)nc;
-        a.rz = rz;
-        a.z0 = mat[11];
-        a.dz = mat[10];
-        a.c22 = calib[10];
-        a.c23 = calib[11];
-        a.zmul = zmul;
-        a.zdiv = zdiv;
-        const unsigned grid = (unsigned)((nc < cus) ? nc : cus);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        bool prof;
-        a.kstat = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(g_prof.mu);
-            prof = g_prof.on;
-            if (prof && restated) {
-                int dev = 0;
-                SURS_HIP_CHECK(hipGetDevice(&dev));
-                unsigned long long *&ctr = g_prof.kstat[dev];
-                if (!ctr) {
-                    SURS_HIP_CHECK(hipMalloc((void **)&ctr, sizeof(unsigned long long)));
-                    SURS_HIP_CHECK(hipMemset(ctr, 0, sizeof(unsigned long long)));
-                }
-                a.kstat = ctr;
-                g_prof.tiles += 2.0 * (double)nc * (dtype == SURS_F32 ? (rz + 63) / 64 : (rz + 127) / 128);
-            }
-        }
-        if (prof) {
-            SURS_HIP_CHECK(hipEventCreate(&e0));
-            SURS_HIP_CHECK(hipEventCreate(&e1));
-            SURS_HIP_CHECK(hipEventRecord(e0, st));
-        }
-        if (dtype == SURS_F32) {
-            if (kver32 == 11) {
-                // two passes over the batch (lr, then hr on the lr occupancies just written): each pass streams ONE classifier's
-                // split weights (2.6 MiB), which an XCD's 4 MiB L2 holds; both together do not fit and 8 % of the stream came from
-                // HBM.  Only with whole 64-voxel tiles (the hr pass reads its tile's lr occupancies back from vol_lr, which has no
-                // room for the voxels beyond the column's end that the one-pass form computes and classifies on); same bits.
-                static const int passes_env = getenv("SURS_GRID_F32_PASSES") ? atoi(getenv("SURS_GRID_F32_PASSES")) : 2;
-                const bool two = passes_env == 2 && rz % 64 == 0;
-                for (int ph = two ? 1 : 0; ph <= (two ? 2 : 0); ++ph) {
-                    a.phase = ph;
-                    hipLaunchKernelGGL(grid_mlp_kernel_v11, dim3(grid), dim3(V11_THREADS), GRID11_LDS_BYTES, st, a);
-                }
-            }
-            else if (kver32 == 8)
-                hipLaunchKernelGGL(grid_mlp_kernel_v8, dim3(grid), dim3(256), GRID8_LDS_BYTES, st, a);
-            else
-                hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
-        } else if (kver == 10) {
-            if (dtype == SURS_BF16)
-                hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_BF16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
-            else
-                hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_F16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
-        } else if (kver == 7) {
-            if (dtype == SURS_BF16)
-                hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_BF16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
-            else
-                hipLaunchKernelGGL(grid_mlp_kernel_v7<SURS_F16>, dim3(grid), dim3(256), GRID7_LDS_BYTES, st, a);
-        } else {
-            if (dtype == SURS_BF16)
-                hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_BF16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
-            else
-                hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
-        }
-        SURS_LAUNCH_CHECK();
-#ifdef SURS_V3_TRACE
-        if ((dtype == SURS_F32 || kver == 3 || kver == 7 || kver == 10) && c0 == 0 && getenv("SURS_V3_TRACE")) {
-            unsigned long long t[64];
-            SURS_HIP_CHECK(hipStreamSynchronize(st));
-            SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
-            for (int m = 0; m < 2; ++m) {
-                fprintf(stderr, "v3 trace MLP %d:", m);
-                for (int i = 1; i < 10; ++i) fprintf(stderr, " %llu", t[16 * m + i] - t[16 * m + i - 1]);
-                fprintf(stderr, "  total %llu\n", t[16 * m + 9] - t[16 * m]);
-                if (restated) {
-                    fprintf(stderr, "   v7 layer 1 (since start): init issued %llu, list %llu, chunk 0: gathered %llu, residuals %llu, barrier %llu, mfma+barrier %llu; listed %llu\n",
-                            t[16 * m + 10] - t[16 * m], t[16 * m + 1] - t[16 * m], t[16 * m + 11] - t[16 * m], t[16 * m + 12] - t[16 * m],
-                            t[16 * m + 13] - t[16 * m], t[16 * m + 14] - t[16 * m], t[48 + m]);
-                }
-            }
-            fprintf(stderr, "v3 trace between MLPs: %llu\n", t[16] - t[9]);
-            const double cyc = (double)(t[42] - t[40]), us = (double)(t[43] - t[41]) / 100.0;
-            const int tile = dtype == SURS_F32 ? 64 : 128;
-            fprintf(stderr, "workgroup 0: %.0f cycles in %.1f us = %.3f GHz; %.0f cycles per %d-point tile\n", cyc, us,
-                    cyc / us * 1e-3, cyc / ((double)((nc + grid - 1) / grid) * ((rz + tile - 1) / tile)), tile);
-        }
-#endif
-        if (prof) {
-            SURS_HIP_CHECK(hipEventRecord(e1, st));
-            std::lock_guard<std::mutex> lock(g_prof.mu);
-            g_prof.ev.emplace_back(e0, e1);
-            g_prof.pts.push_back((double)nc * rz);
-        }
+        if ((rc = run_column_batch(cs, src, nc, rz, 1, nullptr, vol_hr + (size_t)c0 * rz, vol_lr + (size_t)c0 * rz, c0 == 0))) return rc;
     }
     return 0;
 }
@@ -1517,4 +1570,127 @@ extern "C" int surs_query_grid_indexed(const long long *idx, int n, int ry, int 
     if (rc) return rc;
     return run_points_fp32(st, src, n, feat_lr, hl, wl, feat_hr, hh, wh, (const char *)mlp_blob, h, w, pred_hr, pred_lr, nullptr,
                            nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One level of the octree sweep on the COLUMN kernel (lib/sdf.py:68-74 for an axis-aligned sweep).  The lattice points of stride
+// `reso` form columns along axis 2 that share their image position, exactly like the dense sweep's columns: the per-column
+// constants and the restated layer 1 apply unchanged, with the z items of a column reso voxels apart.  Work unit = one z tile of
+// 64 lattice points; a tile is evaluated iff it holds a dirty lattice point, and only the dirty points' values are kept (the
+// reference evaluates exactly the dirty lattice points: the other values of a tile are computed and dropped).
+//   select : one wave per lattice column: bit t of its mask = "tile t holds a dirty lattice point"; columns with a non-zero
+//            mask are appended to the list (any order: a column's values do not depend on its place in the list)
+//   sweep  : run_column_batch over the listed columns (mode 4 gather), tile masks, zstride = reso, compact outputs [column][nl]
+//   scatter: sdf[voxel] = value, dirty[voxel] = 0 for the dirty lattice points of the listed columns
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lattice_select_kernel(const unsigned char *__restrict__ dirty, int R, int reso, int nl,
+                                                             int *__restrict__ cols, unsigned *__restrict__ masks,
+                                                             unsigned long long *__restrict__ counters /* [0] columns, [1] dirty points */) {
+    const int lane = threadIdx.x & 63;
+    const long long lc = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // lattice column = li * nl + lj
+    if (lc >= (long long)nl * nl) return;
+    const int li = (int)(lc / nl), lj = (int)(lc - (long long)li * nl);
+    const long long col = (long long)(li * reso) * R + (long long)(lj * reso);   // full-resolution column index i * R + j
+    const unsigned char *row = dirty + col * R;
+    unsigned mask = 0, npts = 0;
+    for (int t = 0; t * 64 < nl; ++t) {
+        const int k = t * 64 + lane;
+        const bool hit = k < nl && row[(long long)k * reso] != 0;
+        const unsigned long long b = __ballot(hit);
+        if (b) mask |= 1u << t;
+        npts += (unsigned)__popcll(b);
+    }
+    if (lane == 0 && mask) {
+        const unsigned long long slot = atomicAdd(counters, 1ull);
+        cols[slot] = (int)col;
+        masks[slot] = mask;
+        atomicAdd(counters + 1, (unsigned long long)npts);
+    }
+}
+
+__global__ __launch_bounds__(256) void lattice_scatter_kernel(const int *__restrict__ cols, long long ncols, int R, int reso, int nl,
+                                                              const float *__restrict__ vh, const float *__restrict__ vl,
+                                                              double *__restrict__ sdf_hr, double *__restrict__ sdf_lr,
+                                                              unsigned char *__restrict__ dirty) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ncols * nl) return;
+    const long long c = t / nl;
+    const int k = (int)(t - c * nl);
+    const long long f = (long long)cols[c] * R + (long long)k * reso;
+    if (dirty[f]) {
+        sdf_hr[f] = (double)vh[t];
+        sdf_lr[f] = (double)vl[t];
+        dirty[f] = 0;
+    }
+}
+
+static size_t lattice_list_bytes(int R) { return align_up((size_t)R * R * 8 + 64, 256); }
+
+extern "C" size_t surs_octree_columns_workspace_bytes(int R) {
+    return col_ws_bytes(COL_BATCH) + lattice_list_bytes(R) + (size_t)2 * COL_BATCH * R * sizeof(float) + 256;
+}
+
+extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid,
+                                         const double *mat, const float *calib, float zmul, float zdiv, const float *feat_lr, int hl,
+                                         int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace,
+                                         size_t workspace_bytes, long long *counts, void *stream) {
+    SURS_REQUIRE(sdf_hr && sdf_lr && dirty && mat && calib && feat_lr && feat_hr && mlp_blob && workspace, "null argument");
+    SURS_REQUIRE(R > 0 && reso > 0 && R <= 32768, "bad grid");
+    const int nl = (R + reso - 1) / reso;
+    SURS_REQUIRE((nl + 63) / 64 <= 32, "more than 32 z tiles per lattice column");
+    SURS_REQUIRE(workspace_bytes >= surs_octree_columns_workspace_bytes(R), "workspace too small");
+    if (!sweep_has_columns(mat, calib))
+        return fail(SURS_E_UNSUPPORTED, "the column kernel needs an axis-aligned orthographic sweep: use surs_octree_select + "
+                                        "surs_query_grid_indexed + surs_octree_scatter");
+    hipStream_t st = as_stream(stream);
+    int rc = 0;
+    char *base = (char *)workspace + col_ws_bytes(COL_BATCH);
+    int *cols = (int *)base;
+    unsigned *masks = (unsigned *)(cols + (size_t)nl * nl);
+    unsigned long long *ctr = (unsigned long long *)(base + lattice_list_bytes(R) - 64);
+    float *vh = (float *)(base + lattice_list_bytes(R)), *vl = vh + (size_t)COL_BATCH * nl;
+    SURS_HIP_CHECK(hipMemsetAsync(ctr, 0, 16, st));
+    hipLaunchKernelGGL(lattice_select_kernel, dim3((unsigned)ceil_div((long long)nl * nl, 4)), dim3(256), 0, st, dirty, R, reso, nl, cols,
+                       masks, ctr);
+    SURS_LAUNCH_CHECK();
+    unsigned long long host[2] = {0, 0};
+    SURS_HIP_CHECK(hipMemcpyAsync(host, ctr, 16, hipMemcpyDeviceToHost, st));
+    SURS_HIP_CHECK(hipStreamSynchronize(st));
+    if (counts) {
+        counts[0] = (long long)host[1];   // dirty lattice points: what the reference evaluates at this level
+        counts[1] = (long long)host[0];   // lattice columns that hold them
+    }
+    const long long ncols = (long long)host[0];
+    if (ncols == 0) return 0;
+    ColumnSweep cs;
+    cs.st = st;
+    cs.blob = (const char *)mlp_blob;
+    cs.h = blob_layout((uint32_t)SURS_F32);
+    cs.dtype = SURS_F32;
+    cs.kver = SURS_DEFAULT_GRID_KERNEL;
+    cs.kver32 = 11;   // (the dense-layer-1 kernel v5 has no strided / masked form)
+    cs.restated = true;
+    cs.feat_lr = feat_lr; cs.hl = hl; cs.wl = wl;
+    cs.feat_hr = feat_hr; cs.hh = hh; cs.wh = wh;
+    cs.mat = mat; cs.calib = calib; cs.zmul = zmul; cs.zdiv = zdiv;
+    cs.workspace = workspace;
+    cs.cus = device_cus();
+    cs.kmid = kmid;
+    if ((rc = grid_set_attributes())) return rc;
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.mode = 4;
+    src.ry = R;
+    src.rz = R;
+    for (int i = 0; i < 12; ++i) src.mat[i] = mat[i];
+    fill_calib(src, calib, zmul, zdiv);
+    for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
+        const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
+        src.cols = cols + c0;
+        if ((rc = run_column_batch(cs, src, nc, nl, reso, masks + c0, vh, vl, false))) return rc;
+        hipLaunchKernelGGL(lattice_scatter_kernel, dim3((unsigned)ceil_div(nc * nl, 256)), dim3(256), 0, st, cols + c0, nc, R, reso, nl,
+                           (const float *)vh, (const float *)vl, sdf_hr, sdf_lr, dirty);
+        SURS_LAUNCH_CHECK();
+    }
+    return 0;
 }

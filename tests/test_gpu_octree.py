@@ -1,6 +1,8 @@
-"""GPU octree sweep (surs_octree_* + surs_query_grid_indexed through the C ABI).
+"""GPU octree sweep (surs_octree_* + surs_octree_level_columns / surs_query_grid_indexed through the C ABI).
  (1) the cell pass against the oracle's level-by-level trace on an analytic field: bit-exact float64 arrays and masks;
- (2) end to end on the network at R=128 (levels 2, 1) against the reference's own eval_grid_octree output."""
+ (2) end to end on the network at R=128 (levels 2, 1) against the reference's own eval_grid_octree output;
+ (3) the whole walk at BASELINE's 512^3 (levels 8, 4, 2, 1) against the oracle's restatement of lib/sdf.py:55-120 driven by the
+     product's own evaluator: the same lattice points evaluated at every level, the same float64 volumes, bit for bit."""
 import ctypes as C
 import os
 
@@ -78,3 +80,53 @@ def test_octree_reconstruction_vs_reference(golden_dir):
     out = mesh_util.reconstruction(opt, net, dev, calib, 128, b_min, b_max, use_octree=True)
     assert abs(len(out[0]) - g["n_verts"][0]) <= 0.02 * g["n_verts"][0]
     assert abs(len(out[4]) - g["n_verts"][1]) <= 0.02 * g["n_verts"][1]
+
+
+def _walk_inputs(field, dev):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import precision_report as pr
+    if field == "body":
+        sd, Fl, Fh = pr.body_inputs(dev)
+        return sd, Fl, Fh, None
+    return pr.noise_inputs(dev, H=64 if field == "noise64" else 512)
+
+
+@pytest.mark.parametrize("field,R,columns", [("body", 512, True), ("body", 512, False), ("noise64", 128, True), ("noise", 256, True),
+                                             ("noise64", 74, True)])
+def test_octree_walk_equals_oracle_walk_bit_for_bit(field, R, columns):
+    """The reference's octree walk (lib/sdf.py:55-120: evaluate the dirty lattice points of a level, fill the blocks whose corner
+    values span less than --threshold, halve the stride) restated in numpy by the oracle and DRIVEN BY THE PRODUCT'S EVALUATOR
+    (native.octree_level_values: the column kernel of the level / the per-point layer kernels) against the device walk:
+    per level the same number of evaluated lattice points, at the end the same float64 arrays (evaluated values, block fills and
+    the zeros the shared-dirty artefact leaves), bit for bit.  R = 512 is BASELINE's grid (levels 8, 4, 2, 1); R = 74: ragged
+    lattices (74 = 2 * 37: the last cells and tiles are partial)."""
+    import oracle
+    from surs_amd import native
+    dev = native.require_gpu()
+    sd, Fl, Fh, keep = _walk_inputs(field, dev)
+    blob, _ = native.pack_mlp({k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items() if k.startswith("mlp_")},
+                              "fp32", dev)
+    ws = native.Workspace(dev)
+    mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
+    cal = common.CALIB.reshape(-1)[:12]
+    thr, init = 0.05, (64 if R >= 128 else 37)
+    stats = []
+    vh, vl = native.octree_volumes(R, mat, cal, 512, 200.0, Fl, Fh, blob, ws, thr, init, columns=columns, stats=stats)
+    got_hr, got_lr = vh.cpu().numpy(), vl.cpu().numpy()
+    del vh, vl
+    levels = []
+
+    def index_func(reso, ii, jj, kk):
+        idx = torch.from_numpy((ii.astype(np.int64) * R + jj) * R + kk).to(dev)
+        a, b = native.octree_level_values(R, reso, idx, mat, cal, 512, 200.0, Fl, Fh, blob, ws, columns=columns)
+        levels.append((reso, len(ii)))
+        return a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+
+    o_hr, o_lr = oracle.eval_grid_octree(R, [-0.5] * 3, [0.5] * 3, None, thr, init, index_func=index_func)
+    print(field, R, "columns" if columns else "points", "evaluated per level:", levels, "of", R ** 3,
+          "| zero voxels hr %.4f lr %.4f" % ((o_hr == 0).mean(), (o_lr == 0).mean()))
+    assert [(r, n) for r, n, _ in stats] == levels
+    assert len(levels) >= 2 and sum(n for _, n in levels) < R ** 3
+    assert np.array_equal(got_hr, o_hr)
+    assert np.array_equal(got_lr, o_lr)

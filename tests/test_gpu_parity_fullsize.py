@@ -1,0 +1,175 @@
+"""The full-size links of the fp32 parity chain ("next round" item 1), all at BASELINE's sizes:
+
+ (a) every voxel of the default fp32-grade sweep (column kernel v11, 512^3 = 134 217 728 voxels, full-size feature maps) against
+     the per-point layer kernels - the arithmetic of surs_query_points, which tests/test_gpu_query.py holds to the reference's
+     own outputs (query.npz, query_h512.npz) at 1e-4 - in logit space, on the bench's noise field and the smooth body field;
+ (b) the `gain60` stress field (layer 0's depth column x 60: logits of +-60, nearly every channel changes branch inside a tile):
+     v11, the dense-layer-1 kernel v5 and the point path against the ORACLE (oracle.query, the C restatement of
+     SuRSNet.py:131-187 held to the reference's goldens) on 65 536 sampled voxels;
+ (c) BASELINE configs[0] at its stated size: dense R = 128 on the 512 x 512 image against the reference's own run
+     (tests/golden/recon_r128_h512.npz, tools/gen_golden.py recon128; /root/reference/lib/mesh_util.py:8-49): both fields at
+     1e-4, the product's marching cubes on exactly the reference's hr volume -> the reference's mesh, bit for bit.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+R = 512
+
+
+def _logit(p):
+    p = p.double()
+    return torch.log(p / (1.0 - p))
+
+
+@pytest.mark.parametrize("field", ["noise", "body"])
+def test_whole_volume_fp32_sweep_vs_point_path(field):
+    """(a): max |d logit| < 1e-4 over every voxel whose fp32 occupancy resolves its logit to 1e-5 (|logit| < 5); the saturated
+    voxels as occupancies (an occupancy within 6e-8 of 0 or 1 says nothing about its logit at 1e-4).  'fp32x' = the layer
+    kernels of surs_query_points over the grid's points (three bf16 parts: fp32's range and 24 significant bits)."""
+    import precision_report as pr
+    from surs_amd import native
+    dev = native.require_gpu()
+    if field == "body":
+        sd, Fl, Fh = pr.body_inputs(dev)
+        keep = None
+    else:
+        sd, Fl, Fh, keep = pr.noise_inputs(dev)
+    col, t_col, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev)
+    ref, t_ref, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32x",), dev)
+    print(field, "sweep seconds: column kernel %.3f, layer kernels %.3f" % (t_col["fp32"], t_ref["fp32x"]))
+    for i, tag in enumerate(("hr", "lr")):
+        a, b = col["fp32"][i], ref["fp32x"][i]
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+        st = pr.field_stats(a, b, plim=0.0067)
+        print(field, tag, st)
+        assert st["max_abs_dlogit"] < 1e-4, (field, tag, st)
+        assert st["max_abs_docc"] < 2.5e-5, (field, tag, st)   # (d occ <= d logit / 4)
+        assert st["flipped_voxels"] <= 40, (field, tag, st)
+
+
+def test_gain60_field_against_the_oracle():
+    """(b): which of the fp32-grade evaluators holds 1e-4 against the oracle where logits reach +-60.  65 536 voxels: 64 seeded
+    runs of 1024 consecutive voxels (two whole columns each)."""
+    import oracle
+    import precision_report as pr
+    from surs_amd import native
+    dev = native.require_gpu()
+    sd, Fl, Fh, keep = pr.noise_inputs(dev)
+    sd = {k: (v.clone() if torch.is_tensor(v) else np.array(v, copy=True)) for k, v in sd.items()}
+    for m in ("mlp_lr.", "mlp_hr."):
+        sd[m + "conv0.weight"][:, 320] *= 60.0
+    sd_np = {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+    v11, _, ws = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev)
+    v5, _, _ = pr.sweeps(sd, Fl, Fh, R, ("fp32",), dev, kernel=5)
+    blob, _ = native.pack_mlp({k: v for k, v in sd_np.items() if k.startswith("mlp_")}, "fp32", dev)
+    rng = np.random.RandomState(60)
+    starts = (rng.randint(0, R * R // 2, 64).astype(np.int64) * 2) * R
+    n = 1024
+    fl = np.ascontiguousarray(Fl.buf.view(Fl.h, Fl.w, Fl.c).permute(2, 0, 1).cpu().numpy())
+    fh = np.ascontiguousarray(Fh.buf.view(Fh.h, Fh.w, Fh.c).permute(2, 0, 1).cpu().numpy())
+    cal = common.CALIB.reshape(-1)[:12]
+    worst = {}
+    for s0 in starts:
+        s0 = int(s0)
+        pts = oracle.grid_points(R, [-0.5] * 3, [0.5] * 3, s0, s0 + n)
+        o_hr, o_lr, o_lhr, o_llr = oracle.query(sd_np, pts, common.CALIB, fl, fh, 1024, 200.0, want_logits=True)
+        p_hr, p_lr, p_lhr, p_llr = [t.cpu().numpy() for t in native.query_points(torch.from_numpy(pts).to(dev), cal, 512, 200.0, Fl, Fh,
+                                                                                 blob, ws, want_logits=True)]
+        cands = {"points": (p_hr, p_lr, p_lhr, p_llr)}
+        for name, vols in (("v11", v11["fp32"]), ("v5", v5["fp32"])):
+            a = vols[0].view(-1)[s0:s0 + n]
+            b = vols[1].view(-1)[s0:s0 + n]
+            cands[name] = (a.cpu().numpy(), b.cpu().numpy(), _logit(a).cpu().numpy(), _logit(b).cpu().numpy())
+        for name, (hr, lr, lhr, llr) in cands.items():
+            w = worst.setdefault(name, {"docc": 0.0, "dlogit": 0.0, "rel": 0.0, "maxlogit": 0.0})
+            w["docc"] = max(w["docc"], float(np.abs(hr - o_hr).max()), float(np.abs(lr - o_lr).max()))
+            for got, want, occ in ((lhr, o_lhr, o_hr), (llr, o_llr, o_lr)):
+                # logits recovered from fp32 occupancies are only meaningful where the occupancy resolves them (|logit| < 5);
+                # the point path returns its logits directly and is compared everywhere
+                ok = np.isfinite(got) & ((name == "points") | ((occ > 0.0067) & (occ < 1 - 0.0067)))
+                if ok.any():
+                    d = np.abs(got[ok].astype(np.float64) - want[ok])
+                    w["dlogit"] = max(w["dlogit"], float(d.max()))
+                    w["rel"] = max(w["rel"], float((d / np.maximum(1.0, np.abs(want[ok]))).max()))
+                w["maxlogit"] = max(w["maxlogit"], float(np.abs(want).max()))
+    print("gain60 vs oracle:", worst)
+    dump = os.environ.get("SURS_FULLVOLUME_JSON")
+    if dump:
+        import json
+        allf = json.load(open(dump)) if os.path.exists(dump) else {}
+        allf["gain60_vs_oracle"] = worst
+        json.dump(allf, open(dump, "w"), indent=1)
+    # occupancies: the north star's quantity after the sigmoid - every evaluator within 1e-4 of the oracle
+    for name, w in worst.items():
+        assert w["docc"] < 1e-4, (name, w)
+    # logits: 1e-4 absolute where |logit| < 5 for the column kernels; the point path's own logits (up to +-60) relative to their
+    # magnitude - fp32 has 24 bits, and an absolute 1e-4 on a logit of 60 is 1.7e-6 relative, inside one ulp of its summands
+    assert worst["v11"]["dlogit"] < 1e-4 and worst["v5"]["dlogit"] < 1e-4, worst
+    assert worst["points"]["rel"] < 1e-4, worst
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_configs0_dense_r128_h512_vs_reference(golden_dir):
+    """(c): BASELINE configs[0]'s workload at its size against the reference's own run of it."""
+    from surs_amd import mesh_util, model, native, weights
+    g = np.load(os.path.join(golden_dir, "recon_r128_h512.npz"))
+    dev = torch.device("cuda:0")
+    opt = common.opt()
+    net = model.SuRSNet(opt).to(device=dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    _, f_lr, f_hr = net.super_res(torch.from_numpy(weights.synthetic_image(512, seed=1)).to(dev))
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    calib = torch.from_numpy(common.CALIB[None]).to(dev)
+    b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
+    Rr = 128
+    # the fields: whole hr volume, every second voxel of the lr volume
+    vh, vl, mat = mesh_util.eval_volumes(opt, net, calib, Rr, b_min, b_max)
+    hr, lr = vh.cpu().numpy(), vl.cpu().numpy()
+    e_hr, e_lr = float(np.abs(hr - g["sdf_hr"]).max()), float(np.abs(lr[::2, ::2, ::2] - g["sdf_lr_sub"]).max())
+    print("configs[0] R=128 H=512: max |d occupancy| hr %.2e lr %.2e" % (e_hr, e_lr))
+    assert e_hr < 1e-4 and e_lr < 1e-4
+    assert abs(float(lr.astype(np.float64).mean()) - float(g["sdf_lr_mean"])) < 1e-5
+    # marching cubes on exactly the reference's hr volume: the reference's mesh, bit for bit (vertices in world space, float64)
+    ws = net._workspace()
+    ref_vol = torch.from_numpy(g["sdf_hr"]).to(dev)
+    v, f, _, _ = native.marching_cubes_lewiner(ref_vol, 0.5, ws, want_normals=False)
+    vw = native.transform_points(v, mat[:3].reshape(-1)).cpu().numpy()
+    f = f.cpu().numpy()
+    assert (len(vw), len(f)) == (int(g["n_verts"][0]), int(g["n_faces"][0]))
+    assert _sha(f.astype(np.int32)) == str(g["faces_hr_sha256"])
+    assert _sha(vw.astype(np.float64)) == str(g["verts_hr_sha256"])
+    assert np.array_equal(vw[::16], g["verts_hr_sub"])
+    # ... and the same bytes from the OBJ writer
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        mesh_util.save_obj_mesh(os.path.join(d, "m.obj"), vw, f)
+        assert hashlib.sha256(open(os.path.join(d, "m.obj"), "rb").read()).hexdigest() == str(g["obj_hr_sha256"])
+    # the product end to end (its own fp32 fields): mesh sizes within 0.5 % of the reference's, every sampled reference vertex
+    # has a product vertex within 0.02 voxel
+    out = mesh_util.reconstruction(opt, net, dev, calib, Rr, b_min, b_max, use_octree=False, want_normals=False)
+    for k, (vv, ff) in enumerate(((out[0], out[1]), (out[4], out[5]))):
+        assert abs(len(vv) - int(g["n_verts"][k])) <= 0.005 * int(g["n_verts"][k]), (k, len(vv), int(g["n_verts"][k]))
+        assert abs(len(ff) - int(g["n_faces"][k])) <= 0.005 * int(g["n_faces"][k])
+        sub = g["verts_hr_sub" if k == 0 else "verts_lr_sub"]
+        import precision_report as pr
+        a = torch.from_numpy(((sub + 0.5) * Rr).astype(np.float32)).to(dev)       # world -> index coordinates
+        b = torch.from_numpy(((np.asarray(vv) + 0.5) * Rr).astype(np.float32)).to(dev)
+        d = pr.nearest_vertex_distance(a, b, Rr)
+        assert bool(torch.isfinite(d).all()) and float(d.max()) < 0.02, (k, float(d.max()))

@@ -1,5 +1,5 @@
 """Acceptance of the reduced-precision sweeps (BASELINE configs[2] bf16, configs[4] fp16) at FULL size: 512^3 grid,
-full-size feature maps (256^2 x 256 and 1024^2 x 64), against the fp32-grade sweep (column kernel v8, which the other
+full-size feature maps (256^2 x 256 and 1024^2 x 64), against the fp32-grade sweep (column kernel v11, which the other
 GPU tests hold to the reference's goldens at 1e-4) - in logit space, as a count of voxels on the other side of the 0.5
 level, and on the extracted meshes (vertex / face counts, symmetric nearest-vertex distance in voxel units).  Two fields:
 the bench's noise-like field and a smooth closed body-sized blob (tools/precision_report.py, SURVEY.md section 7 "parity

@@ -1,4 +1,4 @@
-"""The identity behind column kernels v7 / v8, checked in float64 numpy on the oracle's inputs - no GPU,
+"""The identity behind the restated column kernels v10 / v11, checked in float64 numpy on the oracle's inputs - no GPU,
 no product code: along a grid column the layer-0 pre-activation of every channel is affine in (z_feat, p_lr), so
 
     W1 LeakyReLU(x(k)) + b1  ==  b1 + RA + RB z_feat(k) + RC p_lr(k) + sum over LISTED channels of W1[:, c] res_c(k)

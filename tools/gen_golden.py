@@ -296,6 +296,57 @@ def gen_recon():
                             obj_hr_sha256=np.array(obj_sha))
 
 
+def gen_recon128():
+    """BASELINE configs[0] at its stated size: the reference's dense reconstruction (lib/mesh_util.py:8-49, lib/sdf.py:32-52) at
+    R = 128 on the 512 x 512 synthetic image (encoder included).  Fixture: the whole hr field (fp32, so that the product's
+    marching cubes can be run on exactly the reference's volume and held to the digests of the reference's mesh), every
+    second voxel of the lr field, mesh sizes, SHA-256 of the vertex / face arrays and of the reference writer's OBJ bytes."""
+    import hashlib
+    import tempfile
+    net, opt_ref, sd = make_net()
+    ns = rh.load_reference()
+    img = weights.synthetic_image(512, seed=1)
+    t = time.time()
+    with torch.no_grad(), rh.quiet():
+        img_sr, f_lr, f_hr = net.super_res(torch.from_numpy(img.copy()))
+        net.filter_hr(f_hr)
+        net.filter_lr(f_lr)
+    print("encoder H=512: %.1fs" % (time.time() - t))
+    calib = torch.from_numpy(CALIB[None].copy())
+    b_min, b_max = np.array([-0.5, -0.5, -0.5]), np.array([0.5, 0.5, 0.5])
+    R = 128
+    cap = {}
+    orig = ns.sdf.eval_grid
+
+    def spy(coords, eval_func, num_samples):
+        a, b = orig(coords, eval_func, num_samples=num_samples)
+        cap["hr"], cap["lr"] = a, b
+        return a, b
+
+    ns.mesh_util.eval_grid = spy
+    t = time.time()
+    try:
+        with torch.no_grad(), rh.quiet():
+            vh, fh, _, _, vl, fl_, _, _ = ns.mesh_util.reconstruction(
+                opt_ref, net, torch.device("cpu"), calib, R, b_min, b_max, use_octree=False, num_samples=50000)
+    finally:
+        ns.mesh_util.eval_grid = orig
+    print("recon R=128 H=512 %.1fs: hr %s %s | lr %s %s; sdf_hr range %.4f..%.4f" %
+          (time.time() - t, vh.shape, fh.shape, vl.shape, fl_.shape, cap["hr"].min(), cap["hr"].max()))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    with tempfile.TemporaryDirectory() as d:
+        ns.mesh_util.save_obj_mesh(os.path.join(d, "m.obj"), vh, fh)
+        obj_sha = hashlib.sha256(open(os.path.join(d, "m.obj"), "rb").read()).hexdigest()
+    hr, lr = cap["hr"].astype(np.float32), cap["lr"].astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "recon_r128_h512.npz"), sdf_hr=hr, sdf_lr_sub=lr[::2, ::2, ::2],
+                        sdf_lr_mean=np.array(lr.astype(np.float64).mean()), sdf_lr_sha256=np.array(sha(lr)),
+                        n_verts=np.array([len(vh), len(vl)]), n_faces=np.array([len(fh), len(fl_)]),
+                        verts_hr_sha256=np.array(sha(vh.astype(np.float64))), faces_hr_sha256=np.array(sha(fh.astype(np.int32))),
+                        verts_lr_sha256=np.array(sha(vl.astype(np.float64))), faces_lr_sha256=np.array(sha(fl_.astype(np.int32))),
+                        verts_hr_sub=vh[::16].astype(np.float64), verts_lr_sub=vl[::16].astype(np.float64),
+                        obj_hr_sha256=np.array(obj_sha))
+
+
 def gen_octree():
     """eval_grid_octree of the reference: (i) an analytic field (exact restatement check of the cell logic),
     (ii) the network at R=128 (the default init_resolution=64 -> levels 2, 1)."""

@@ -1,7 +1,7 @@
 """Compares a column-kernel version (SURS_GRID_KERNEL of this process) against volumes saved by another run.
 
     SURS_GRID_KERNEL=3 python tools/gpu_grid_cmp.py save /tmp/v3.npz
-    SURS_GRID_KERNEL=7 python tools/gpu_grid_cmp.py cmp  /tmp/v3.npz
+    SURS_GRID_KERNEL=10 python tools/gpu_grid_cmp.py cmp  /tmp/v3.npz
 """
 import os, sys
 import numpy as np

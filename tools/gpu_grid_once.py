@@ -29,6 +29,6 @@ for _ in range(3):
     native.query_grid(0, R, R, R, mat, common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, b, dt, ws, vh, vl)
 torch.cuda.synchronize()
 tiles, ks = C.c_double(0), C.c_double(0)
-L.surs_profile_read_ksteps(C.byref(tiles), C.byref(ks))   # column kernels v7 / v8: residual k-steps of layer 1 (data dependent)
+L.surs_profile_read_ksteps(C.byref(tiles), C.byref(ks))   # column kernels v10 / v11: residual k-steps of layer 1 (data dependent)
 L.surs_profile_enable(0)
 print("done tile_mlps_per_sweep %.0f residual_ksteps_per_sweep %.0f" % (tiles.value / 3, ks.value / 3))

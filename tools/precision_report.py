@@ -1,5 +1,5 @@
 """What the reduced-precision column kernels (bf16 / fp16) do to the RESULT of a dense reconstruction, measured against the
-fp32-grade sweep (column kernel v8, itself held to the reference's goldens at 1e-4) on the same features and weights:
+fp32-grade sweep (column kernel v11, itself held to the reference's goldens at 1e-4) on the same features and weights:
 
   * field:  max / mean |d logit|, max |d occupancy|, number of voxels on the other side of the 0.5 level
   * mesh :  vertex / face counts and their deltas, and a symmetric nearest-vertex distance in voxel units between the two
@@ -136,7 +136,7 @@ def sweeps(sd, Fl, Fh, R, precisions, dev, zmul=512, zdiv=200.0, kernel=0):
 
 def report(sd, Fl, Fh, R, dev, precisions=("bf16", "fp16"), sample=1 << 20):
     vols, times, ws = sweeps(sd, Fl, Fh, R, ("fp32",) + tuple(precisions), dev)
-    rep = {"resolution": R, "reference": "fp32-grade column kernel (v8)", "sweep_s": times}
+    rep = {"resolution": R, "reference": "fp32-grade column kernel (v11)", "sweep_s": times}
     for prec in precisions:
         r = {}
         for i, tag in enumerate(("hr", "lr")):

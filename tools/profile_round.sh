@@ -3,7 +3,7 @@
 #   1. the bench line itself (un-profiled),
 #   2. rocprofv3 --kernel-trace --stats of the same bench.py command without the CPU leg / extras (per-kernel time),
 #   3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, L2 hits, clock, MFMA busy cycles) of the column-kernel sweep at R=512,
-#      for the bf16 kernel (v7) and the fp32-grade kernel (v8), as the MI355X guide prescribes (one counter group per run).
+#      for the bf16 kernel (v10) and the fp32-grade kernel (v11), as the MI355X guide prescribes (one counter group per run).
 # Copy what is to be judged into profiles/ afterwards: tools/pmc_summarize.py rNN writes profiles/pmc_summary.json.
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
