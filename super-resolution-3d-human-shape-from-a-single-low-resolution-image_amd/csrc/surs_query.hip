@@ -599,7 +599,8 @@ struct GridArgs {
     const char *b1frag;    // layer-1 biases as A fragments (kernel v3)
     const char *w1t;       // layer-1 weights channel-major (kernel v7)
     const char *w1tx;      // the same as two f16 parts (kernel v8)
-    const char *rfrag;     // per column and MLP: the affine part of layer 1 as A fragments [16 row tiles][64][8] (kernel v7)
+    const float *rvec_lr, *rvec_hr;   // restated kernels: R = W1 (g . [a0 | w0z | w0p]) of the batch, fp32 [column][2 | 3 vectors][512 rows]
+    long long rld_lr, rld_hr;         // (unused)
     float zmid;            // zf at mid column: where kernel v7's per-column LeakyReLU branch g_c is taken
     unsigned *colctr;      // kernels v7 / v8: next column to hand out (zeroed before the launch); kernel v11: one counter per pass
     int phase;             // kernel v11: 0 = both classifiers per tile, 1 = the lr classifier only, 2 = the hr classifier on vol_lr
@@ -679,32 +680,6 @@ __global__ __launch_bounds__(256) void colsum_prepare_kernel(const float *__rest
             *reinterpret_cast<u32x4 *>(dst + q * part + 8) = w1;
         }
     }
-}
-
-// Step 3 (after the GEMMs R = W1 G): the per-column A operand of the affine k-step, [column][MLP][16 row tiles][64 lanes][8]:
-// lane (r, h) of row tile T holds, for row 32 T + r, the three 16-bit parts a, b, c of (b1 + RA, RB, RC) in the slot order
-// h = 0: a0 a1 a2 b0 b0 b1 b0 b1,  h = 1: b2 c0 c0 c1 c0 c1 c2 0  (the B operand pairs them with 1 1 1 z0 z1 z0 z2 z1 |
-// z0 p0 p1 p0 p2 p1 p0 0: all products of parts down to 2^-24 relative).
-template <int DT>
-__global__ __launch_bounds__(256) void colsum_frag_kernel(const float *__restrict__ r_lr, const float *__restrict__ r_hr,
-                                                          const float *__restrict__ zvec, int ncols, char *__restrict__ frag) {
-    typedef typename HalfT<DT>::elem elem;
-    typedef typename HalfT<DT>::vec8 vec8;
-    const int lane = threadIdx.x & 63;
-    const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // fragment index: (col * 2 + m) * 16 + T
-    if (f >= (long long)ncols * 32) return;
-    const int T = (int)(f & 15), m = (int)((f >> 4) & 1);
-    const long long col = f >> 5;
-    const int r = 32 * T + (lane & 31);
-    const float *base = m ? r_hr + col * (3 * D2) : r_lr + col * (2 * D2);
-    const elem zero = (elem)0.0f;
-    elem a[3], b[3], c[3] = {zero, zero, zero};
-    split3_elem<DT>(base[r] + zvec[(m ? ZV_B1_HR : ZV_B1_LR) + r], a);
-    split3_elem<DT>(base[D2 + r], b);
-    if (m) split3_elem<DT>(base[2 * D2 + r], c);
-    const vec8 lo = {a[0], a[1], a[2], b[0], b[0], b[1], b[0], b[1]};
-    const vec8 hi = {b[2], c[0], c[0], c[1], c[0], c[1], c[2], zero};
-    *reinterpret_cast<vec8 *>(frag + f * 1024 + lane * 16) = (lane >> 5) ? hi : lo;
 }
 
 }  // namespace surs
@@ -1017,12 +992,8 @@ static size_t col_base_bytes(long long ncb) {
     // F rows 0..335 for the column gather + CC + mask
     return (size_t)ncb * (C0PAD + CC_PAD + 1) * sizeof(float) + (size_t)ncb * C0PAD * 6 + 4096;   // + split image of F
 }
-// column kernel v7: split images of the five g-scaled vectors per column (up to three parts), the five R vectors, a zero bias
-// (the A-fragment image of the R vectors, 32 KiB per column, then takes the place of the split images)
-static size_t col_v7_image_bytes(long long ncb) {
-    const size_t g = (size_t)ncb * 5 * D1 * 6, f = (size_t)ncb * 32768;
-    return g > f ? g : f;
-}
+// restated column kernels: split images of the five g-scaled vectors per column (up to three parts), the five R vectors, a zero bias
+static size_t col_v7_image_bytes(long long ncb) { return (size_t)ncb * 5 * D1 * 6; }
 static size_t col_v7_bytes(long long ncb) { return col_v7_image_bytes(ncb) + (size_t)ncb * 5 * D2 * 4 + D2 * 4 + 256; }
 static size_t col_ws_bytes(long long ncb) { return col_base_bytes(ncb) + col_v7_bytes(ncb); }
 
@@ -1258,7 +1229,8 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     a.b1_inv_scale = 1.0f / (dtype == SURS_F16 ? B1FRAG_SCALE_F16 : B1FRAG_SCALE_BF16);
     a.w1t = blob + h.w1t;
     a.w1tx = blob + h.w1tx;
-    a.rfrag = nullptr;
+    a.rvec_lr = a.rvec_hr = nullptr;
+    a.rld_lr = a.rld_hr = 0;
     a.colctr = nullptr;
     a.phase = 0;
     a.zmid = 0.0f;
@@ -1300,6 +1272,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
             const int nb256 = (int)(npm / 256);
             float *R = m ? r_hr : r_lr;
+            // output R[column][vector][512] (transposed; the kernel swaps the MFMA operands so that its stores run along the rows)
             if (rparts == 1)   // (the first part of the two-part weight image is f16(w))
                 hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32_T, 1>), dim3(gemm_grid(D2 / 256, nb256)), dim3(512), g3_lds_bytes(256, 1),
                                    st, (const unsigned short *)(blob + h.wt2[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
@@ -1314,15 +1287,9 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
                                    (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
             SURS_LAUNCH_CHECK();
         }
-        {
-            const unsigned fb = (unsigned)ceil_div(nc * 32, 4);
-            if (dtype == SURS_BF16)   // (the fp32-grade kernel's fragments are f16 parts)
-                hipLaunchKernelGGL(colsum_frag_kernel<SURS_BF16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
-            else
-                hipLaunchKernelGGL(colsum_frag_kernel<SURS_F16>, dim3(fb), dim3(256), 0, st, r_lr, r_hr, (const float *)(blob + h.zvec), (int)nc, v7);
-            SURS_LAUNCH_CHECK();
-        }
-        a.rfrag = v7;
+        a.rvec_lr = r_lr;
+        a.rvec_hr = r_hr;
+        a.rld_lr = a.rld_hr = 0;
     }
     a.vol_hr = vol_hr;
     a.vol_lr = vol_lr;
