@@ -225,13 +225,13 @@ int surs_octree_select(const unsigned char *dirty, int R, int reso, long long *i
                        void *stream);
 /* select + evaluate + scatter of one level in ONE call, on the sweep's fp32-grade COLUMN kernel (axis-aligned orthographic sweeps:
  * the lattice points of stride `reso` form columns along axis 2 that share their image position, so the per-column constants
- * and the restated layer 1 of surs_query_grid apply with the z items of a column `reso` voxels apart).  A z tile of 64 lattice
- * points is evaluated iff it holds a dirty lattice point; only the dirty points are written (sdf = value, dirty = 0), i.e. exactly
- * the points lib/sdf.py:68-74 evaluates.  A lattice point's value is a function of the point and of `reso` alone (its tile is
- * evaluated whole), not of which other points are dirty.  kmid: axis-2 voxel index where the kernel takes its per-column
- * LeakyReLU branches (R / 2; any value gives the same function up to rounding).  counts (HOST, nullable): [0] dirty lattice
- * points evaluated, [1] lattice columns that held them.  Synchronises the stream once.  SURS_E_UNSUPPORTED for a general
- * calibration: use the three calls above and below. */
+ * and the restated layer 1 of surs_query_grid apply).  A column's work items are its dirty lattice points in ascending order, 64
+ * per tile; exactly the points lib/sdf.py:68-74 evaluates are evaluated and written (sdf = value, dirty = 0).  A point's value
+ * depends on the point, on `reso` and - in the last bits, through the tile it shares - on which other points of its column are
+ * dirty: the same dirty set gives the same bits.  kmid: axis-2 voxel index where the kernel takes its per-column LeakyReLU
+ * branches (R / 2; any value gives the same function up to rounding).  counts (HOST, nullable, 3 values): dirty lattice points
+ * evaluated, lattice columns that held them, 64-point tiles run.  Synchronises the stream once.  SURS_E_UNSUPPORTED for a
+ * general calibration: use the three calls above and below. */
 int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid, const double *mat,
                               const float *calib, float zmul, float zdiv, const float *feat_lr, int hl, int wl,
                               const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,

@@ -608,10 +608,12 @@ struct GridArgs {
     float b1_inv_scale;    // what B_ones holds: 1 / B1FRAG_SCALE of the blob's dtype
     float *vol_hr, *vol_lr;  // [ncols][rz]
     int ncols, rz;
-    // lattice sweeps (the octree levels, surs_octree_level_columns): a column's rz items are the voxels k * zstride, and only the
-    // z tiles whose bit is set in tilemask[column] are evaluated (null: all of them).  Dense sweeps: zstride 1, tilemask null.
+    // lattice sweeps (the octree levels, surs_octree_level_columns): column c has kcount[c] <= rz items, the voxels
+    // klist[c * rz + e] * zstride (ascending), e < kcount[c]; outputs at vol[c * rz + e].  Dense sweeps: zstride 1, both null
+    // (item e = voxel e, rz items).
     int zstride;
-    const unsigned *tilemask;
+    const int *kcount;
+    const unsigned short *klist;
     double z0, dz;  // world z of voxel k = (float)(dz*k + z0)
     float c22, c23;  // Z(k) = c23 + c22 * z(k)   (calib[2][0] = calib[2][1] = 0 in column mode)
     float zmul, zdiv;
@@ -1201,9 +1203,9 @@ static int device_cus() {
 
 // One batch of nc <= COL_BATCH columns described by src (mode 2: consecutive columns from src.base; mode 4: listed columns):
 // gather + column constants, the restated kernels' per-column affine part, then the column kernel over `items` z items per column
-// (voxels k * zstride; only the z tiles flagged in tilemask[column] when that is given).  vol_*: [nc][items].
+// (dense: the voxels 0 .. items - 1; lattice sweeps: the kcount[column] listed voxels klist[column][.] * zstride).  vol_*: [nc][items].
 static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long long nc, int items, int zstride,
-                            const unsigned *tilemask, float *vol_hr, float *vol_lr, bool trace_this) {
+                            const int *kcount, const unsigned short *klist, float *vol_hr, float *vol_lr, bool trace_this) {
     hipStream_t st = cs.st;
     const char *blob = cs.blob;
     const MlpBlobHeader &h = cs.h;
@@ -1235,7 +1237,8 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     a.phase = 0;
     a.zmid = 0.0f;
     a.zstride = zstride;
-    a.tilemask = tilemask;
+    a.kcount = kcount;
+    a.klist = klist;
     if (restated) {
         // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
         if ((rc = g3_set_attributes())) return rc;
@@ -1307,7 +1310,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     a.kstat = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_prof.mu);
-        prof = g_prof.on && !tilemask;   // (the bench's per-launch figures are those of dense sweeps)
+        prof = g_prof.on && !kcount;   // (the bench's per-launch figures are those of dense sweeps)
         if (prof && restated) {
             int dev = 0;
             SURS_HIP_CHECK(hipGetDevice(&dev));
@@ -1452,7 +1455,7 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
         const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
         src.base = (long long)i0 * ry + c0;
-        if ((rc = run_column_batch(cs, src, nc, rz, 1, nullptr, vol_hr + (size_t)c0 * rz, vol_lr + (size_t)c0 * rz, c0 == 0))) return rc;
+        if ((rc = run_column_batch(cs, src, nc, rz, 1, nullptr, nullptr, vol_hr + (size_t)c0 * rz, vol_lr + (size_t)c0 * rz, c0 == 0))) return rc;
     }
     return 0;
 }
@@ -1542,59 +1545,76 @@ extern "C" int surs_query_grid_indexed(const long long *idx, int n, int ry, int 
 // ------------------------------------------------------------------------------------------------
 // One level of the octree sweep on the COLUMN kernel (lib/sdf.py:68-74 for an axis-aligned sweep).  The lattice points of stride
 // `reso` form columns along axis 2 that share their image position, exactly like the dense sweep's columns: the per-column
-// constants and the restated layer 1 apply unchanged, with the z items of a column reso voxels apart.  Work unit = one z tile of
-// 64 lattice points; a tile is evaluated iff it holds a dirty lattice point, and only the dirty points' values are kept (the
-// reference evaluates exactly the dirty lattice points: the other values of a tile are computed and dropped).
-//   select : one wave per lattice column: bit t of its mask = "tile t holds a dirty lattice point"; columns with a non-zero
-//            mask are appended to the list (any order: a column's values do not depend on its place in the list)
-//   sweep  : run_column_batch over the listed columns (mode 4 gather), tile masks, zstride = reso, compact outputs [column][nl]
-//   scatter: sdf[voxel] = value, dirty[voxel] = 0 for the dirty lattice points of the listed columns
+// constants and the restated layer 1 apply unchanged.  A column's work items are its DIRTY lattice points, compacted in ascending
+// k (a surface crosses a column in a few short runs: whole z tiles would be a tenth full), 64 per tile; the reference evaluates
+// exactly these points (lib/sdf.py:68-73).
+//   select : one wave per lattice column counts its dirty lattice points; columns with any are appended to the list (any order:
+//            a column's values do not depend on its place in the list)
+//   klist  : per batch of listed columns, the lattice indices of their dirty points
+//   sweep  : run_column_batch over the listed columns (mode 4 gather), items = klist, zstride = reso, compact outputs [column][nl]
+//   scatter: sdf[voxel] = value, dirty[voxel] = 0 for the listed points
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lattice_select_kernel(const unsigned char *__restrict__ dirty, int R, int reso, int nl,
-                                                             int *__restrict__ cols, unsigned *__restrict__ masks,
-                                                             unsigned long long *__restrict__ counters /* [0] columns, [1] dirty points */) {
+                                                             int *__restrict__ cols, int *__restrict__ counts,
+                                                             unsigned long long *__restrict__ counters /* [0] columns, [1] dirty points, [2] tiles */) {
     const int lane = threadIdx.x & 63;
     const long long lc = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // lattice column = li * nl + lj
     if (lc >= (long long)nl * nl) return;
     const int li = (int)(lc / nl), lj = (int)(lc - (long long)li * nl);
     const long long col = (long long)(li * reso) * R + (long long)(lj * reso);   // full-resolution column index i * R + j
     const unsigned char *row = dirty + col * R;
-    unsigned mask = 0, npts = 0;
+    unsigned npts = 0;
+    for (int t = 0; t * 64 < nl; ++t) {
+        const int k = t * 64 + lane;
+        npts += (unsigned)__popcll(__ballot(k < nl && row[(long long)k * reso] != 0));
+    }
+    if (lane == 0 && npts) {
+        const unsigned long long slot = atomicAdd(counters, 1ull);
+        cols[slot] = (int)col;
+        counts[slot] = (int)npts;
+        atomicAdd(counters + 1, (unsigned long long)npts);
+        atomicAdd(counters + 2, (unsigned long long)((npts + 63) / 64));
+    }
+}
+
+// the listed lattice points of a batch of listed columns, ascending: klist[c][e] = lattice index k of the e-th dirty point
+__global__ __launch_bounds__(256) void lattice_klist_kernel(const unsigned char *__restrict__ dirty, const int *__restrict__ cols, long long ncols,
+                                                            int R, int reso, int nl, unsigned short *__restrict__ klist) {
+    const int lane = threadIdx.x & 63;
+    const long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= ncols) return;
+    const unsigned char *row = dirty + (long long)cols[c] * R;
+    unsigned short *out = klist + c * nl;
+    int base = 0;
     for (int t = 0; t * 64 < nl; ++t) {
         const int k = t * 64 + lane;
         const bool hit = k < nl && row[(long long)k * reso] != 0;
         const unsigned long long b = __ballot(hit);
-        if (b) mask |= 1u << t;
-        npts += (unsigned)__popcll(b);
-    }
-    if (lane == 0 && mask) {
-        const unsigned long long slot = atomicAdd(counters, 1ull);
-        cols[slot] = (int)col;
-        masks[slot] = mask;
-        atomicAdd(counters + 1, (unsigned long long)npts);
+        if (hit) out[base + __popcll(b & ((1ull << lane) - 1ull))] = (unsigned short)k;
+        base += __popcll(b);
     }
 }
 
-__global__ __launch_bounds__(256) void lattice_scatter_kernel(const int *__restrict__ cols, long long ncols, int R, int reso, int nl,
+__global__ __launch_bounds__(256) void lattice_scatter_kernel(const int *__restrict__ cols, const int *__restrict__ counts,
+                                                              const unsigned short *__restrict__ klist, long long ncols, int R, int reso, int nl,
                                                               const float *__restrict__ vh, const float *__restrict__ vl,
                                                               double *__restrict__ sdf_hr, double *__restrict__ sdf_lr,
                                                               unsigned char *__restrict__ dirty) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= ncols * nl) return;
     const long long c = t / nl;
-    const int k = (int)(t - c * nl);
-    const long long f = (long long)cols[c] * R + (long long)k * reso;
-    if (dirty[f]) {
-        sdf_hr[f] = (double)vh[t];
-        sdf_lr[f] = (double)vl[t];
-        dirty[f] = 0;
-    }
+    const int e = (int)(t - c * nl);
+    if (e >= counts[c]) return;
+    const long long f = (long long)cols[c] * R + (long long)klist[t] * reso;
+    sdf_hr[f] = (double)vh[t];
+    sdf_lr[f] = (double)vl[t];
+    dirty[f] = 0;
 }
 
 static size_t lattice_list_bytes(int R) { return align_up((size_t)R * R * 8 + 64, 256); }
 
 extern "C" size_t surs_octree_columns_workspace_bytes(int R) {
-    return col_ws_bytes(COL_BATCH) + lattice_list_bytes(R) + (size_t)2 * COL_BATCH * R * sizeof(float) + 256;
+    return col_ws_bytes(COL_BATCH) + lattice_list_bytes(R) + (size_t)COL_BATCH * R * (2 * sizeof(float) + sizeof(unsigned short)) + 512;
 }
 
 extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid,
@@ -1604,7 +1624,7 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
     SURS_REQUIRE(sdf_hr && sdf_lr && dirty && mat && calib && feat_lr && feat_hr && mlp_blob && workspace, "null argument");
     SURS_REQUIRE(R > 0 && reso > 0 && R <= 32768, "bad grid");
     const int nl = (R + reso - 1) / reso;
-    SURS_REQUIRE((nl + 63) / 64 <= 32, "more than 32 z tiles per lattice column");
+    SURS_REQUIRE(nl <= 65535, "lattice indices are 16-bit");
     SURS_REQUIRE(workspace_bytes >= surs_octree_columns_workspace_bytes(R), "workspace too small");
     if (!sweep_has_columns(mat, calib))
         return fail(SURS_E_UNSUPPORTED, "the column kernel needs an axis-aligned orthographic sweep: use surs_octree_select + "
@@ -1613,19 +1633,21 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
     int rc = 0;
     char *base = (char *)workspace + col_ws_bytes(COL_BATCH);
     int *cols = (int *)base;
-    unsigned *masks = (unsigned *)(cols + (size_t)nl * nl);
+    int *kcnt = cols + (size_t)nl * nl;
     unsigned long long *ctr = (unsigned long long *)(base + lattice_list_bytes(R) - 64);
     float *vh = (float *)(base + lattice_list_bytes(R)), *vl = vh + (size_t)COL_BATCH * nl;
-    SURS_HIP_CHECK(hipMemsetAsync(ctr, 0, 16, st));
+    unsigned short *klist = (unsigned short *)(vl + (size_t)COL_BATCH * nl);
+    SURS_HIP_CHECK(hipMemsetAsync(ctr, 0, 32, st));
     hipLaunchKernelGGL(lattice_select_kernel, dim3((unsigned)ceil_div((long long)nl * nl, 4)), dim3(256), 0, st, dirty, R, reso, nl, cols,
-                       masks, ctr);
+                       kcnt, ctr);
     SURS_LAUNCH_CHECK();
-    unsigned long long host[2] = {0, 0};
-    SURS_HIP_CHECK(hipMemcpyAsync(host, ctr, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long host[3] = {0, 0, 0};
+    SURS_HIP_CHECK(hipMemcpyAsync(host, ctr, 24, hipMemcpyDeviceToHost, st));
     SURS_HIP_CHECK(hipStreamSynchronize(st));
     if (counts) {
         counts[0] = (long long)host[1];   // dirty lattice points: what the reference evaluates at this level
         counts[1] = (long long)host[0];   // lattice columns that hold them
+        counts[2] = (long long)host[2];   // 64-point tiles the column kernel evaluates for them
     }
     const long long ncols = (long long)host[0];
     if (ncols == 0) return 0;
@@ -1654,9 +1676,13 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
     for (long long c0 = 0; c0 < ncols; c0 += COL_BATCH) {
         const long long nc = (ncols - c0 < COL_BATCH) ? ncols - c0 : COL_BATCH;
         src.cols = cols + c0;
-        if ((rc = run_column_batch(cs, src, nc, nl, reso, masks + c0, vh, vl, false))) return rc;
-        hipLaunchKernelGGL(lattice_scatter_kernel, dim3((unsigned)ceil_div(nc * nl, 256)), dim3(256), 0, st, cols + c0, nc, R, reso, nl,
-                           (const float *)vh, (const float *)vl, sdf_hr, sdf_lr, dirty);
+        hipLaunchKernelGGL(lattice_klist_kernel, dim3((unsigned)ceil_div(nc, 4)), dim3(256), 0, st, (const unsigned char *)dirty, (const int *)(cols + c0),
+                           nc, R, reso, nl, klist);
+        SURS_LAUNCH_CHECK();
+        if ((rc = run_column_batch(cs, src, nc, nl, reso, kcnt + c0, klist, vh, vl, false))) return rc;
+        hipLaunchKernelGGL(lattice_scatter_kernel, dim3((unsigned)ceil_div(nc * nl, 256)), dim3(256), 0, st, (const int *)(cols + c0),
+                           (const int *)(kcnt + c0), (const unsigned short *)klist, nc, R, reso, nl, (const float *)vh, (const float *)vl, sdf_hr,
+                           sdf_lr, dirty);
         SURS_LAUNCH_CHECK();
     }
     return 0;

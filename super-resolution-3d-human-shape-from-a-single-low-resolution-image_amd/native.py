@@ -680,12 +680,13 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
     """eval_grid_octree on the device: float64 volumes (sdf_hr, sdf_lr) [R,R,R] like the reference's arrays.
     Host code only walks the levels; selection, evaluation (fp32-grade kernels), scatter and the cell pass are kernels.
     Single view, axis-aligned sweep (gen_mesh's): every level runs on the sweep's COLUMN kernel (surs_octree_level_columns: the
-    lattice points of a level form columns of constant image position, evaluated in z tiles of 64 lattice points); general
+    lattice points of a level form columns of constant image position; a column's dirty points are evaluated 64 at a time); general
     calibrations, `columns=False` and native.wide_operands() (the retry after an f16 overflow: the column kernel carries f16
     parts) take the per-point layer kernels (surs_octree_select + surs_query_grid_indexed + surs_octree_scatter).
     evaluate(idx int64 device tensor [n]) -> (pred_hr, pred_lr) float32 [n] replaces the single-view evaluator
     (mesh_util passes the multi-view / perspective query there).
-    stats: a list that receives (reso, dirty lattice points evaluated, lattice columns or None) per level."""
+    stats: a list that receives (reso, dirty lattice points evaluated, lattice columns, 64-point tiles) per level (None, None on
+    the per-point path)."""
     dev = device if device is not None else blob.device
     n3 = R * R * R
     sdf_hr = torch.zeros(n3, dtype=torch.float64, device=dev)
@@ -701,7 +702,7 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
     while reso > 0:
         if use_cols:
             w = ws.get(lib().surs_octree_columns_workspace_bytes(R))
-            counts = (C.c_longlong * 2)(0, 0)
+            counts = (C.c_longlong * 3)(0, 0, 0)
             rc = lib().surs_octree_level_columns(_ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul),
                                                  float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
                                                  _ptr(blob), _ptr(w), w.numel(), counts, _stream())
@@ -710,7 +711,7 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
                 continue
             check(rc)
             if stats is not None:
-                stats.append((reso, int(counts[0]), int(counts[1])))
+                stats.append((reso, int(counts[0]), int(counts[1]), int(counts[2])))
         else:
             nl = (R + reso - 1) // reso
             cap = nl * nl * nl
@@ -734,7 +735,7 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
                                                     C.c_void_p(plr.data_ptr() + 4 * b0), _stream()))
             check(lib().surs_octree_scatter(_ptr(idx), n, _ptr(phr), _ptr(plr), _ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), _stream()))
             if stats is not None:
-                stats.append((reso, n, None))
+                stats.append((reso, n, None, None))
         if reso <= 1:
             break
         w = ws.get(lib().surs_octree_workspace_bytes(R, reso))
@@ -746,8 +747,9 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
 
 def octree_level_values(R, reso, idx, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, columns=True):
     """What the octree sweep assigns to the lattice points `idx` (flat voxel indices, int64 device tensor, all on the lattice of
-    stride reso) at level `reso`: (pred_hr, pred_lr) float32.  columns=True: the column kernel of surs_octree_level_columns (a
-    point's value there is a function of the point and the level only); False: the per-point layer kernels.  The checker of
+    stride reso) at level `reso`: (pred_hr, pred_lr) float32.  columns=True: the column kernel of surs_octree_level_columns, run on
+    a walk state in which exactly `idx` is dirty (a point's last bits there depend on which points of its column share its tile:
+    ask for a level's whole dirty set to get the walk's bits); False: the per-point layer kernels.  The checker of
     tests/test_gpu_octree.py drives the oracle's restatement of lib/sdf.py:55-120 with it."""
     dev = idx.device
     n = idx.numel()

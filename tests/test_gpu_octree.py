@@ -126,7 +126,8 @@ def test_octree_walk_equals_oracle_walk_bit_for_bit(field, R, columns):
     o_hr, o_lr = oracle.eval_grid_octree(R, [-0.5] * 3, [0.5] * 3, None, thr, init, index_func=index_func)
     print(field, R, "columns" if columns else "points", "evaluated per level:", levels, "of", R ** 3,
           "| zero voxels hr %.4f lr %.4f" % ((o_hr == 0).mean(), (o_lr == 0).mean()))
-    assert [(r, n) for r, n, _ in stats] == levels
+    assert [(r, n) for r, n, _, _ in stats] == levels
+    print("   tiles per level:", [(r, t, "fill %.2f" % (n / (64.0 * t))) for r, n, _, t in stats if t])
     assert len(levels) >= 2 and sum(n for _, n in levels) < R ** 3
     assert np.array_equal(got_hr, o_hr)
     assert np.array_equal(got_lr, o_lr)
