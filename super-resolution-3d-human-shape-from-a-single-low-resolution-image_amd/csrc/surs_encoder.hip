@@ -227,6 +227,15 @@ template <> struct ConvSplit<2> {
     }
 };
 
+// NP = 1: ONE f16 part per operand, one product per MAC - 11 significant bits, NOT fp32-grade: the encoder of the reduced-precision
+// modes (--precision bf16 / fp16), whose consumer - the 16-bit column kernel - rounds the features' contributions to 8 / 11 bits
+// anyway.  Reads part 0 of the two-part weight image (hi = f16(w)).
+template <> struct ConvSplit<1> {
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ void split(float x, unsigned short (&p)[1]) { p[0] = __builtin_bit_cast(unsigned short, (_Float16)x); }
+};
+
 #ifdef SURS_CONV_TRACE
 __device__ unsigned long long g_conv_trace[8];
 #define CSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); g_conv_trace[i] += t_ - tprev; tprev = t_; } } while (0)
@@ -413,15 +422,17 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             if (more) fetch_slice(ch + PD, pb, tap);
             __builtin_amdgcn_sched_barrier(0);   // the next tap's reads and this tap's slice of the prefetch are in flight before its MFMAs start
             // the partial products that matter, smallest first: (x part, w part); six of three parts, three of two
-            constexpr int NPROD = NP == 3 ? 6 : 3;
-            constexpr int PA[6] = {NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, 1, NP == 3 ? 2 : 0, 0, 1, 0};
+            constexpr int NPROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
+            constexpr int PA[6] = {NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0, 0}, PB[6] = {0, NP == 1 ? 0 : 1, NP == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
             for (int t = 0; t < NPROD; ++t)
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[t % NA][r][j] = CS::mfma(ax[cur][r][PA[t]], bw[cur][j][PB[t]], acc[t % NA][r][j]);
+                    for (int j = 0; j < NJ; ++j) {
+                        const int sl = (NP == 1 ? tap : t) % NA;   // (one product per tap: consecutive taps on different accumulators)
+                        acc[sl][r][j] = CS::mfma(ax[cur][r][PA[t]], bw[cur][j][PB[t]], acc[sl][r][j]);
+                    }
             __builtin_amdgcn_sched_barrier(0);
         }
         CSTAMP(3);
@@ -1063,7 +1074,27 @@ extern "C" int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_
     return launch_conv_x3<3, 1, 3>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
+static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                            float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
+                            float slope, const float *residual, int res_ld, void *stream);
+
 extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                                   float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
+                                   const float *in_shift, int act, float slope, const float *residual, int res_ld,
+                                   void *stream) {
+    return conv2d_split_f16(2, x, h, w, cin, x_ld, wsplit, bias, y, cout, y_ld, ksize, stride, in_scale, in_shift, act, slope, residual,
+                            res_ld, stream);
+}
+
+extern "C" int surs_conv2d_nhwc_x1(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                                   float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
+                                   const float *in_shift, int act, float slope, const float *residual, int res_ld,
+                                   void *stream) {
+    return conv2d_split_f16(1, x, h, w, cin, x_ld, wsplit, bias, y, cout, y_ld, ksize, stride, in_scale, in_shift, act, slope, residual,
+                            res_ld, stream);
+}
+
+static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
                                    float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
                                    const float *in_shift, int act, float slope, const float *residual, int res_ld,
                                    void *stream) {
@@ -1083,9 +1114,13 @@ extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.act = act; a.slope = slope;
     a.res = residual; a.res_ld = res_ld;
-    if (ksize == 1) return launch_conv1x1_x2(a, (const unsigned short *)wsplit, as_stream(stream));
+    if (ksize == 1) return launch_conv1x1_x2(a, (const unsigned short *)wsplit, as_stream(stream));   // (HBM-bound: two parts always)
     // stride 2 (the three down-sampling convolutions of the super-resolution net): the 4-row x 32-channel tile, whose 9 x 65 pixel
     // patch fits the LDS
+    if (parts == 1) {
+        if (stride == 2) return launch_conv_x3_cfg<3, 2, 4, 32, 1>(a, (const unsigned short *)wsplit, as_stream(stream));
+        return launch_conv_x3<3, 1, 1>(a, (const unsigned short *)wsplit, as_stream(stream));
+    }
     if (stride == 2) return launch_conv_x3_cfg<3, 2, 4, 32, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
     return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
 }

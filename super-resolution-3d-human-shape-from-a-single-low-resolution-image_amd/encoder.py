@@ -24,13 +24,18 @@ class EncoderWeights:
         self.conv = {}
         self.gn = {}
         self.opt = opt
+        # --encoder_precision: "fp32" = two f16 parts, three products per MAC (parity mode); "f16" = one f16 product in the 3x3
+        # convolutions; "auto" follows --precision (bf16 / fp16 -> f16)
+        ep = getattr(opt, "encoder_precision", "auto")
+        self.reduced = ep == "f16" or (ep == "auto" and getattr(opt, "precision", "fp32") in ("bf16", "fp16"))
 
         def get(k):
             v = sd[k]
             return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
 
         def add_conv(name, bias=True):
-            self.conv[name] = native.ConvWeights(get(name + ".weight"), get(name + ".bias") if bias else None, device)
+            self.conv[name] = native.ConvWeights(get(name + ".weight"), get(name + ".bias") if bias else None, device,
+                                                 reduced=self.reduced)
 
         def add_gn(name):
             self.gn[name] = (torch.from_numpy(np.ascontiguousarray(get(name + ".weight"), np.float32)).to(device),

@@ -106,9 +106,10 @@ def wide_operands_active():
 class ConvWeights:
     """Packed conv weights ([tap][cin_pad][cout_pad]) + bias on the device."""
 
-    def __init__(self, w, b, device):
+    def __init__(self, w, b, device, reduced=False):
         w = np.ascontiguousarray(w, np.float32)
         self._host_w, self._w3_wide = w, None
+        self.reduced = bool(reduced)   # 3x3: one f16 product per MAC (surs_conv2d_nhwc_x1) - the encoder of --precision bf16 / fp16
         self.cout, self.cin, self.k = w.shape[0], w.shape[1], w.shape[2]
         n = lib().surs_conv_pack_weights(None, self.cout, self.cin, self.k, None)
         packed = np.empty(n, np.float32)
@@ -156,6 +157,8 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
     w3, parts = cw.split_image() if x3 else (None, 0)
     x3 = x3 and w3 is not None and (stride == 1 or parts == 2)
     fn, wt = ((lib().surs_conv2d_nhwc_x3 if parts == 3 else lib().surs_conv2d_nhwc_x2), w3) if x3 else (lib().surs_conv2d_nhwc, cw.w)
+    if x3 and parts == 2 and cw.reduced and cw.k == 3 and not wide_operands_active():
+        fn = lib().surs_conv2d_nhwc_x1
     check(fn(x.ptr(), x.h, x.w, x.c, x.ld, _ptr(wt), _ptr(cw.b), out.ptr(), cw.cout, out.ld, cw.k,
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
              residual.ptr() if residual is not None else None,

@@ -152,10 +152,11 @@ def body_inputs(dev, hl=256, hh=1024):
     return weights.body_state_dict(opt), _upload(fl, dev), _upload(fh, dev)
 
 
-def noise_inputs(dev, H=512):
-    """The bench's field: seeded random weights, the encoder's features of the H x H synthetic image."""
+def noise_inputs(dev, H=512, encoder_precision="fp32"):
+    """The bench's field: seeded random weights, the encoder's features of the H x H synthetic image.  encoder_precision: "fp32"
+    (two f16 parts, fp32-grade) or "f16" (one f16 product per MAC in the 3x3 convolutions: the encoder of --precision bf16 / fp16)."""
     from surs_amd import model
-    opt = options.BaseOptions().parse(FLAGS)
+    opt = options.BaseOptions().parse(FLAGS + ["--encoder_precision", encoder_precision])
     sd = weights.synthetic_state_dict(opt, seed=0)
     net = model.SuRSNet(opt).to(device=dev)
     net.load_state_dict(sd)
@@ -165,6 +166,29 @@ def noise_inputs(dev, H=512):
     net.filter_lr(f_lr)
     Fl, Fh = net.features()
     return sd, Fl, Fh, net
+
+
+def encoder_report(dev, R=512, precisions=("bf16", "fp16"), sample=1 << 20):
+    """What the reduced-precision ENCODER (--encoder_precision f16, the default of --precision bf16 / fp16) adds: the feature maps
+    against the fp32-grade encoder's, and the whole reduced pipeline (f16 encoder + 16-bit sweep) against the whole fp32-grade one
+    (fp32-grade encoder + fp32-grade sweep) on the bench's noise field, in the terms of report()."""
+    sd, Fl, Fh, keep = noise_inputs(dev, encoder_precision="fp32")
+    sd2, Gl, Gh, keep2 = noise_inputs(dev, encoder_precision="f16")
+    rep = {"resolution": R}
+    for tag, a, b in (("im_feat_lr", Gl, Fl), ("im_feat_hr", Gh, Fh)):
+        d = (a.buf - b.buf).abs()
+        rep[tag] = {"max_abs_err_over_absmax": d.max().item() / b.buf.abs().max().item(),
+                    "mean_abs_err_over_mean_abs": d.mean().item() / b.buf.abs().mean().item()}
+    ref, t_ref, ws = sweeps(sd, Fl, Fh, R, ("fp32",), dev)
+    for prec in precisions:
+        new, t_new, _ = sweeps(sd, Gl, Gh, R, (prec,), dev)
+        r = {}
+        for i, tag in enumerate(("hr", "lr")):
+            r[tag] = field_stats(new[prec][i], ref["fp32"][i])
+            r[tag]["mesh"] = mesh_stats(ws, new[prec][i], ref["fp32"][i], R, sample=sample)
+        rep[prec] = r
+        del new
+    return rep
 
 
 def main():
@@ -178,6 +202,8 @@ def main():
     if which in ("noise", "both"):
         sd, Fl, Fh, keep = noise_inputs(dev)
         out["noise"] = report(sd, Fl, Fh, R, dev)
+    if which in ("encoder", "both"):
+        out["encoder_f16"] = encoder_report(dev, R)
     print(json.dumps(out))
 
 
