@@ -220,6 +220,7 @@ template <> struct ConvSplit<2> {
     typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ void split(float x, unsigned short (&p)[2]) {
+        asm volatile("" : "+v"(x));   // (one value feeds the conversion and the remainder: see split2_f16 in surs_grid_v5.inc)
         const _Float16 hi = (_Float16)x;
         const _Float16 lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);
         p[0] = __builtin_bit_cast(unsigned short, hi);
