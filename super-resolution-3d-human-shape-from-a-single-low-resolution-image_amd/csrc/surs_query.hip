@@ -1564,9 +1564,19 @@ __global__ __launch_bounds__(256) void lattice_select_kernel(const unsigned char
     const long long col = (long long)(li * reso) * R + (long long)(lj * reso);   // full-resolution column index i * R + j
     const unsigned char *row = dirty + col * R;
     unsigned npts = 0;
-    for (int t = 0; t * 64 < nl; ++t) {
-        const int k = t * 64 + lane;
-        npts += (unsigned)__popcll(__ballot(k < nl && row[(long long)k * reso] != 0));
+    if (reso == 1 && (R & 7) == 0) {
+        // the finest level reads every byte of the mask (134 MB at 512^3): 8 bytes per lane (the mask holds 0 / 1: the word's
+        // population count is the number of dirty voxels); one byte per lane ran at 40 GB/s, 3 ms per level
+        unsigned c = 0;
+        for (int k = lane * 8; k < nl; k += 512) c += (unsigned)__popcll(*reinterpret_cast<const unsigned long long *>(row + k));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        npts = c;
+    } else {
+        for (int t = 0; t * 64 < nl; ++t) {
+            const int k = t * 64 + lane;
+            npts += (unsigned)__popcll(__ballot(k < nl && row[(long long)k * reso] != 0));
+        }
     }
     if (lane == 0 && npts) {
         const unsigned long long slot = atomicAdd(counters, 1ull);

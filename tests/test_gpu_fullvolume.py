@@ -9,7 +9,9 @@ on three fields: the bench's noise-like field, the smooth closed body field, and
 column scaled by 60 (nearly every channel changes branch inside a tile: multi-chunk lists at full size).  Measured in logit
 space and as the number of voxels on the other side of the 0.5 level.  The logits are recovered in float64 from the fp32
 occupancies where those resolve them to 1e-5 (|logit| < 5: an occupancy within 6e-8 of 1 says nothing about its logit at
-1e-4); the saturated voxels are compared as occupancies (2e-6).  Bounds: about twice the values measured on MI355X
+1e-4); the saturated voxels are compared as occupancies (2e-6).  (Until round 4 the restated fp32-grade kernel left the dense one by
+6.7e-4 on the gain-60 field and 1e-5 on the noise field: hipcc had folded the residuals' product into the f16 conversion for one
+copy of the hi part only - csrc/surs_grid_v5.inc, split2_f16; now 1.5e-5 and 1.5e-6.)  Bounds: about twice the values measured on MI355X
 (profiles/r03_fullvolume.json; that file also holds the
 v10 == v7 / v11 == v8 bit-equality of the four-wave kernels that were removed from the build in round 4)."""
 import os
@@ -27,9 +29,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 R = 512
 #                 fp32-grade: max|dlogit|, flipped      fp16: max|dlogit|, mean|dlogit|, flipped fraction
 BOUNDS = {
-    "noise": ((2.5e-5, 40), (2.2e-3, 2.4e-4, 1.5e-4)),
+    "noise": ((5e-6, 40), (2.2e-3, 2.4e-4, 1.5e-4)),
     "body": ((4e-5, 4), (1.6e-2, 1.6e-3, 2.6e-5)),
-    "gain60": ((1.4e-3, 40), (2.2e-2, 1.5e-3, 2.1e-4)),
+    "gain60": ((4e-5, 40), (2.2e-2, 1.5e-3, 2.1e-4)),
 }
 
 

@@ -116,7 +116,8 @@ def test_gain60_field_against_the_oracle():
         assert w["docc"] < 1e-4, (name, w)
     # logits: 1e-4 absolute where |logit| < 5 for the column kernels; the point path's own logits (up to +-60) relative to their
     # magnitude - fp32 has 24 bits, and an absolute 1e-4 on a logit of 60 is 1.7e-6 relative, inside one ulp of its summands
-    assert worst["v11"]["dlogit"] < 1e-4 and worst["v5"]["dlogit"] < 1e-4, worst
+    # (measured in round 4: v11 2.0e-5, v5 1.5e-5, the point path 1.4e-5; before the split2_f16 fix v11 stood at 3.9e-4)
+    assert worst["v11"]["dlogit"] < 5e-5 and worst["v5"]["dlogit"] < 5e-5, worst
     assert worst["points"]["rel"] < 1e-4, worst
 
 
