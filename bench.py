@@ -302,6 +302,75 @@ def main():
                                                   "the GPU busy in both, the pipeline hides the input stage and the host gaps"}
         except Exception as e:
             extras["subject_pipeline"] = {"error": repr(e)}
+    if world == 1 and not args.no_extras:
+        # (a) "drops in unchanged": the reference's own sweep loop (lib/sdf.py:32-45 batch_eval over lib/mesh_util.py:20-28 eval_func)
+        # around the facade - 50 000 points per call, query_mr + query_sr + get_preds()[0][0].detach().cpu().numpy() - timed on
+        # 40 chunks of a 512^3 grid's points; (b) gen_mesh's DEFAULT sweep (use_octree=True, lib/train_util.py:53,73) at 512^3 in the
+        # parity precision on the smooth body field (the noise field leaves nothing to skip)
+        try:
+            from surs_amd import sdf
+            o32 = options.BaseOptions().parse(flags + ["--precision", "fp32"])
+            n32 = model.SuRSNet(o32).to(device=dev)
+            n32.load_state_dict(sd)
+            n32.eval()
+            n32.im_feat_list_lr, n32.im_feat_list_hr = net.im_feat_list_lr, net.im_feat_list_hr
+            ns = 50000
+            nchunks = min(40, max(1, R ** 3 // ns))
+            # (grid points as create_grid lays them out - float64 matmul on the voxel indices - from the middle of the grid; the 3.2 GB
+            #  coordinate array of a 512^3 grid is not materialised for 40 chunks)
+            mat4 = sdf.create_grid(R, R, R, b_min, b_max)[1]
+            idx = np.arange(nchunks * ns, dtype=np.int64) + max(0, (R // 2) * R * R - nchunks * ns // 2)
+            ijk = np.stack([idx // (R * R), (idx // R) % R, idx % R]).astype(np.float64)
+            pts_all = np.matmul(mat4[:3, :3], ijk) + mat4[:3, 3:4]
+
+            def eval_func(points):   # lib/mesh_util.py:20-28
+                points = np.expand_dims(points, axis=0)
+                samples = torch.from_numpy(points).to(device=dev).float()
+                n32.query_mr(samples, calib)
+                n32.query_sr(samples, calib)
+                return n32.get_preds()[0][0].detach().cpu().numpy(), n32.get_preds()[1][0].detach().cpu().numpy()
+
+            def loop():
+                for i in range(pts_all.shape[1] // ns):
+                    eval_func(pts_all[:, i * ns:(i + 1) * ns])
+
+            loop()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop()
+            torch.cuda.synchronize()
+            tl = time.perf_counter() - t0
+            extras["reference_loop"] = {"what": "the reference's eval_grid loop (50 000-point chunks, host numpy in / out, lib/sdf.py:32-45) "
+                                                "around SuRSNet.query_mr / query_sr / get_preds, fp32",
+                                        "points": int(pts_all.shape[1] // ns * ns), "seconds": tl, "value": pts_all.shape[1] // ns * ns / tl,
+                                        "unit": "queries/s", "ms_per_50k_chunk": tl / (pts_all.shape[1] // ns) * 1e3}
+        except Exception as e:
+            extras["reference_loop"] = {"error": repr(e)}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import precision_report as pr
+            o32 = options.BaseOptions().parse(flags + ["--precision", "fp32"])
+            nb = model.SuRSNet(o32).to(device=dev)
+            full = dict(sd)
+            full.update(weights.body_state_dict(o32))
+            nb.load_state_dict(full)
+            nb.eval()
+            fl_b, fh_b = weights.body_features(IMG // 2, 2 * IMG)
+            feats = (pr._upload(fl_b, dev), pr._upload(fh_b, dev))
+            res = {}
+            for name, use_oct in (("dense", False), ("octree", True)):
+                for rep in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    out = mesh_util.reconstruction(o32, nb, dev, calib, R, b_min, b_max, use_octree=use_oct, features=feats, want_normals=False)
+                    torch.cuda.synchronize()
+                    res[name] = {"seconds": time.perf_counter() - t0, "verts_hr": int(len(out[0])), "verts_lr": int(len(out[4]))}
+            extras["octree_mode"] = {"what": "mesh_util.reconstruction(use_octree=True) - gen_mesh's default, lib/sdf.py:55-120 - against the "
+                                             "dense sweep, %d^3, fp32, smooth body field (weights.body_*); the octree's output differs from "
+                                             "the dense one by construction (interpolated blocks, shared-dirty artefact)" % R,
+                                     "octree": res["octree"], "dense": res["dense"]}
+        except Exception as e:
+            extras["octree_mode"] = {"error": repr(e)}
     if world == 1 and not args.no_extras and R == RES:
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -317,6 +386,14 @@ def main():
                                                                for s in ("to_ref", "from_ref")}}
                                  for t in ("hr", "lr")} for p in ("bf16", "fp16")}
                 acc[name]["sweep_s"] = rep["sweep_s"]
+            if args.precision != "fp32" and getattr(opt, "encoder_precision", "auto") != "fp32":
+                # the reduced modes also run the encoder's 3x3 convolutions on ONE f16 product per MAC (--encoder_precision auto):
+                # the whole reduced pipeline against the whole fp32-grade one (noise field)
+                er = pr.encoder_report(dev, R, precisions=(args.precision,))
+                acc["encoder_f16"] = {"im_feat_lr": er["im_feat_lr"], "im_feat_hr": er["im_feat_hr"],
+                                      args.precision: {t: {k: er[args.precision][t][k] for k in ("max_abs_dlogit", "mean_abs_dlogit", "flipped_voxels")}
+                                                       for t in ("hr", "lr")},
+                                      "what": "f16-product encoder + %s sweep against fp32-grade encoder + fp32-grade sweep" % args.precision}
             acc["reference"] = "fp32-grade sweep (column kernel v11) on the same features and weights, 512^3"
             acc["why_bf16"] = ("BASELINE configs[2] names bf16: fp32's exponent range, no activation can overflow; fp16 (configs[4]) is "
                                "8x tighter at 0.93x the rate but saturates at 65504 - `--precision fp16` / `fp32` select the others")

@@ -90,9 +90,8 @@ int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_ld, const v
                         float slope, const float *residual, int res_ld, void *stream);
 size_t surs_conv_pack_weights_x2(const float *w, int cout, int cin, int ksize, void *out);
 /* The same entry with ONE f16 part per operand (part 0 of the surs_conv_pack_weights_x2 image) and one product per MAC in the 3x3
- * kernels: 11 significant bits - NOT fp32-grade; a third of the matrix work.  The encoder of the reduced-precision modes
- * (--precision bf16 / fp16), whose 16-bit sweep rounds the features' contributions to 8 / 11 bits anyway; held to the acceptance
- * bounds of tests/test_gpu_precision.py.  1x1 convolutions (HBM-bound) run the two-part kernel. */
+ * kernels: 11 significant bits - NOT fp32-grade; a third of the matrix work.  The encoder of --precision bf16, whose sweep
+ * rounds the features' contributions to 8 bits anyway; held to the acceptance bounds of tests/test_gpu_precision.py.  1x1 convolutions (HBM-bound) run the two-part kernel. */
 int surs_conv2d_nhwc_x1(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias, float *y,
                         int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
                         float slope, const float *residual, int res_ld, void *stream);

@@ -1554,36 +1554,63 @@ extern "C" int surs_query_grid_indexed(const long long *idx, int n, int ry, int 
 //   sweep  : run_column_batch over the listed columns (mode 4 gather), items = klist, zstride = reso, compact outputs [column][nl]
 //   scatter: sdf[voxel] = value, dirty[voxel] = 0 for the listed points
 // ------------------------------------------------------------------------------------------------
+// One workgroup takes 64 consecutive lattice columns (a wave 16 of them, one after the other) and appends the ones that hold dirty
+// points with ONE atomic per counter (an atomic per listed column serialised on the three counters: 3 ms per level at 512^3).
 __global__ __launch_bounds__(256) void lattice_select_kernel(const unsigned char *__restrict__ dirty, int R, int reso, int nl,
                                                              int *__restrict__ cols, int *__restrict__ counts,
                                                              unsigned long long *__restrict__ counters /* [0] columns, [1] dirty points, [2] tiles */) {
-    const int lane = threadIdx.x & 63;
-    const long long lc = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // lattice column = li * nl + lj
-    if (lc >= (long long)nl * nl) return;
-    const int li = (int)(lc / nl), lj = (int)(lc - (long long)li * nl);
-    const long long col = (long long)(li * reso) * R + (long long)(lj * reso);   // full-resolution column index i * R + j
-    const unsigned char *row = dirty + col * R;
-    unsigned npts = 0;
-    if (reso == 1 && (R & 7) == 0) {
-        // the finest level reads every byte of the mask (134 MB at 512^3): 8 bytes per lane (the mask holds 0 / 1: the word's
-        // population count is the number of dirty voxels); one byte per lane ran at 40 GB/s, 3 ms per level
-        unsigned c = 0;
-        for (int k = lane * 8; k < nl; k += 512) c += (unsigned)__popcll(*reinterpret_cast<const unsigned long long *>(row + k));
+    __shared__ int cnt[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ncolumns = (long long)nl * nl;
+    const long long lc0 = (long long)blockIdx.x * 64;
+    for (int q = 0; q < 16; ++q) {
+        const long long lc = lc0 + wave * 16 + q;   // lattice column = li * nl + lj
+        unsigned npts = 0;
+        if (lc < ncolumns) {
+            const int li = (int)(lc / nl), lj = (int)(lc - (long long)li * nl);
+            const unsigned char *row = dirty + ((long long)(li * reso) * R + (long long)(lj * reso)) * R;
+            if (reso == 1 && (R & 7) == 0) {
+                // the finest level reads every byte of the mask (134 MB at 512^3): 8 bytes per lane (the mask holds 0 / 1: the
+                // word's population count is the number of dirty voxels)
+                unsigned c = 0;
+                for (int k = lane * 8; k < nl; k += 512) c += (unsigned)__popcll(*reinterpret_cast<const unsigned long long *>(row + k));
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-        npts = c;
-    } else {
-        for (int t = 0; t * 64 < nl; ++t) {
-            const int k = t * 64 + lane;
-            npts += (unsigned)__popcll(__ballot(k < nl && row[(long long)k * reso] != 0));
+                for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+                npts = c;
+            } else {
+                for (int t = 0; t * 64 < nl; ++t) {
+                    const int k = t * 64 + lane;
+                    npts += (unsigned)__popcll(__ballot(k < nl && row[(long long)k * reso] != 0));
+                }
+            }
         }
+        if (lane == 0) cnt[wave * 16 + q] = (int)npts;
     }
-    if (lane == 0 && npts) {
-        const unsigned long long slot = atomicAdd(counters, 1ull);
-        cols[slot] = (int)col;
-        counts[slot] = (int)npts;
-        atomicAdd(counters + 1, (unsigned long long)npts);
-        atomicAdd(counters + 2, (unsigned long long)((npts + 63) / 64));
+    __syncthreads();
+    if (wave == 0) {
+        const int n = cnt[lane];
+        const unsigned long long b = __ballot(n > 0);
+        unsigned pts = (unsigned)n, tiles = (unsigned)((n + 63) / 64);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            pts += __shfl_xor(pts, d);
+            tiles += __shfl_xor(tiles, d);
+        }
+        unsigned long long mine = 0;
+        if (lane == 0 && b) {
+            mine = atomicAdd(counters, (unsigned long long)__popcll(b));
+            atomicAdd(counters + 1, (unsigned long long)pts);
+            atomicAdd(counters + 2, (unsigned long long)tiles);
+        }
+        const unsigned long long base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mine & 0xffffffffull));
+        if (n > 0) {
+            const long long lc = lc0 + lane;
+            const int li = (int)(lc / nl), lj = (int)(lc - (long long)li * nl);
+            const unsigned long long slot = base + (unsigned long long)__popcll(b & ((1ull << lane) - 1ull));
+            cols[slot] = (int)((long long)(li * reso) * R + (long long)(lj * reso));   // full-resolution column index i * R + j
+            counts[slot] = n;
+        }
     }
 }
 
@@ -1648,7 +1675,7 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
     float *vh = (float *)(base + lattice_list_bytes(R)), *vl = vh + (size_t)COL_BATCH * nl;
     unsigned short *klist = (unsigned short *)(vl + (size_t)COL_BATCH * nl);
     SURS_HIP_CHECK(hipMemsetAsync(ctr, 0, 32, st));
-    hipLaunchKernelGGL(lattice_select_kernel, dim3((unsigned)ceil_div((long long)nl * nl, 4)), dim3(256), 0, st, dirty, R, reso, nl, cols,
+    hipLaunchKernelGGL(lattice_select_kernel, dim3((unsigned)ceil_div((long long)nl * nl, 64)), dim3(256), 0, st, dirty, R, reso, nl, cols,
                        kcnt, ctr);
     SURS_LAUNCH_CHECK();
     unsigned long long host[3] = {0, 0, 0};

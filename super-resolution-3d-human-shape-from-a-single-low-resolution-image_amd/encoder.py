@@ -25,9 +25,11 @@ class EncoderWeights:
         self.gn = {}
         self.opt = opt
         # --encoder_precision: "fp32" = two f16 parts, three products per MAC (parity mode); "f16" = one f16 product in the 3x3
-        # convolutions; "auto" follows --precision (bf16 / fp16 -> f16)
+        # convolutions (features within 1.8e-3 / 4e-4 of their range); "auto" = f16 with --precision bf16 only: measured at 512^3
+        # (tools/precision_report.py encoder, tests/test_gpu_precision.py) it adds a quarter to the bf16 sweep's own error
+        # (mean |d logit| 1.0e-3 -> 1.3e-3) but would multiply the fp16 sweep's by nine (6e-5 -> 5.9e-4)
         ep = getattr(opt, "encoder_precision", "auto")
-        self.reduced = ep == "f16" or (ep == "auto" and getattr(opt, "precision", "fp32") in ("bf16", "fp16"))
+        self.reduced = ep == "f16" or (ep == "auto" and getattr(opt, "precision", "fp32") == "bf16")
 
         def get(k):
             v = sd[k]

@@ -68,8 +68,8 @@ _IGNORED = [
 _NATIVE = [
     ("precision", str, "fp32"),      # fp32 | bf16 | fp16 : arithmetic of the MLP contractions
     ("encoder_precision", str, "auto"),   # fp32 (two f16 parts, three products per MAC: the parity mode) | f16 (one f16 product per
-                                          # MAC in the 3x3 convolutions: 11 significant bits) | auto = fp32 with --precision fp32, f16 with
-                                          # bf16 / fp16, whose 16-bit sweep rounds the features' contributions to 8 / 11 bits anyway
+                                          # MAC in the 3x3 convolutions: 11 significant bits) | auto = f16 with --precision bf16 (whose
+                                          # sweep rounds the features' contributions to 8 bits anyway), fp32 otherwise
     ("no_octree", None, False),      # dense sweep (the parity target)
     ("synthetic", None, False),      # synthetic image + PRNG weights instead of dataroot / checkpoint
     ("pipeline", None, False),       # eval driver: subjects as a pipeline (train_util.gen_mesh_pipelined) instead of one by one

@@ -62,3 +62,34 @@ def test_body_field_is_one_closed_surface(reports):
     m = reports["body"]["fp16"]["hr"]["mesh"]
     assert m["faces_ref"] == 2 * m["verts_ref"] - 4
     assert 2e5 < m["verts_ref"] < 1e6
+
+
+def test_reduced_encoder_acceptance_512():
+    """--precision bf16 also runs the encoder's 3x3 convolutions on ONE f16 product per MAC (--encoder_precision auto).  The whole
+    reduced pipeline (f16-product encoder + bf16 sweep) against the whole fp32-grade one (two-part encoder + fp32-grade sweep) at
+    512^3 on the bench's noise field, in the terms of the test above; bounds = about twice the values measured on MI355X (round 4:
+    features within 1.8e-3 / 3.8e-4 of their range; max |d logit| 0.0074, mean 0.0013, 1.1e-3 of the voxels across 0.5 - the bf16
+    sweep alone: 0.0049 / 0.0010 / 9e-4).  For fp16 the same encoder would be the dominant error (mean 5.9e-4 against the sweep's
+    6e-5): `auto` keeps the fp32-grade encoder there, asserted below."""
+    import precision_report as pr
+    from surs_amd import encoder, native, options
+    dev = native.require_gpu()
+    rep = pr.encoder_report(dev, 512, precisions=("bf16",))
+    print({k: rep[k] for k in ("im_feat_lr", "im_feat_hr")})
+    assert rep["im_feat_lr"]["max_abs_err_over_absmax"] < 4e-3 and rep["im_feat_hr"]["max_abs_err_over_absmax"] < 1e-3
+    b = (0.015, 0.0026, 2.2e-3, 6e-3, 0.05, 0.95, 2.2e-3)
+    for tag in ("hr", "lr"):
+        r = rep["bf16"][tag]
+        m = r["mesh"]
+        print("f16 encoder + bf16 sweep", tag, {k: r[k] for k in ("max_abs_dlogit", "mean_abs_dlogit", "flipped_voxels")}, m)
+        assert r["max_abs_dlogit"] < b[0] and r["mean_abs_dlogit"] < b[1] and r["flipped_fraction"] < b[2], (tag, r)
+        assert abs(m["verts"] - m["verts_ref"]) <= b[3] * m["verts_ref"]
+        for side in ("to_ref", "from_ref"):
+            d = m[side]
+            assert d["mean"] < b[4] and d["p999"] < b[5] and d["unmatched"] <= b[6] * d["n"], (tag, side, d)
+    # what `auto` selects
+    for prec, want in (("fp32", False), ("bf16", True), ("fp16", False)):
+        opt = options.BaseOptions().parse(pr.FLAGS + ["--precision", prec])
+        assert (getattr(opt, "encoder_precision") == "auto")
+        ep = opt.encoder_precision
+        assert (ep == "f16" or (ep == "auto" and opt.precision == "bf16")) == want
