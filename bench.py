@@ -103,7 +103,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(o, steps, warmup):
+    def run(o, steps, warmup, net=net):
         """warmup untimed steps, then `steps` timed ones between barriers; -> (seconds, per-stage ms, mesh sizes, kernel timing)."""
         stage_ms = {"encoder": 0.0, "query": 0.0, "exchange": 0.0, "mesh": 0.0}
         last = {}
@@ -111,9 +111,12 @@ def main():
         def step(timed):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-            _, f_lr, f_hr = net.super_res(image)
-            net.filter_hr(f_hr)
-            net.filter_lr(f_lr)
+            if slab:   # super_res on this rank's image strip, feature_lr all-gathered, filter_hr on the strip (dist.encode_sharded)
+                sdist.encode_sharded(net, image, calib, R, b_min, b_max)
+            else:
+                _, f_lr, f_hr = net.super_res(image)
+                net.filter_hr(f_hr)
+                net.filter_lr(f_lr)
             ev[1].record()
             if slab:
                 m = sdist.reconstruction_sharded(o, net, calib, R, b_min, b_max, want_normals=False, timing=ev[2], copy_out=False)
@@ -207,9 +210,14 @@ def main():
 
     extras = {}
     if world == 1 and not args.no_extras and args.precision != "fp32":
-        # the same step in the parity-grade precision (fp32-grade column kernel; same network object, same blob)
+        # the same step in the parity-grade precision: fp32-grade column kernel AND fp32-grade encoder (a network object of its own:
+        # --precision bf16 runs the encoder's 3x3 convolutions on one f16 product per MAC)
         o32 = options.BaseOptions().parse(flags + ["--precision", "fp32"])
-        d32, st32, last32, (k32, p32, ks32) = run(o32, 2, 1)
+        net32 = model.SuRSNet(o32).to(device=dev)
+        net32.load_state_dict(sd)
+        net32.eval()
+        d32, st32, last32, (k32, p32, ks32) = run(o32, 2, 1, net=net32)
+        del net32
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
                                "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}

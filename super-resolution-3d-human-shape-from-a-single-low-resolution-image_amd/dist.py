@@ -239,6 +239,92 @@ def node_identity():
     return float(zlib.crc32((boot + "|" + socket.gethostname()).encode()))
 
 
+def slab_feature_columns(i0, i1, mat, calib, width):
+    """Columns [lo, hi) of a `width`-column feature map that the bilinear taps of the x-slab [i0, i1) touch, or None when the
+    projected image column is not a function of the voxel's axis-0 index alone (general calibration / grid transform).
+    lib/geometry.py:4-31: X = calib[0,:3] . p + calib[0,3], pixel = (X + 1) / 2 * (width - 1); one column of slack each side."""
+    m, c = np.asarray(mat, np.float64).reshape(3, 4), np.asarray(calib, np.float64).reshape(-1)[:12].reshape(3, 4)
+    row = c[0, :3] @ m[:, :3]                      # dX / d(i, j, k)
+    if row[1] != 0.0 or row[2] != 0.0:
+        return None
+    x0 = c[0, :3] @ m[:, 3] + c[0, 3]
+    us = [((row[0] * i + x0) + 1.0) / 2.0 * (width - 1) for i in (i0, i1 - 1)]
+    lo, hi = int(np.floor(min(us))) - 1, int(np.floor(max(us))) + 3
+    return max(0, lo), min(width, hi)
+
+
+def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transform=None, group=None):
+    """The encoder for ONE subject on all ranks of a slab-mode reconstruction (call it instead of super_res -> filter_hr ->
+    filter_lr; every rank passes the same image).  What is sharded and what is not, and why:
+
+      super_res  (SuRSSR_v3.py:143-181, no normalisation, receptive field 119 columns of the 2W map): rank r runs it on the image
+                 strip its share of the columns depends on (encoder.super_res_strip: share + a 128-column halo each side, recomputed,
+                 no exchange) - bit-identical to the columns of the full maps;
+      feature_lr strips are all-gathered (67 MB at H = 512, the one collective of the encoder: RCCL over xGMI / gloo in the tests);
+      filter_lr  (three stacked hourglasses: its receptive field covers the whole map and its 78 GroupNorms need global statistics)
+                 runs replicated on the gathered feature_lr;
+      filter_hr  (one 1x1 convolution) runs on the rank's strip of feature_hr only: the rank's x-slab samples no other columns.
+
+    Leaves net.im_feat_list_lr / im_feat_list_hr as the replicated encoder would, except that im_feat_hr holds zeros outside the
+    rank's strip.  Falls back to the replicated encoder (returns False) for one rank, several views, a general calibration, or a
+    width the ranks cannot share in even strips."""
+    from . import encoder, native
+    from .model import _as_img, _as_nchw_view
+    from .sdf import create_grid
+    world, rank = _world(group)
+    R = int(resolution)
+
+    def replicated():
+        _, f_lr, f_hr = net.super_res(images)
+        net.filter_hr(f_hr)
+        net.filter_lr(f_lr)
+        return False
+
+    if world == 1 or net.num_views != 1 or images.shape[0] != 1:
+        return replicated()
+    x = _as_img(images[0:1].to(net._device()))
+    wl, wh = x.w // 2, 2 * x.w
+    _, mat = create_grid(R, R, R, b_min, b_max, transform=transform)
+    calib = calib_tensor[0].detach().to("cpu", torch.float64).numpy().reshape(-1)[:12]
+    i0, i1 = slab_range(R, rank, world)
+    need_hr = slab_feature_columns(i0, i1, mat[:3], calib, wh)
+    if need_hr is None or wl % (2 * world) != 0:
+        return replicated()
+    share = wl // world
+    a, b = rank * share, (rank + 1) * share
+    a, b = min(a, need_hr[0] // 4 // 2 * 2), max(b, -(-need_hr[1] // 4) + (-(-need_hr[1] // 4)) % 2)   # + what the slab samples of feature_hr (even bounds)
+    b = min(b, wl)
+    W = net._encoder_weights()
+    img_sr, new2, new_fin = encoder.super_res_strip(W, x, a, b)
+    dev = x.buf.device
+    # ---- feature_lr: every rank's share, gathered
+    mine = new2.buf.view(new2.h, new2.w, new2.c)[:, rank * share - a:(rank + 1) * share - a, :].contiguous()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    if _host_staged(mine, group):
+        host = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+        dist.all_gather(host, mine.cpu(), group=group)
+        parts = [h.to(dev) for h in host]
+    else:
+        dist.all_gather(parts, mine, group=group)
+    f_lr = torch.cat(parts, dim=1).contiguous()
+    feature_lr = native.Img(new2.h, wl, new2.c, buf=f_lr.reshape(-1), device=dev)
+    # ---- filter_lr replicated, filter_hr on the strip (placed in a zeroed full-size map: the sweep addresses absolute columns)
+    outs = encoder.filter_lr(W, feature_lr, keep_all=net.training)
+    net._feat_lr_imgs = [[o] for o in outs]
+    net.im_feat_list_lr = [_as_nchw_view(o) for o in outs]
+    strip = encoder.filter_hr(W, new_fin)[0]
+    full = torch.zeros((new_fin.h, wh, strip.c), dtype=torch.float32, device=dev)
+    full[:, 4 * a:4 * b, :] = strip.buf.view(strip.h, strip.w, strip.c)
+    hr = native.Img(new_fin.h, wh, strip.c, buf=full.reshape(-1), device=dev)
+    net._feat_hr_imgs = [[hr]]
+    net.im_feat_list_hr = [_as_nchw_view(hr)]
+    net.im_SR = net.feature_hr = None
+    net.feature_lr = _as_nchw_view(feature_lr)
+    net._last_images = None          # (nothing here can be re-encoded by reencode_wide: the features are not super_res()'s)
+    net._sr_out = net._lr_from = net._hr_from = None
+    return True
+
+
 def offsets_from_counts(counts):
     """counts [world] -> exclusive prefix sums (int64): where each rank's vertices / faces start in the whole mesh."""
     c = np.asarray(counts, np.int64)
@@ -330,7 +416,11 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
         planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
         sweep = torch.cuda.current_stream(dev)
         done = []
-        kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws)   # (probes the whole grid: every rank the same)
+        # the column-kernel choice probes the grid's MIDDLE plane: the rank whose slab holds it decides for everybody (with a sharded
+        # encoder - encode_sharded - the other ranks do not have that plane's feature_hr columns)
+        owner = next(r for r in range(world) if slab_range(R, r, world)[0] <= R // 2 < slab_range(R, r, world)[1])
+        kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws) if rank == owner else 0
+        kern = int(all_gather_rows([float(kern)], dev, group)[owner, 0])
         for a in range(0, nloc, planes):
             b = min(nloc, a + planes)
             try:

@@ -119,6 +119,36 @@ def super_res(W, x):
     return img_sr, new2, new_fin
 
 
+# The super-resolution net has no normalisation: an output column depends on input columns within its receptive field only -
+# in columns of the 2W-wide maps: bicubic x2 (4) + head (1) + down1 (1) + 6 convolutions at W (12) + down2 (2) + 6 at W/2 (24) +
+# down3 (4) + 8 at W/4 (64) + ups2 (4) + ups3 (2) + ups4 (1) = 119.  Rounded up to a multiple of 8 (the three stride-2 stages and
+# the pixel shuffles keep their phase when a strip starts at a multiple of 8): 128 columns = 32 columns of feature_lr.
+SR_HALO_LR = 32
+
+
+def super_res_strip(W, x, a, b):
+    """super_res restricted to the columns [a, b) of feature_lr (= columns [4a, 4b) of feature_hr / img_SR): runs the net on the
+    image columns that range depends on (a halo of SR_HALO_LR feature_lr columns on each side, clipped at the image border, where
+    the convolutions' own zero padding applies) and returns (img_sr, new2, new_fin) cropped to the range.  Every value is computed
+    from the same inputs by the same instruction sequence as in super_res on the whole image: the strips are BIT-IDENTICAL to
+    the corresponding columns of the full maps (tests/test_gpu_dist.py).  a, b even; what one rank of a sharded reconstruction
+    computes (dist.encode_sharded)."""
+    wl = x.w // 2
+    if a % 2 or b % 2 or not (0 <= a < b <= wl):
+        raise ValueError("strip [%d, %d) of %d feature_lr columns: bounds must be even and inside the map" % (a, b, wl))
+    a0, b0 = max(0, a - SR_HALO_LR), min(wl, b + SR_HALO_LR)
+    dev = x.buf.device
+    hwc = lambda t: torch.as_strided(t.buf, (t.h, t.w, t.c), (t.w * t.ld, t.ld, 1), t.buf.storage_offset() + t.off)
+    xs = Img(x.h, 2 * (b0 - a0), x.c, buf=hwc(x)[:, 2 * a0:2 * b0, :].contiguous().reshape(-1), device=dev)
+    img_sr, new2, new_fin = super_res(W, xs)
+
+    def crop(t, scale):   # columns [scale * (a - a0), scale * (b - a0)) of a strip map with `scale` columns per feature_lr column
+        v = hwc(t)[:, scale * (a - a0):scale * (b - a0), :]
+        return Img(t.h, scale * (b - a), t.c, buf=v.contiguous().reshape(-1), device=dev)
+
+    return crop(img_sr, 4), crop(new2, 1), crop(new_fin, 4)
+
+
 def conv_block(W, prefix, x):
     """ConvBlock with in_planes == out_planes: cat(o1, o2, o3) + x, GroupNorm+ReLU fused into each conv's staging."""
     c = x.c

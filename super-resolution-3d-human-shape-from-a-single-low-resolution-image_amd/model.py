@@ -210,6 +210,18 @@ class SuRSNet:
         s (x) row2, so that h01' / h2 = S xy + s.  (The reference slices `transforms[:2, :2]` - of a [B,2,3] tensor that is not
         the 2x2 scale its baddbmm needs, and of a [2,3] matrix baddbmm refuses the rank -, so this follows the evident meaning,
         which is PIFu's `transforms[:, :2, :2]`; the eval path never passes transforms.)"""
+        # (the reference's sweep loop passes the same device tensors 2 684 times per 512^3 grid: a device-to-host copy - a host
+        #  synchronisation - per call is what the loop then spends its time in; cached on the tensors' identity and version)
+        key = (calibs.data_ptr(), calibs._version, tuple(calibs.shape), None if transforms is None else (transforms.data_ptr(), transforms._version),
+               self.projection_mode)
+        hit = getattr(self, "_calib_cache", None)
+        if hit is not None and hit[0] == key and hit[1] is calibs and hit[2] is transforms:
+            return hit[3]
+        rows = self._calib_rows_uncached(calibs, transforms)
+        self._calib_cache = (key, calibs, transforms, rows)
+        return rows
+
+    def _calib_rows_uncached(self, calibs, transforms):
         cal = calibs.detach().to("cpu", torch.float64).numpy()[:, :3, :].copy()
         if transforms is not None:
             tr = transforms.detach().to("cpu", torch.float64).numpy()
@@ -278,7 +290,7 @@ class SuRSNet:
         synchronisation) are computed again on three bf16 parts - fp32's exponent range -, after re-running the encoder the same
         way if its features are what overflowed."""
         phr, plr = run()
-        if bool(torch.isfinite(phr).all()) and bool(torch.isfinite(plr).all()):
+        if bool(torch.isfinite(phr).all() & torch.isfinite(plr).all()):   # (one host synchronisation, not two)
             return phr, plr
         import warnings
         warnings.warn("query: non-finite predictions from the two-part f16 operand split; repeating on three bf16 parts", stacklevel=3)

@@ -23,6 +23,42 @@ def test_sharded_reconstruction_equals_single_process(world, R):
     assert "flat field raises on every rank" in r.stdout and "no error on a flat field" not in r.stdout, r.stdout
 
 
+@pytest.mark.parametrize("world,R,H", [(2, 64, 256), (4, 128, 512)])
+def test_sharded_encoder_is_bit_identical(world, R, H):
+    """dist.encode_sharded: the super-resolution net on each rank's image strip (recomputed 128-column halo, no exchange), the
+    feature_lr strips all-gathered, filter_lr replicated, filter_hr on the strip - the feature maps every rank holds and the
+    sharded meshes must equal the replicated encoder's and the single-GPU reconstruction's bit for bit."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_slab_check.py"), str(world), str(R), str(H)], capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("sharded encoder used") == world and "DIFFERENT" not in r.stdout and "fallback" not in r.stdout, r.stdout
+    assert "sharded == replicated == one GPU" in r.stdout and "MISMATCH" not in r.stdout, r.stdout
+
+
+def test_super_res_strip_equals_full_columns():
+    """encoder.super_res_strip: every strip of an 8-way split of the 512 x 512 image's maps - interior strips (halo on both
+    sides), border strips (the convolutions' own zero padding on one side) - equals the columns of the full maps bit for bit."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import common
+    from surs_amd import encoder, model, weights
+    from surs_amd.model import _as_img
+    dev = torch.device("cuda:0")
+    net = model.SuRSNet(common.opt()).to(device=dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    img = torch.from_numpy(weights.synthetic_image(512, seed=1)).to(dev)
+    W = net._encoder_weights()
+    x = _as_img(img)
+    full = encoder.super_res(W, x)
+    hwc = lambda t: t.buf.view(t.h, t.w, t.c)
+    for a, b in ((0, 32), (32, 64), (94, 128), (126, 160), (222, 256), (0, 256)):
+        got = encoder.super_res_strip(W, x, a, b)
+        for g, f, sc in zip(got, full, (4, 1, 4)):
+            assert (g.h, g.w, g.c) == (f.h, sc * (b - a), f.c)
+            assert torch.equal(hwc(g), hwc(f)[:, sc * a:sc * b, :]), (a, b, sc)
+
+
 @pytest.mark.parametrize("mode", ["slab", "replicas"])
 def test_bench_multi_rank_paths_on_one_gpu(mode):
     """bench.py's N > 1 code paths (BASELINE configs[3] = slab, configs[4] = replicas), launched as the driver launches them
