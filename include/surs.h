@@ -95,6 +95,11 @@ size_t surs_conv_pack_weights_x2(const float *w, int cout, int cin, int ksize, v
 int surs_conv2d_nhwc_x1(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias, float *y,
                         int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
                         float slope, const float *residual, int res_ld, void *stream);
+/* The split-operand 3x3 kernels come in two tiles (8 rows x 64 channels, 4 x 32 for maps too small to fill the chip with the
+ * first) that sum their partial products in different orders.  surs_conv_tile_scale(num, den) makes the calling thread's following
+ * convolutions choose the tile as if their maps were num / den times as wide: a column strip of an image then reproduces the bits
+ * of the full image's columns (one rank's share of a sharded encoder).  (1, 1) restores the default. */
+int surs_conv_tile_scale(int num, int den);
 /* HOST helper: repack a PyTorch [cout][cin][k][k] weight into the kernel layout [k*k][cin_pad][cout_pad] (floats).
  * Returns the number of floats written (query with out == NULL). */
 size_t surs_conv_pack_weights(const float *w, int cout, int cin, int ksize, float *out);

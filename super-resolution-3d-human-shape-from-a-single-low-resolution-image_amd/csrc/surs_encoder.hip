@@ -496,9 +496,21 @@ static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, h
 // 8 rows x 64 channels (140 KB of LDS, one workgroup per CU, 216 MFMAs per wave and chunk: long enough to cover the
 // prefetch, and the input is re-read least) where that still gives every CU two workgroups' worth of tiles; 4 rows x 32
 // channels (79 KB, two workgroups per CU) for the small maps.
+// surs_conv_tile_scale: the tile is chosen as if the map were num / den times as wide (calling thread only).  The two tiles sum
+// their partial products in different orders, so a column strip of a map reproduces the bits of the full map's columns only if it
+// runs the full map's tile (encoder.super_res_strip: one rank's share of a sharded encoder).
+static thread_local int t_tile_num = 1, t_tile_den = 1;
+extern "C" int surs_conv_tile_scale(int num, int den) {
+    SURS_REQUIRE(num >= 1 && den >= 1, "scale must be positive");
+    t_tile_num = num;
+    t_tile_den = den;
+    return 0;
+}
+
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
-    const long long wg_big = (long long)ceil_div(a.wo, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64);
+    const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
+    const long long wg_big = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64);
     if (wg_big >= 512) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }

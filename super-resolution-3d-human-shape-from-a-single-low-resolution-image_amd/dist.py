@@ -411,18 +411,28 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     try:
         # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
         import os
-        # (16 384 columns per launch here, half of what one GPU sweeps per launch: a rank of eight holds 64 planes of a 512^3 grid,
-        #  and with one launch its marching cubes would all follow the sweep instead of running under its second half)
-        planes = max(1, int(os.environ.get("SURS_SLAB_COLUMNS", "16384")) // R)
+        # 16 384 columns per launch here (half of what one GPU sweeps per launch: a rank of eight holds 64 planes of a 512^3 grid, and
+        # with one launch its marching cubes would all follow the sweep instead of running under its second half), the last launch's
+        # planes as a taper (mesh_util.sweep_schedule): what follows the sweep on every rank - the extraction of the last launch's cell
+        # layers - is the serial tail of the strong-scaling step.  SURS_SLAB_COLUMNS: equal launches of that many columns (tests)
+        env = os.environ.get("SURS_SLAB_COLUMNS")
+        sched = mesh_util.sweep_schedule(nloc, max(1, 16384 // R), max(1, int(env) // R) if env else None)
         sweep = torch.cuda.current_stream(dev)
         done = []
         # the column-kernel choice probes the grid's MIDDLE plane: the rank whose slab holds it decides for everybody (with a sharded
         # encoder - encode_sharded - the other ranks do not have that plane's feature_hr columns)
         owner = next(r for r in range(world) if slab_range(R, r, world)[0] <= R // 2 < slab_range(R, r, world)[1])
-        kern = native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws) if rank == owner else 0
-        kern = int(all_gather_rows([float(kern)], dev, group)[owner, 0])
-        for a in range(0, nloc, planes):
-            b = min(nloc, a + planes)
+        k, kern_err = 0.0, None
+        if rank == owner:
+            try:
+                k = float(native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws))
+            except Exception as e:   # noqa: BLE001 - the others are waiting in the gather below: tell them
+                k, kern_err = -1.0, e
+        k = all_gather_rows([k], dev, group)[owner, 0]
+        if k < 0:
+            raise kern_err or RuntimeError("the column-kernel probe failed on rank %d" % owner)
+        kern = int(k)
+        for a, b in sched:
             try:
                 native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b],
                                   kernel=kern)

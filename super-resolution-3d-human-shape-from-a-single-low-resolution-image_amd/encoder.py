@@ -140,7 +140,13 @@ def super_res_strip(W, x, a, b):
     dev = x.buf.device
     hwc = lambda t: torch.as_strided(t.buf, (t.h, t.w, t.c), (t.w * t.ld, t.ld, 1), t.buf.storage_offset() + t.off)
     xs = Img(x.h, 2 * (b0 - a0), x.c, buf=hwc(x)[:, 2 * a0:2 * b0, :].contiguous().reshape(-1), device=dev)
-    img_sr, new2, new_fin = super_res(W, xs)
+    # (the 3x3 kernels pick their tile by the size of the map, and the two tiles sum in different orders: the strip runs the full
+    #  image's tiles)
+    native.check(native.lib().surs_conv_tile_scale(x.w, xs.w))
+    try:
+        img_sr, new2, new_fin = super_res(W, xs)
+    finally:
+        native.check(native.lib().surs_conv_tile_scale(1, 1))
 
     def crop(t, scale):   # columns [scale * (a - a0), scale * (b - a0)) of a strip map with `scale` columns per feature_lr column
         v = hwc(t)[:, scale * (a - a0):scale * (b - a0), :]

@@ -139,6 +139,26 @@ def meshes_from_volumes(net, vols, mat, level=0.5, want_normals=True):
 SLAB_COLUMNS = 32768   # the library's COL_BATCH (csrc/surs_query.hip): columns per launch of the column kernel
 
 
+def sweep_schedule(nplanes, big, equal=None):
+    """[(a, b)] plane ranges of the launches of a streamed sweep over `nplanes` axis-0 planes: launches of `big` planes (one batch of
+    the column kernel), and the LAST batch's planes as a taper (5/8, 1/4, 1/8 of it) - what follows the sweep, the extraction and
+    the copies of the last launch's cell layers, shrinks with it (mesh tail 1.3 -> 0.65 ms at 512^3).  equal: that many planes per
+    launch instead (timing experiments, tests)."""
+    if equal:
+        return [(a, min(nplanes, a + equal)) for a in range(0, nplanes, equal)]
+    cuts, a = [], 0
+    while nplanes - a > big:
+        cuts.append(big)
+        a += big
+    rem = nplanes - a
+    cuts += [c for c in (rem * 5 // 8, rem // 4, rem - rem * 5 // 8 - rem // 4) if c > 0] if rem >= 8 else [rem]
+    sched, a = [], 0
+    for c in cuts:
+        sched.append((a, a + c))
+        a += c
+    return sched
+
+
 def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, want_normals=True, timing=None,
                             planes=None, features=None, after_enqueue=None):
     """Dense reconstruction with the mesh extraction pipelined into the sweep: the sweep writes the volumes 32 768 columns
@@ -172,23 +192,7 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
     sweep = torch.cuda.current_stream(dev)
     done = []
     kern = native.grid_kernel_for(R, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws)
-    if planes:
-        sched = [(i0, min(R, i0 + planes)) for i0 in range(0, R, planes)]
-    else:
-        # one launch of the column kernel per slab (the library's COL_BATCH = 32 768 columns = 64 planes at 512^3), and the last
-        # slab's planes as a taper (5/8, 1/4, 1/8 of it): what follows the sweep - extraction and copies of the last slab's meshes -
-        # shrinks with it (mesh tail 1.3 -> 0.65 ms at 512^3)
-        big = max(1, SLAB_COLUMNS // R)
-        cuts, a = [], 0
-        while R - a > big:
-            cuts.append(big)
-            a += big
-        rem = R - a
-        cuts += [c for c in (rem * 5 // 8, rem // 4, rem - rem * 5 // 8 - rem // 4) if c > 0] if rem >= 8 else [rem]
-        sched, a = [], 0
-        for c in cuts:
-            sched.append((a, a + c))
-            a += c
+    sched = sweep_schedule(R, max(1, SLAB_COLUMNS // R), planes)
     for i0, i1 in sched:
         try:
             native.query_grid(i0, i1, R, R, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, prec, ws, vh[i0:i1], vl[i0:i1],
