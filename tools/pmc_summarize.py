@@ -10,7 +10,7 @@ import csv, glob, json, os, sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 PRODUCTS = {"bf16": 1, "fp32": 3}
 COLS = 32768                      # columns per batch of the column kernel (the library's COL_BATCH)
 BATCHES = 512 * 512 // COLS       # batches per 512^3 sweep
@@ -104,7 +104,9 @@ def one(prec):
         # per-column constants (CC_PAD floats per column) and masks are the sweep's own intermediate, listed separately
         "algorithmic_bytes_per_launch": QUERIES * 8 + weights,
         "column_constant_bytes_per_launch": COLS * 2944 * 4 + COLS * 4,
-        "affine_fragment_bytes_per_launch": COLS * 32768 if tiles else 0,   # kernels v7 / v8: [column][MLP][16][64][8] 16-bit
+        # restated kernels: the per-column vectors R (5 x 512 fp32), read by the column kernel, which builds the affine A fragments
+        # itself (until round 3 a kernel of its own wrote them: 32 KiB per column = 1.07 GB per launch, read back once)
+        "r_vector_bytes_per_launch": COLS * 5 * 512 * 4 if tiles else 0,
     }
 
 
