@@ -31,6 +31,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 
 #include "surs_common.h"
 
@@ -1339,11 +1340,18 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     }
     SURS_REQUIRE((long long)d.cz * d.cy * d.prow < (1ll << 32), "volume too large");
     const int nb = mc_nblocks(d.q_end - d.q_begin);
-    static DeviceOnce fast_table;
-    if (fast_table.first()) {   // (host calls are sequential: the table is complete before any other stream can need it)
-        hipLaunchKernelGGL(mc_fast_init_kernel, dim3(1), dim3(256), 0, st);
-        SURS_LAUNCH_CHECK();
-        SURS_HIP_CHECK(hipStreamSynchronize(st));
+    {
+        // the table of cell codes that need no test, filled once per device.  Under a mutex: a second host thread (the pipelined flows
+        // drive two streams; surs_query_grid_opt is documented as thread-safe) that arrives while the first is still filling it must
+        // wait for the COMPLETE table - first() alone would let it through to classify against a half-written one
+        static std::mutex fast_mu;
+        static DeviceOnce fast_table;
+        std::lock_guard<std::mutex> lock(fast_mu);
+        if (fast_table.first()) {
+            hipLaunchKernelGGL(mc_fast_init_kernel, dim3(1), dim3(256), 0, st);
+            SURS_LAUNCH_CHECK();
+            SURS_HIP_CHECK(hipStreamSynchronize(st));
+        }
     }
     size_t off[5];
     const size_t fixed = mc_ws_layout(n0, n1, n2, off);

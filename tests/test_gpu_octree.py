@@ -15,6 +15,11 @@ from surs_amd import weights
 
 pytestmark = pytest.mark.gpu
 
+# tolerances of the end-to-end comparison with the REFERENCE's walk (different evaluator: a flat / not-flat decision flips where a
+# cell's corner range is within the evaluators' 1e-5 of --threshold, and the flipped block is then interpolated instead of evaluated):
+# twice what round 4 measured on MI355X (printed by the test)
+OCTREE_BAD_FRACTION, OCTREE_ZERO_DRIFT, OCTREE_VERT_DRIFT = 1e-3, 2e-3, 0.02
+
 
 def test_cell_pass_bitwise_vs_oracle_trace():
     import oracle
@@ -75,11 +80,15 @@ def test_octree_reconstruction_vs_reference(golden_dir):
     # a flat/not-flat decision can flip where the corner range is within ~1e-6 of the threshold: allow 0.1 % of voxels
     for got, want in ((hr[::2, ::2, ::2], g["hr_sub"]), (lr[1::2, ::2, 1::2], g["lr_sub"])):
         bad = np.abs(got - want) > 1e-4
-        assert bad.mean() < 1e-3, bad.mean()
-    assert abs((hr == 0).mean() - g["zero_frac"][0]) < 2e-3 and abs((lr == 0).mean() - g["zero_frac"][1]) < 2e-3
+        print("octree R=128 vs the reference's own walk: voxels off by > 1e-4: %.2e (max |d| where evaluated by both %.2e)" %
+              (bad.mean(), np.abs(got - want)[~bad].max()))
+        assert bad.mean() < OCTREE_BAD_FRACTION, bad.mean()
+    print("zero fractions", (hr == 0).mean(), (lr == 0).mean(), "reference", g["zero_frac"])
+    assert abs((hr == 0).mean() - g["zero_frac"][0]) < OCTREE_ZERO_DRIFT and abs((lr == 0).mean() - g["zero_frac"][1]) < OCTREE_ZERO_DRIFT
     out = mesh_util.reconstruction(opt, net, dev, calib, 128, b_min, b_max, use_octree=True)
-    assert abs(len(out[0]) - g["n_verts"][0]) <= 0.02 * g["n_verts"][0]
-    assert abs(len(out[4]) - g["n_verts"][1]) <= 0.02 * g["n_verts"][1]
+    print("vertices", len(out[0]), len(out[4]), "reference", g["n_verts"])
+    assert abs(len(out[0]) - g["n_verts"][0]) <= OCTREE_VERT_DRIFT * g["n_verts"][0]
+    assert abs(len(out[4]) - g["n_verts"][1]) <= OCTREE_VERT_DRIFT * g["n_verts"][1]
 
 
 def _walk_inputs(field, dev):
