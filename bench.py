@@ -216,10 +216,10 @@ def main():
         net32 = model.SuRSNet(o32).to(device=dev)
         net32.load_state_dict(sd)
         net32.eval()
-        d32, st32, last32, (k32, p32, ks32) = run(o32, 2, 1, net=net32)
+        d32, st32, last32, (k32, p32, ks32) = run(o32, 2, 2, net=net32)   # (a new object: one reconstruction sizes the mesh buffers, one warms the streamed path)
         del net32
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
-                               "steps": 2, "warmup": 1, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32),
+                               "steps": 2, "warmup": 2, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
     if world == 1 and not args.no_extras:
         # The restated column kernels' cost depends on the weights and features (how many layer-0 channels change LeakyReLU branch

@@ -5,8 +5,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import common, gpu_common as g, oracle
 from surs_amd import native
-R = 256
-fl, fh = common.synth_features()
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+fl, fh = common.synth_features(hl=256, hh=1024) if R >= 512 else common.synth_features()
 Fl, Fh = g.upload_nhwc(fl), g.upload_nhwc(fh)
 ws = native.Workspace(g.dev())
 mat = oracle.coords_matrix(R, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
