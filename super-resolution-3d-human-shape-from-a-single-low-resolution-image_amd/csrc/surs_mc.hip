@@ -18,8 +18,9 @@
 //      pass 2  exclusive scan of the block sums, two levels (1024 blocks per group, then the groups)
 //      pass 3  emit: the same classification again, only in blocks that have active cells; one 16-byte entry per active
 //              cell in sweep order: (cell, code = table / offset / counts, first vertex id, first triangle id)
-//      pass 4a vertices, one thread per ACTIVE cell: positions; ids stored in 4 dense per-voxel tables
-//              (x-edge, y-edge, z-edge starting at the voxel, centre of the cell whose corner 0 it is)
+//      pass 4a vertices, one thread per ACTIVE cell: positions; ids stored in 4 per-voxel tables (x-edge, y-edge, z-edge
+//              starting at the voxel, centre of the cell whose corner 0 it is) that hold a RING of MC_RING planes: the sweep is
+//              walked in chunks of MC_RING - 1 cell layers (mc_chunked), a layer only touches the ids of its two planes
 //      pass 4b faces (+ values by atomic max, normals by atomic add): vertex ids looked up in the tables
 //      pass 5  normalise normals.
 // HBM-bound by design: the volume is read once (pass 1) plus the blocks with a surface once more (pass 3: a few per cent
@@ -58,6 +59,7 @@ struct Dims {
     long long q_begin, q_end;         // the same range as padded indices q = (z * cy + y) * prow + x
     int base_verts, base_faces;      // vertices / triangles produced by earlier ranges
     int zoff;                        // slab mode: index of the volume's plane 0 in the whole grid (0 = the grid's bottom)
+    int ring;                        // planes of the edge -> vertex-id tables: plane z lives in slot z % ring (mc_ring)
     // q / prow and row / cy by multiplication (fast_div): n / d = mulhi(n, m) >> s for every n < 2^31, with m = ceil(2^(32 + s) / d),
     // s = ceil(log2 d) - 1 (error of m below d, times n below 2^(32 + s)); fastdiv = 0 (d = 1 or q_end >= 2^31): plain division
     unsigned m_prow, s_prow, m_cy, s_cy;
@@ -993,11 +995,11 @@ __device__ __forceinline__ void edge_slot(int e, int x, int y, int z, int &axis,
 
 // the content of MCL_EDGE_DX / DY / DZ as arithmetic: axis and lower end of each cell edge, five bits per edge
 constexpr unsigned long long MC_EDGE_PACK = 0x538c28e2b00a0a0ull;   // edge e: bits 5e.. = axis (2 bits) | min dx | min dy | min dz
-__device__ __forceinline__ size_t edge_slot_index(int e, int x, int y, int z, size_t nvox, int ny, int nx) {
+__device__ __forceinline__ size_t edge_slot_index(int e, int x, int y, int z, size_t nvox, int ny, int nx, int ring) {
     const unsigned v = e == 12 ? 3u : (unsigned)((MC_EDGE_PACK >> (5 * e)) & 31ull);   // centre vertex: table 3, the cell's own voxel
     const unsigned axis = v & 3u;
     const int vx = x + (int)((v >> 2) & 1u), vy = y + (int)((v >> 3) & 1u), vz = z + (int)((v >> 4) & 1u);
-    return (size_t)axis * nvox + ((size_t)vz * ny + vy) * nx + vx;
+    return (size_t)axis * nvox + ((size_t)(vz % ring) * ny + vy) * nx + vx;
 }
 
 // ---------------------------------------------------------------- pass 4a: vertices, one thread per active cell
@@ -1010,7 +1012,7 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
     if (a >= nactive) return;
     const ActiveCell ac = alist[a];
     if (code_nv(ac.code) == 0) return;   // the cell creates no vertex
-    const size_t nvox = (size_t)d.nx * d.ny * d.nz;
+    const size_t nvox = (size_t)d.nx * d.ny * d.ring;
     int x, y, z;
     cell_xyz(d, (long long)ac.cell, x, y, z);
     Cell cell;
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(THREADS) void mc_vertex_kernel(const float *__restr
             fx += (double)dx2 * w2; fy += (double)dy2 * w2; fz += (double)dz2 * w2; ff += w2;
             px = (double)x + fx / ff; py = (double)y + fy / ff; pz = (double)(z + d.zoff) + fz / ff;
         }
-        evid[edge_slot_index(e, x, y, z, nvox, d.ny, d.nx)] = vid;
+        evid[edge_slot_index(e, x, y, z, nvox, d.ny, d.nx, d.ring)] = vid;
         if (vid < cap_verts) {
             // output order (axis0, axis1, axis2) = (z, y, x)
             verts[3 * (size_t)vid + 0] = (float)pz;
@@ -1098,7 +1100,7 @@ __global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restric
     const int a = blockIdx.x * THREADS + threadIdx.x, tid = threadIdx.x;
     if (a >= nactive) return;
     const ActiveCell ac = alist[a];
-    const size_t nvox = (size_t)d.nx * d.ny * d.nz;
+    const size_t nvox = (size_t)d.nx * d.ny * d.ring;
     int x, y, z;
     cell_xyz(d, (long long)ac.cell, x, y, z);
     const Tiling t = decode_cell(ac.code);
@@ -1110,7 +1112,7 @@ __global__ __launch_bounds__(THREADS) void mc_face_kernel(const float *__restric
 #pragma unroll
     for (int i = 0; i < 36; ++i) e[i] = i < n3 ? (int)t.row[i] : 0;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) vid[i] = i < n3 ? evid[edge_slot_index(e[i], x, y, z, nvox, d.ny, d.nx)] : 0;
+    for (int i = 0; i < 36; ++i) vid[i] = i < n3 ? evid[edge_slot_index(e[i], x, y, z, nvox, d.ny, d.nx, d.ring)] : 0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int tri = ac.tri0 + i;
@@ -1204,7 +1206,7 @@ __global__ __launch_bounds__(THREADS) void mc_face_ids_kernel(Dims d, const Acti
     const int a = blockIdx.x * THREADS + threadIdx.x;
     if (a >= nactive) return;
     const ActiveCell ac = alist[a];
-    const size_t nvox = (size_t)d.nx * d.ny * d.nz;
+    const size_t nvox = (size_t)d.nx * d.ny * d.ring;
     int x, y, z;
     cell_xyz(d, (long long)ac.cell, x, y, z);
     const Tiling t = decode_cell(ac.code);
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(THREADS) void mc_face_ids_kernel(Dims d, const Acti
 #pragma unroll
     for (int i = 0; i < 36; ++i) e[i] = i < n3 ? (int)t.row[i] : 0;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) vid[i] = i < n3 ? evid[edge_slot_index(e[i], x, y, z, nvox, d.ny, d.nx)] : 0;
+    for (int i = 0; i < 36; ++i) vid[i] = i < n3 ? evid[edge_slot_index(e[i], x, y, z, nvox, d.ny, d.nx, d.ring)] : 0;
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int tri = ac.tri0 + i;
@@ -1276,26 +1278,43 @@ using namespace surs::mc;
 
 static int mc_nblocks(long long ncells) { return (int)((ncells + CELLS_PER_BLOCK - 1) / CELLS_PER_BLOCK); }
 
+// The edge -> vertex-id tables are a RING of planes: Lewiner's sweep has axis 0 outermost, a cell layer reads and writes the ids of
+// its two planes only, and every extraction proceeds in contiguous layer ranges - so a range of L layers needs L + 1 planes, and the
+// plane it shares with the next range survives as long as L + 1 <= ring.  MC_RING planes (the streamed extraction advances by at most
+// 64 layers - one launch of the sweep at 512^3); larger ranges, the one-piece extraction included, are walked in chunks of ring - 1
+// layers (mc_chunked).  Until round 4 the tables were dense: 4 x int32[n0 n1 n2] = 2.1 GB per field at 512^3 (now 277 MB), and the
+// active-cell list was sized for every cell of the volume (2.1 GB; now for the cells of one chunk, 272 MB).
+constexpr int MC_RING = 66;
+static int mc_ring(int n0) { return n0 < MC_RING ? n0 : MC_RING; }
+static long long mc_chunk_cells(int n0, int n1, int n2) {   // the most cells one mc_range call processes
+    const int layers = (n0 - 1) < (mc_ring(n0) - 1) ? (n0 - 1) : (mc_ring(n0) - 1);
+    return (long long)layers * (n1 - 1) * (n2 - 1);
+}
+static size_t mc_chunk_blocks(int n0, int n1, int n2) {     // ... and the blocks of padded rows they form
+    const int layers = (n0 - 1) < (mc_ring(n0) - 1) ? (n0 - 1) : (mc_ring(n0) - 1);
+    return (size_t)mc_nblocks((long long)layers * (n1 - 1) * ((n2 - 1 + 3) / 4 * 4));
+}
+
 static size_t mc_ws_layout(int n0, int n1, int n2, size_t off[5]) {
-    const size_t nb = (size_t)mc_nblocks((long long)(n0 - 1) * (n1 - 1) * ((n2 - 1 + 3) / 4 * 4));   // padded rows (mc_scan_block)
-    const size_t nvox = (size_t)n0 * n1 * n2;
+    const size_t nb = mc_chunk_blocks(n0, n1, n2);   // padded rows (mc_scan_block)
+    const size_t nvox = (size_t)mc_ring(n0) * n1 * n2;
     size_t o = 0;
     const size_t ng = (nb + SCAN_GROUP - 1) / SCAN_GROUP;
     off[0] = o; o += align_up(nb * sizeof(BlockSums), 256);         // block sums
     off[1] = o; o += align_up(nb * sizeof(BlockSums), 256);         // block offsets (local to their scan group)
     off[2] = o; o += 256 + align_up(nb * sizeof(float2), 256);      // min/max, totals; per-block min/max
     off[3] = o; o += 3 * align_up(ng * sizeof(BlockSums), 256);     // scan groups: totals, offsets, min/max
-    off[4] = o; o += align_up(4 * nvox * sizeof(int), 256);         // edge -> vertex id tables
-    return o;   // the active-cell list follows; its size is known after pass 2 (worst case: every cell)
+    off[4] = o; o += align_up(4 * nvox * sizeof(int), 256);         // edge -> vertex id tables (ring of planes)
+    return o;   // the active-cell list follows (worst case: every cell of a chunk)
 }
 
 extern "C" size_t surs_mc_workspace_bytes(int n0, int n1, int n2) {
     if (n0 < 2 || n1 < 2 || n2 < 2) return 0;
     size_t off[5];
-    const long long ncells = (long long)(n0 - 1) * (n1 - 1) * (n2 - 1);
-    // the active-cell list (worst case: every cell); the count pass's codes use its upper half, 1024 slots per block of PADDED cells
-    const size_t nb = (size_t)mc_nblocks((long long)(n0 - 1) * (n1 - 1) * ((n2 - 1 + 3) / 4 * 4));
-    const size_t slots = nb * CELLS_PER_BLOCK;
+    const long long ncells = mc_chunk_cells(n0, n1, n2);
+    // the active-cell list (worst case: every cell of a chunk); the count pass's codes use its upper half, 1024 slots per block of
+    // PADDED cells
+    const size_t slots = mc_chunk_blocks(n0, n1, n2) * CELLS_PER_BLOCK;
     return mc_ws_layout(n0, n1, n2, off) + align_up((size_t)ncells * 8 + (slots > (size_t)ncells ? slots : (size_t)ncells) * 8, 256);
 }
 
@@ -1308,6 +1327,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
                     int32_t *faces, int cap_faces, bool count_only, surs_mc_counts *run, hipStream_t st, int zoff = 0) {
     Dims d;
     d.zoff = zoff;
+    d.ring = mc_ring(n0);
     d.nz = n0; d.ny = n1; d.nx = n2;
     d.cz = n0 - 1; d.cy = n1 - 1; d.cx = n2 - 1;
     d.ncells = (long long)d.cz * d.cy * d.cx;
@@ -1322,6 +1342,8 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     d.prow = (d.cx + 3) / 4 * 4;
     const long long per_layer = (long long)d.cy * d.cx;
     SURS_REQUIRE(cell_begin % per_layer == 0 && cell_end % per_layer == 0, "cell range must consist of whole layers");
+    const long long list_cells = mc_chunk_cells(n0, n1, n2);   // capacity of the active-cell list = the cells of the largest range
+    SURS_REQUIRE(cell_end - cell_begin <= list_cells, "range of more than ring - 1 cell layers (mc_chunked splits them)");
     d.q_begin = cell_begin / d.cx * d.prow;
     d.q_end = cell_end / d.cx * d.prow;
     {
@@ -1376,7 +1398,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     SURS_HIP_CHECK(hipMemsetAsync(nan_flag, 0, sizeof(int), st));
     // the count pass's (cell, code) pairs, 1024 slots per block: the upper half of the worst-case active-cell list (8 of 16 bytes
     // per cell) and the row padding behind it (surs_mc_workspace_bytes)
-    uint2 *codes = (uint2 *)(ws + fixed + (size_t)d.ncells * 8);
+    uint2 *codes = (uint2 *)(ws + fixed + (size_t)list_cells * 8);
     hipLaunchKernelGGL(mc_count_kernel, dim3(nb), dim3(SCAN_THREADS), 0, st, vol, d, level, levelf, nb, bcounts, bminmax, nan_flag, codes);
     SURS_LAUNCH_CHECK();
     hipLaunchKernelGGL(mc_scan1_kernel, dim3(ng), dim3(1024), 0, st, bcounts, boffs, nb, gcounts, bminmax, gminmax);
@@ -1401,7 +1423,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     if (run->n_verts > cap_verts || run->n_faces > cap_faces)
         return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
     static const int emit_reclassify = getenv("SURS_MC_EMIT_RECLASSIFY") ? atoi(getenv("SURS_MC_EMIT_RECLASSIFY")) : 0;   // tests
-    if (2ll * nactive > d.ncells || emit_reclassify)   // the sorted list would run into the count pass's codes: classify again
+    if (2ll * nactive > list_cells || emit_reclassify)   // the sorted list would run into the count pass's codes: classify again
         hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 16384 ? nb : 16384), dim3(SCAN_THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs,
                            goffs, alist);
     else
@@ -1421,6 +1443,25 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     return 0;
 }
 
+// [cell_begin, cell_end) in chunks of at most ring - 1 layers (the vertex-id ring holds ring planes).  A chunk that does not fit the
+// output buffers turns the rest of the walk into a counting walk: run ends at the sizes the whole range needs, SURS_E_CAPACITY.
+static int mc_chunked(const float *vol, int n0, int n1, int n2, long long cell_begin, long long cell_end, double level,
+                      void *workspace, size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
+                      int32_t *faces, int cap_faces, bool count_only, surs_mc_counts *run, hipStream_t st, int zoff = 0) {
+    const long long per_layer = (long long)(n1 - 1) * (n2 - 1);
+    const long long step = (long long)((n0 - 1) < (mc_ring(n0) - 1) ? (n0 - 1) : (mc_ring(n0) - 1)) * per_layer;
+    bool overflow = false;
+    for (long long a = cell_begin; a < cell_end; a += step) {
+        const long long b = a + step < cell_end ? a + step : cell_end;
+        const int rc = mc_range(vol, n0, n1, n2, a, b, level, workspace, workspace_bytes, verts, normals, values, cap_verts, faces, cap_faces,
+                                count_only || overflow, run, st, zoff);
+        if (rc == SURS_E_CAPACITY) overflow = true;
+        else if (rc) return rc;
+    }
+    if (overflow) return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
+    return 0;
+}
+
 extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double level, void *workspace,
                                size_t workspace_bytes, float *verts, float *normals, float *values, int cap_verts,
                                int32_t *faces, int cap_faces, surs_mc_counts *counts, void *stream) {
@@ -1437,8 +1478,8 @@ extern "C" int surs_mc_lewiner(const float *vol, int n0, int n1, int n2, double 
     counts->vmax = -FLT_MAX;
     // the level-range and no-surface errors come before the capacity error, as in one pass over the whole volume
     surs_mc_counts probe = *counts;
-    int rc = mc_range(vol, n0, n1, n2, 0, ncells, level, workspace, workspace_bytes, verts, normals, values, cap_verts, faces,
-                      cap_faces, count_only, &probe, st);
+    int rc = mc_chunked(vol, n0, n1, n2, 0, ncells, level, workspace, workspace_bytes, verts, normals, values, cap_verts, faces,
+                        cap_faces, count_only, &probe, st);
     *counts = probe;
     if (rc && rc != SURS_E_CAPACITY) return rc;
     if (level < (double)counts->vmin || level > (double)counts->vmax)
@@ -1462,8 +1503,8 @@ extern "C" int surs_mc_lewiner_range(const float *vol, int n0, int n1, int n2, i
     SURS_REQUIRE(workspace_bytes >= surs_mc_workspace_bytes(n0, n1, n2), "workspace too small");
     SURS_REQUIRE(layer_begin >= 0 && layer_begin <= layer_end && layer_end <= n0 - 1, "bad layer range");
     const long long per_layer = (long long)(n1 - 1) * (n2 - 1);
-    return mc_range(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
-                    normals, values, cap_verts, faces, cap_faces, false, run, as_stream(stream));
+    return mc_chunked(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
+                      normals, values, cap_verts, faces, cap_faces, false, run, as_stream(stream));
 }
 
 extern "C" int surs_mc_lewiner_range_slab(const float *vol, int n0, int n1, int n2, int layer_begin, int layer_end, double level,
@@ -1480,12 +1521,12 @@ extern "C" int surs_mc_lewiner_range_slab(const float *vol, int n0, int n1, int 
         mc_ws_layout(n0, n1, n2, off);
         int *evid = (int *)((char *)workspace + off[4]);
         const int plane = n1 * n2;
-        hipLaunchKernelGGL(mc_slab_refs_kernel, dim3(ceil_div(2 * plane, 256)), dim3(256), 0, st, evid, (size_t)n0 * n1 * n2, plane);
+        hipLaunchKernelGGL(mc_slab_refs_kernel, dim3(ceil_div(2 * plane, 256)), dim3(256), 0, st, evid, (size_t)mc_ring(n0) * n1 * n2, plane);
         SURS_LAUNCH_CHECK();
     }
     const long long per_layer = (long long)(n1 - 1) * (n2 - 1);
-    return mc_range(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
-                    nullptr, nullptr, cap_verts, faces, cap_faces, false, run, st, z_offset);
+    return mc_chunked(vol, n0, n1, n2, layer_begin * per_layer, layer_end * per_layer, level, workspace, workspace_bytes, verts,
+                      nullptr, nullptr, cap_verts, faces, cap_faces, false, run, st, z_offset);
 }
 
 extern "C" int surs_mc_slab_top_ids(const void *workspace, size_t workspace_bytes, int n0, int n1, int n2, int32_t *ids, void *stream) {
@@ -1494,9 +1535,9 @@ extern "C" int surs_mc_slab_top_ids(const void *workspace, size_t workspace_byte
     size_t off[5];
     mc_ws_layout(n0, n1, n2, off);
     const int *evid = (const int *)((const char *)workspace + off[4]);
-    const size_t nvox = (size_t)n0 * n1 * n2, plane = (size_t)n1 * n2;
+    const size_t nvox = (size_t)mc_ring(n0) * n1 * n2, plane = (size_t)n1 * n2;   // (the top plane's slot in the ring of planes)
     for (int axis = 0; axis < 2; ++axis)
-        SURS_HIP_CHECK(hipMemcpyAsync(ids + axis * plane, evid + axis * nvox + (size_t)(n0 - 1) * plane, plane * sizeof(int),
+        SURS_HIP_CHECK(hipMemcpyAsync(ids + axis * plane, evid + axis * nvox + (size_t)((n0 - 1) % mc_ring(n0)) * plane, plane * sizeof(int),
                                       hipMemcpyDeviceToDevice, as_stream(stream)));
     return 0;
 }
