@@ -290,11 +290,25 @@ class HostCopy:
         return [h.numpy() if h is not None else None for h in self._hosts]
 
 
+_shared_streams = {}
+
+
+def shared_stream(device, name):
+    """The process's side stream `name` on `device` (copy stream, one marching-cubes stream per field): ONE set per device, shared
+    by every Workspace.  HIP maps streams onto a handful of hardware queues; a second SuRSNet object with side streams of its own
+    (bench.py's fp32 leg) found its copy stream on the hardware queue of the sweep, and the 1 GB of mesh copies that should travel
+    under the sweep followed it instead: + 19 ms per 512^3 reconstruction (round 4, tools/diag/second_net.py)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), name)
+    st = _shared_streams.get(key)
+    if st is None:
+        st = _shared_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _to_host_async(ws, tensors):
     cur = torch.cuda.current_stream()
-    if getattr(ws, "_copy_stream", None) is None:
-        ws._copy_stream = torch.cuda.Stream(device=ws.device)
-    side = ws._copy_stream
+    side = shared_stream(ws.device, "copy")
     ready = torch.cuda.Event()
     ready.record(cur)
     side.wait_event(ready)
@@ -501,12 +515,10 @@ def _warm_stream_buffers(ws, key):
     del a, b, d
     warm[key] = cap
     # ... and the field's extraction stream: the first use of a HIP stream creates its hardware queue (milliseconds)
-    streams = getattr(ws, "_mc_streams", None)
-    if streams is None:
-        streams = ws._mc_streams = {}
-    if key not in streams:
-        streams[key] = torch.cuda.Stream(device=ws.device)
-        with torch.cuda.stream(streams[key]):
+    known = len(_shared_streams)
+    st = shared_stream(ws.device, ("mc", key))
+    if len(_shared_streams) > known:
+        with torch.cuda.stream(st):
             torch.zeros(1, device=ws.device).cpu()   # (a pageable read-back like the extraction's counts)
 
 
@@ -547,17 +559,10 @@ class MeshStream:
         self.layers = 0          # cell layers (axis 0) extracted so far
         self.sent_v = self.sent_f = 0
         self.overflow = False
-        if getattr(ws, "_copy_stream", None) is None:
-            ws._copy_stream = torch.cuda.Stream(device=dev)
-        self.side = ws._copy_stream
+        self.side = shared_stream(dev, "copy")
         # the extraction runs on a stream of its own (one per field): its kernels and its count read-backs (host syncs)
         # then neither sit between two launches of the sweep nor keep the host from enqueueing the next launch
-        streams = getattr(ws, "_mc_streams", None)
-        if streams is None:
-            streams = ws._mc_streams = {}
-        if key not in streams:
-            streams[key] = torch.cuda.Stream(device=dev)
-        self.mc = streams[key]
+        self.mc = shared_stream(dev, ("mc", key))
         self.mc.wait_stream(torch.cuda.current_stream(dev))   # the buffers above were allocated on the caller's stream
         for t in (self.world, self.faces):
             t.record_stream(self.side)
