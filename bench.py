@@ -331,16 +331,19 @@ def main():
             ijk = np.stack([idx // (R * R), (idx // R) % R, idx % R]).astype(np.float64)
             pts_all = np.matmul(mat4[:3, :3], ijk) + mat4[:3, 3:4]
 
-            def eval_func(points):   # lib/mesh_util.py:20-28
+            def eval_func(points):   # lib/mesh_util.py:20-28 (np.repeat is what makes the strided chunk view contiguous)
                 points = np.expand_dims(points, axis=0)
+                points = np.repeat(points, n32.num_views, axis=0)
                 samples = torch.from_numpy(points).to(device=dev).float()
                 n32.query_mr(samples, calib)
                 n32.query_sr(samples, calib)
                 return n32.get_preds()[0][0].detach().cpu().numpy(), n32.get_preds()[1][0].detach().cpu().numpy()
 
-            def loop():
+            out_hr, out_lr = np.zeros(pts_all.shape[1]), np.zeros(pts_all.shape[1])
+
+            def loop():                # lib/sdf.py:32-45
                 for i in range(pts_all.shape[1] // ns):
-                    eval_func(pts_all[:, i * ns:(i + 1) * ns])
+                    out_hr[i * ns:(i + 1) * ns], out_lr[i * ns:(i + 1) * ns] = eval_func(pts_all[:, i * ns:(i + 1) * ns])
 
             loop()
             torch.cuda.synchronize()

@@ -25,7 +25,8 @@ def full(i, prep):
     samples = prep(i)
     net.query_mr(samples, calib); net.query_sr(samples, calib)
     return net.get_preds()[0][0].detach().cpu().numpy()
-timeit("reference eval_func (f64 strided view -> .to(dev).float())", lambda i: full(i, lambda i: torch.from_numpy(np.expand_dims(sl(i), 0)).to(device=dev).float()))
+timeit("reference eval_func (expand_dims, np.repeat, .to(dev).float())", lambda i: full(i, lambda i: torch.from_numpy(np.repeat(np.expand_dims(sl(i), 0), 1, axis=0)).to(device=dev).float()))
+timeit("WITHOUT np.repeat (f64 strided view -> .to(dev).float())", lambda i: full(i, lambda i: torch.from_numpy(np.expand_dims(sl(i), 0)).to(device=dev).float()))
 timeit("contiguous f64 -> .to(dev).float()", lambda i: full(i, lambda i: torch.from_numpy(np.ascontiguousarray(sl(i))[None]).to(device=dev).float()))
 timeit("f32 host -> .to(dev)", lambda i: full(i, lambda i: torch.from_numpy(np.ascontiguousarray(sl(i), np.float32)[None]).to(device=dev)))
 timeit("H2D only: strided f64 .to(dev).float()", lambda i: torch.from_numpy(np.expand_dims(sl(i), 0)).to(device=dev).float())
