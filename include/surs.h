@@ -120,6 +120,27 @@ int surs_pixel_shuffle2(const float *x, int h, int w, int c4, int x_ld, float sl
 /* y = a + b (+ c, nullable) */
 int surs_add3(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch, float *y,
               int y_ld, void *stream);
+/* GroupNorm(32, C) handed from kernel to kernel (ConvBlock, lib/model/HGFilters.py:57-74: three GroupNorm + ReLU + 3x3 convolutions
+ * and a sum - four launches instead of ten).  A kernel that writes a map leaves the statistics of exactly the values it stored as
+ * partial sums gn_out[32 groups][*gn_out_slots][2] (sum, sum of squares; doubles; *gn_out_slots <= gn_out_capacity is written to
+ * the HOST int; one slot per workgroup, so the layout is a function of the shapes alone); the 3x3 convolution that consumes the map
+ * folds them - every workgroup, in the same fixed order - into surs_groupnorm_coeffs' coefficients (same formulas) and applies
+ * GroupNorm(gamma, beta, eps) + ReLU while staging.  Deterministic: no atomics.
+ *   surs_conv2d_nhwc_gn: surs_conv2d_nhwc_x2 (parts = 2) / _x1 (parts = 1), 3x3; gn_in (nullable) = the statistics of x with their
+ *   slot count, gamma / beta [cin], 32 | cin; gn_out (nullable) as above, cout / 32 a power of two <= 32 (a buffer of
+ *   ceil(w / 32) * ceil(h / 4) slots always suffices).
+ *   surs_avgpool2_gn / surs_bicubic_up2_gn / surs_add3_gn: the elementwise kernels, the same values bit for bit, plus gn_out
+ *   (C a power of two in [32, 1024], 16-byte aligned rows; at most 512 slots). */
+int surs_conv2d_nhwc_gn(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias, float *y,
+                        int cout, int y_ld, int ksize, int stride, const double *gn_in, int gn_in_slots, const float *gamma,
+                        const float *beta, float eps, int act, float slope, const float *residual, int res_ld, double *gn_out,
+                        int gn_out_capacity, int *gn_out_slots, void *stream);
+int surs_avgpool2_gn(const float *x, int h, int w, int c, int x_ld, float *y, int y_ld, double *gn_out, int gn_out_capacity,
+                     int *gn_out_slots, void *stream);
+int surs_bicubic_up2_gn(const float *x, int h, int w, int c, int x_ld, int align_corners, const float *addend, int add_ld, float *y,
+                        int y_ld, double *gn_out, int gn_out_capacity, int *gn_out_slots, void *stream);
+int surs_add3_gn(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch, float *y, int y_ld,
+                 double *gn_out, int gn_out_capacity, int *gn_out_slots, void *stream);
 /* Input stage of the test path (lib/data/EvalDataset_LR_v2.py:227-243): rgb uint8 [h][w][3], mask uint8 [h][w] (device) ->
  * y[h][w][0:3] (pitch y_ld) = (mask / 255) * ((rgb / 255 - 0.5) / 0.5), float32, the reference's operations in its order
  * (ToTensor, Normalize(0.5, 0.5), mask multiply): bit-identical to its img_LR, already in the encoder's NHWC layout. */

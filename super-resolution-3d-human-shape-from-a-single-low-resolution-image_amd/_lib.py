@@ -65,6 +65,11 @@ _SIGS = {
     "surs_conv_pack_weights_x2": (_sz, [_vp, _i, _i, _i, _vp]),
     "surs_conv_tile_scale": (C.c_int, [_i, _i]),
     "surs_conv2d_nhwc_x1": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),
+    "surs_conv2d_nhwc_gn": (C.c_int, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f, _i, _f, _vp, _i,
+                                      _vp, _i, C.POINTER(C.c_int), _vp]),
+    "surs_avgpool2_gn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int), _vp]),
+    "surs_bicubic_up2_gn": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int), _vp]),
+    "surs_add3_gn": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int), _vp]),
     "surs_mlp_pack": (_sz, [_vp, _vp, _vp, _vp, _i, _vp]),
     "surs_set_operand_split": (C.c_int, [_i]),
     "surs_set_operand_split_local": (C.c_int, [_i]),

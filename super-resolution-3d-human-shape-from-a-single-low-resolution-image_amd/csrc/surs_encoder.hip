@@ -42,6 +42,13 @@ struct ConvArgs {
     const float *in_scale, *in_shift;
     int act; float slope;
     const float *res; int res_ld;
+    // GroupNorm(32) carried between kernels (conv_x3_kernel only; null = not used).  gn_in: the statistics of x as partial sums
+    // [32 groups][gn_in_slots][2] (sum, sum of squares: doubles) left by the kernel that produced x; every workgroup folds them, in a
+    // fixed order, into the scale / shift of GroupNorm(gamma, beta, eps) + ReLU that its staging applies - instead of in_scale /
+    // in_shift from surs_groupnorm_coeffs' two launches.  gn_out: the same partial sums of THIS kernel's output, one slot per
+    // pixel tile (blockIdx.y * gridDim.x + blockIdx.x), for the GroupNorm(32, cout) that follows.
+    const double *gn_in; int gn_in_slots; const float *gamma, *beta; float eps;
+    double *gn_out;
 };
 
 template <int KS, int STRIDE, int TR, int NT>
@@ -237,6 +244,57 @@ template <> struct ConvSplit<1> {
     static __device__ __forceinline__ void split(float x, unsigned short (&p)[1]) { p[0] = __builtin_bit_cast(unsigned short, (_Float16)x); }
 };
 
+// GroupNorm(32) statistics handed over by the producer of x (ConvArgs::gn_in) -> per-channel scale at gn[c], shift at
+// gn[shift_off + c], by all 256 threads of a workgroup: eight threads per group, thread `sub` adds the slots sub, sub + 8, ... in
+// order (eight loads in flight), then a butterfly over the eight - a fixed summation tree, the same in every workgroup of every
+// launch - then gn_finish_kernel's arithmetic.  cin is a multiple of 32: no pad channels.  The caller synchronises.
+__device__ __forceinline__ void gn_fold_to_lds(const ConvArgs &a, float *gn, int shift_off, int tid) {
+    const int g = tid >> 3, sub = tid & 7, cgi = a.cin / 32, slots = a.gn_in_slots;
+    const double2 *pg = reinterpret_cast<const double2 *>(a.gn_in) + (size_t)g * slots;
+    double S = 0, SS = 0;
+    for (int base = 0; base < slots; base += 64) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = base + sub + 8 * u;
+            v[u] = sl < slots ? pg[sl] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            S += v[u].x;
+            SS += v[u].y;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        S += __shfl_xor(S, o);
+        SS += __shfl_xor(SS, o);
+    }
+    const double n = (double)a.h * (double)a.w * cgi;
+    const double mean = S / n;
+    double var = SS / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)a.eps);
+    for (int k = sub; k < cgi; k += 8) {
+        const int ch = g * cgi + k;
+        gn[ch] = (float)(rstd * a.gamma[ch]);
+        gn[shift_off + ch] = (float)(a.beta[ch] - mean * rstd * a.gamma[ch]);
+    }
+}
+
+// The statistics of the values a workgroup stored (ConvArgs::gn_out), from the MFMA epilogue layout of both convolution kernels:
+// lane & 31 = channel co0 + (lane & 31) of a 32-channel tile, this lane's sums S, SS over its pixels.  Folds the two pixel halves
+// (lanes l, l + 32) and the cg = cout / 32 (a power of two <= 32) channels of a group (neighbouring lanes); lanes < 32 with
+// (lane & (cg - 1)) == 0 then hold the sums of group (co0 + lane) / cg.
+__device__ __forceinline__ void gn_fold_lanes(double &S, double &SS, int cg) {
+    S += __shfl_xor(S, 32);
+    SS += __shfl_xor(SS, 32);
+    for (int o = 1; o < cg; o <<= 1) {
+        S += __shfl_xor(S, o);
+        SS += __shfl_xor(SS, o);
+    }
+}
+
 #ifdef SURS_CONV_TRACE
 __device__ unsigned long long g_conv_trace[8];
 #define CSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) { unsigned long long t_ = __builtin_readcyclecounter(); g_conv_trace[i] += t_ - tprev; tprev = t_; } } while (0)
@@ -275,13 +333,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[s_][r][j][q] = 0.0f;
 
-    if (a.in_scale) {   // once per workgroup: read per element from global memory they stall every chunk's staging
-        for (int c = tid; c < a.cin_pad; c += 256) {
-            gn[c] = c < a.cin ? a.in_scale[c] : 0.f;
-            gn[a.cin_pad + c] = c < a.cin ? a.in_shift[c] : 0.f;
-        }
-        __syncthreads();
-    }
+    const bool norm = a.in_scale != nullptr || a.gn_in != nullptr;   // GroupNorm-apply + ReLU in the staging
     // A chunk's MFMAs take ~1.7 k cycles, less than a global-memory round trip: the next chunk's patch and weight
     // slices are fetched into registers while the current chunk multiplies, and split / stored to LDS afterwards.
     constexpr int NPI = (PR * PC * (CK / 4) + 255) / 256;   // patch items per thread (4 channels of one pixel each)
@@ -355,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     auto stage = [&](int ch, int pb) {
         const int c0 = ch * CK;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (a.in_scale) {
+        if (norm) {
             sc = *reinterpret_cast<const f32x4 *>(gn + c0 + cq);
             sh = *reinterpret_cast<const f32x4 *>(gn + a.cin_pad + c0 + cq);
         }
@@ -366,7 +418,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v = pre_x[pb][k][q];
-                if (a.in_scale) v = fmaxf(v * sc[q] + sh[q], 0.f);
+                if (norm) v = fmaxf(v * sc[q] + sh[q], 0.f);
                 v = px_ok[k] ? v : 0.f;   // zero padding is applied after the norm
                 unsigned short parts[NP];
                 CS::split(v, parts);
@@ -384,6 +436,17 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     };
     fetch(0, 0);
     if (PD == 2 && nch > 1) fetch(1, 1);
+    // (behind the first chunks' loads: their latency covers the fold)
+    if (a.in_scale) {   // once per workgroup: read per element from global memory they stall every chunk's staging
+        for (int c = tid; c < a.cin_pad; c += 256) {
+            gn[c] = c < a.cin ? a.in_scale[c] : 0.f;
+            gn[a.cin_pad + c] = c < a.cin ? a.in_shift[c] : 0.f;
+        }
+        __syncthreads();
+    } else if (a.gn_in) {
+        gn_fold_to_lds(a, gn, a.cin_pad, tid);
+        __syncthreads();
+    }
 #ifdef SURS_CONV_TRACE
     unsigned long long tprev = __builtin_readcyclecounter();
     if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) for (int i = 0; i < 8; ++i) g_conv_trace[i] = 0;
@@ -445,6 +508,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     }
     // ---- epilogue: register q of a tile is pixel column (q&3) + 8*(q>>2) + 4*(lane>>5), lane&31 is the channel
     const int kh = lane >> 5, li = lane & 31;
+    const bool stats = a.gn_out != nullptr;
+    double st_s[NJ], st_ss[NJ];   // this lane's sums of the values it stores, per channel tile
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) st_s[j] = st_ss[j] = 0.0;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int oy = oy0 + wave * RPW + r;
@@ -465,6 +532,42 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
                 const size_t pix = (size_t)oy * a.wo + ox;
                 if (a.res) t += a.res[pix * a.res_ld + co];
                 a.y[pix * a.y_ld + co] = t;
+                if (stats) {
+                    const double d = (double)t;
+                    st_s[j] += d;
+                    st_ss[j] += d * d;
+                }
+            }
+        }
+    }
+    if (stats) {
+        // fold: the two pixel halves of a channel (lanes l, l + 32), the cg = cout / 32 (a power of two <= 32) channels of a group
+        // (neighbouring lanes), the four waves (rows) through LDS - every step in a fixed order; one slot per pixel tile
+        const int cg = a.cout / 32, gpt = 32 / cg;
+        double *red = reinterpret_cast<double *>(lds16);   // [4 waves][NJ][32][2] (the chunk loop ended with a barrier)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            double S = st_s[j], SS = st_ss[j];
+            gn_fold_lanes(S, SS, cg);
+            if (lane < 32 && (li & (cg - 1)) == 0) {
+                red[((wave * NJ + j) * 32 + li / cg) * 2] = S;
+                red[((wave * NJ + j) * 32 + li / cg) * 2 + 1] = SS;
+            }
+        }
+        __syncthreads();
+        if (tid < NJ * gpt) {
+            const int j = tid / gpt, k = tid - j * gpt;
+            const int g = (n0 + j * 32) / cg + k;
+            if (g < 32) {
+                double S = 0, SS = 0;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    S += red[((wv * NJ + j) * 32 + k) * 2];
+                    SS += red[((wv * NJ + j) * 32 + k) * 2 + 1];
+                }
+                const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x, slots = (size_t)gridDim.x * gridDim.y;
+                a.gn_out[((size_t)g * slots + slot) * 2] = S;
+                a.gn_out[((size_t)g * slots + slot) * 2 + 1] = SS;
             }
         }
     }
@@ -528,7 +631,7 @@ template <int CT>
 __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
     typedef ConvSplit<2> CS;
     typedef typename CS::vec8 vec8;
-    __shared__ float gn[2 * 1024];
+    __shared__ __attribute__((aligned(16))) float gn[2 * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ph = wave & 1, ch = wave >> 1, li = lane & 31, kh = lane >> 5;
     const long long npix = (long long)a.h * a.w;
@@ -536,11 +639,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
     const int n0 = blockIdx.y * (64 * CT) + 32 * CT * ch;
     const int nch = a.cin_pad / CK;
     const size_t per_part = (size_t)nch * a.cout_pad * 16;
+    const bool norm = a.in_scale != nullptr || a.gn_in != nullptr;
     if (a.in_scale) {
         for (int c = tid; c < a.cin_pad; c += 256) {
             gn[c] = c < a.cin ? a.in_scale[c] : 0.f;
             gn[1024 + c] = c < a.cin ? a.in_shift[c] : 0.f;
         }
+        __syncthreads();
+    } else if (a.gn_in) {
+        gn_fold_to_lds(a, gn, 1024, tid);
         __syncthreads();
     }
     f32x16 acc[2][CT];
@@ -585,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float v = xa[t][q >> 2][q & 3];
-                if (a.in_scale) v = fmaxf(v * gn[s * CK + 8 * kh + q] + gn[1024 + s * CK + 8 * kh + q], 0.f);
+                if (norm) v = fmaxf(v * gn[s * CK + 8 * kh + q] + gn[1024 + s * CK + 8 * kh + q], 0.f);
                 v = ok[t] ? v : 0.f;
                 unsigned short parts[2];
                 CS::split(v, parts);
@@ -619,6 +726,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
         }
     }
     // ---- epilogue: register q of a tile is pixel (q & 3) + 8 (q >> 2) + 4 (lane >> 5) of the tile, lane & 31 is the channel
+    const bool stats = a.gn_out != nullptr;
+    double st_s[CT], st_ss[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) st_s[j] = st_ss[j] = 0.0;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -634,8 +745,41 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
                 if (a.act == 1) v = v > 0.f ? v : a.slope * v;
                 if (a.res) v += a.res[(size_t)pix * a.res_ld + co];
                 a.y[(size_t)pix * a.y_ld + co] = v;
+                if (stats) {
+                    const double d = (double)v;
+                    st_s[j] += d;
+                    st_ss[j] += d * d;
+                }
             }
         }
+    if (stats) {
+        // as in conv_x3_kernel: lanes, then the two pixel halves of the workgroup (waves ph = 0, 1) through LDS; one slot per
+        // 128-pixel block (blockIdx.x)
+        const int cg = a.cout / 32, gpt = 32 / cg;
+        __syncthreads();   // (everybody is done with gn[])
+        double *red = reinterpret_cast<double *>(gn);   // [4 waves][CT][32][2] doubles = 8 KB at CT = 4: the 8 KB of gn[]
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            double S = st_s[j], SS = st_ss[j];
+            gn_fold_lanes(S, SS, cg);
+            if (lane < 32 && (li & (cg - 1)) == 0) {
+                red[((wave * CT + j) * 32 + li / cg) * 2] = S;
+                red[((wave * CT + j) * 32 + li / cg) * 2 + 1] = SS;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * CT * gpt) {   // (channel half chh, tile j, group k of the tile)
+            const int chh = tid / (CT * gpt), j = (tid / gpt) % CT, k = tid % gpt;
+            const int g = (blockIdx.y * (64 * CT) + 32 * CT * chh + 32 * j) / cg + k;
+            if (g < 32) {
+                const int w0 = 2 * chh, w1 = 2 * chh + 1;   // the waves (ph = 0, 1) of this channel half
+                const double S = red[((w0 * CT + j) * 32 + k) * 2] + red[((w1 * CT + j) * 32 + k) * 2];
+                const double SS = red[((w0 * CT + j) * 32 + k) * 2 + 1] + red[((w1 * CT + j) * 32 + k) * 2 + 1];
+                a.gn_out[((size_t)g * gridDim.x + blockIdx.x) * 2] = S;
+                a.gn_out[((size_t)g * gridDim.x + blockIdx.x) * 2 + 1] = SS;
+            }
+        }
+    }
 }
 
 static int launch_conv1x1_x2(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
@@ -903,11 +1047,13 @@ __global__ void add3_kernel(const float *__restrict__ a, int a_ld, const float *
 // order, so the same bits): used when the channel count, every row pitch and every base address are multiples of 4 floats.  The scalar
 // forms above ran at 0.1 - 1.4 TB/s (one 4-byte access per thread, 64-bit divisions per element).
 
-__global__ __launch_bounds__(256) void avgpool2_vec4_kernel(const float *__restrict__ x, int h, int w, int c, int x_ld,
-                                                            float *__restrict__ y, int y_ld) {
+// (each of the three kernels below as a functor: item i = 4 consecutive channels of one output pixel, computed, stored and returned -
+//  the plain kernel and the form that also leaves GroupNorm statistics of the output run the same instructions per element)
+struct AvgPool2Op {
+    const float *x; int h, w, c, x_ld; float *y; int y_ld;
+    __device__ __forceinline__ unsigned items() const { return (unsigned)(h / 2) * (w / 2) * (c / 4); }
+    __device__ __forceinline__ f32x4 operator()(unsigned i) const {
     const int wo = w / 2, c4 = c / 4;
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (unsigned)(h / 2) * wo * c4) return;
     const unsigned pix = i / c4, q = i - pix * c4, oy = pix / wo, ox = pix - oy * wo;
     const float *p = x + ((size_t)(2 * oy) * w + 2 * ox) * x_ld + 4 * q;
     const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + x_ld);
@@ -916,14 +1062,15 @@ __global__ __launch_bounds__(256) void avgpool2_vec4_kernel(const float *__restr
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = (a[k] + b[k] + cc[k] + dd[k]) * 0.25f;
     *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = r;
-}
+    return r;
+    }
+};
 
-__global__ __launch_bounds__(256) void bicubic_up2_vec4_kernel(const float *__restrict__ x, int h, int w, int c, int x_ld,
-                                                               int align_corners, const float *__restrict__ addend, int add_ld,
-                                                               float *__restrict__ y, int y_ld) {
+struct BicubicUp2Op {
+    const float *x; int h, w, c, x_ld, align_corners; const float *addend; int add_ld; float *y; int y_ld;
+    __device__ __forceinline__ unsigned items() const { return (unsigned)(2 * h) * (2 * w) * (c / 4); }
+    __device__ __forceinline__ f32x4 operator()(unsigned i) const {
     const int ho = 2 * h, wo = 2 * w, c4 = c / 4;
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= (unsigned)ho * wo * c4) return;
     const unsigned pix = i / c4, q = i - pix * c4;
     const int oy = (int)(pix / wo), ox = (int)(pix - (unsigned)oy * wo);
     const float sy = align_corners ? (ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f) : 0.5f;
@@ -955,7 +1102,9 @@ __global__ __launch_bounds__(256) void bicubic_up2_vec4_kernel(const float *__re
         for (int k = 0; k < 4; ++k) acc[k] = ad[k] + acc[k];
     }
     *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = acc;
-}
+    return acc;
+    }
+};
 
 // one thread = one INPUT pixel x 16 consecutive input channels = 4 output channels of its 2 x 2 output pixels
 __global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *__restrict__ x, int h, int w, int c4, int x_ld, float slope,
@@ -982,12 +1131,11 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *_
         }
 }
 
-__global__ __launch_bounds__(256) void add3_vec4_kernel(const float *__restrict__ a, int a_ld, const float *__restrict__ b, int b_ld,
-                                                        const float *__restrict__ c, int c_ld, unsigned hw, int ch,
-                                                        float *__restrict__ y, int y_ld) {
+struct Add3Op {
+    const float *a; int a_ld; const float *b; int b_ld; const float *c; int c_ld; unsigned hw; int ch; float *y; int y_ld;
+    __device__ __forceinline__ unsigned items() const { return hw * (unsigned)(ch / 4); }
+    __device__ __forceinline__ f32x4 operator()(unsigned i) const {
     const int c4 = ch / 4;
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= hw * (unsigned)c4) return;
     const unsigned pix = i / c4, q = i - pix * c4;
     const f32x4 va = *reinterpret_cast<const f32x4 *>(a + (size_t)pix * a_ld + 4 * q);
     const f32x4 vb = *reinterpret_cast<const f32x4 *>(b + (size_t)pix * b_ld + 4 * q);
@@ -1000,6 +1148,60 @@ __global__ __launch_bounds__(256) void add3_vec4_kernel(const float *__restrict_
         for (int k = 0; k < 4; ++k) t[k] += vc[k];
     }
     *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = t;
+    return t;
+    }
+};
+
+template <class Op>
+__global__ __launch_bounds__(256) void vec4_kernel(Op op) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < op.items()) op(i);
+}
+
+// The same, and the GroupNorm(32, c) statistics of the output as partial sums [32][gridDim.x][2] (ConvArgs::gn_out): workgroups of
+// 1024 threads (few slots for the consumer's fold, still enough threads in flight), a grid-stride loop over the items; c / 4 divides
+// 1024, so a thread keeps its channel quad.  Fold: eight threads per group, thread `sub` adds the pixel lanes sub, sub + 8, ... of the
+// group's channels in order, then a butterfly - fixed order.
+constexpr int VS_THREADS = 1024;
+template <class Op>
+__global__ __launch_bounds__(VS_THREADS) void vec4_stats_kernel(Op op, int c, double *__restrict__ partial) {
+    __shared__ double red[VS_THREADS][8];
+    const int tid = threadIdx.x, c4 = c / 4, cg = c / 32, ppl = VS_THREADS / c4;
+    const unsigned n = op.items();
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (unsigned i = blockIdx.x * (unsigned)VS_THREADS + tid; i < n; i += gridDim.x * (unsigned)VS_THREADS) {
+        const f32x4 v = op(i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double d = v[k];
+            s[k] += d;
+            ss[k] += d * d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid][k] = s[k];
+        red[tid][4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int g = tid >> 3, sub = tid & 7;
+        double S = 0, SS = 0;
+        for (int l = sub; l < ppl; l += 8)
+            for (int chn = g * cg; chn < (g + 1) * cg; ++chn) {
+                S += red[l * c4 + chn / 4][chn % 4];
+                SS += red[l * c4 + chn / 4][4 + chn % 4];
+            }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            S += __shfl_xor(S, o);
+            SS += __shfl_xor(SS, o);
+        }
+        if (sub == 0) {
+            partial[((size_t)g * gridDim.x + blockIdx.x) * 2 + 0] = S;
+            partial[((size_t)g * gridDim.x + blockIdx.x) * 2 + 1] = SS;
+        }
+    }
 }
 
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int c, size_t hw, float *__restrict__ y, int y_ld) {
@@ -1036,7 +1238,7 @@ extern "C" int surs_conv2d_nhwc(const float *x, int h, int w, int cin, int x_ld,
     SURS_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "ksize must be 1 or 3, stride 1 or 2");
     SURS_REQUIRE(!(ksize == 1 && stride != 1), "1x1 convolution with stride 2 is not on the path");
     SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
-    ConvArgs a;
+    ConvArgs a{};
     a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
     a.wp = wpacked; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
     a.bias = bias;
@@ -1076,7 +1278,7 @@ extern "C" int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_
                  "the split-bf16 kernel needs cin %% 16 == 0 and 16-byte aligned pixels");
     SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
     SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
-    ConvArgs a;
+    ConvArgs a{};
     a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
     a.wp = nullptr; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
     a.bias = bias;
@@ -1087,9 +1289,13 @@ extern "C" int surs_conv2d_nhwc_x3(const float *x, int h, int w, int cin, int x_
     return launch_conv_x3<3, 1, 3>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
+struct GnLink {   // GroupNorm(32) statistics handed from kernel to kernel (ConvArgs)
+    const double *in; int in_slots; const float *gamma, *beta; float eps;
+    double *out; int out_capacity; int *out_slots;
+};
 static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
                             float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale, const float *in_shift, int act,
-                            float slope, const float *residual, int res_ld, void *stream);
+                            float slope, const float *residual, int res_ld, void *stream, const GnLink *gn = nullptr);
 
 extern "C" int surs_conv2d_nhwc_x2(const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
                                    float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
@@ -1107,10 +1313,20 @@ extern "C" int surs_conv2d_nhwc_x1(const float *x, int h, int w, int cin, int x_
                             res_ld, stream);
 }
 
+extern "C" int surs_conv2d_nhwc_gn(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                                   float *y, int cout, int y_ld, int ksize, int stride, const double *gn_in, int gn_in_slots,
+                                   const float *gamma, const float *beta, float eps, int act, float slope, const float *residual,
+                                   int res_ld, double *gn_out, int gn_out_capacity, int *gn_out_slots, void *stream) {
+    SURS_REQUIRE(parts == 1 || parts == 2, "one or two f16 parts");
+    GnLink gn = {gn_in, gn_in_slots, gamma, beta, eps, gn_out, gn_out_capacity, gn_out_slots};
+    return conv2d_split_f16(parts, x, h, w, cin, x_ld, wsplit, bias, y, cout, y_ld, ksize, stride, nullptr, nullptr, act, slope, residual,
+                            res_ld, stream, &gn);
+}
+
 static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
                                    float *y, int cout, int y_ld, int ksize, int stride, const float *in_scale,
                                    const float *in_shift, int act, float slope, const float *residual, int res_ld,
-                                   void *stream) {
+                                   void *stream, const GnLink *gn) {
     SURS_REQUIRE(x && wsplit && y, "null argument");
     SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y_ld >= cout, "bad sizes");
     SURS_REQUIRE((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1),
@@ -1119,7 +1335,7 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
                  "the split-f16 kernels need cin %% 16 == 0 and 16-byte aligned pixels");
     SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
     SURS_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "in_scale / in_shift must come together");
-    ConvArgs a;
+    ConvArgs a{};
     a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
     a.wp = nullptr; a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
     a.bias = bias;
@@ -1127,6 +1343,25 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
     a.in_scale = in_scale; a.in_shift = in_shift;
     a.act = act; a.slope = slope;
     a.res = residual; a.res_ld = res_ld;
+    if (gn) {
+        if (gn->in) {
+            SURS_REQUIRE(!in_scale, "GroupNorm input: either coefficients or statistics");
+            SURS_REQUIRE(gn->gamma && gn->beta && gn->in_slots > 0 && cin % 32 == 0 && cin <= 1024, "bad GroupNorm(32) input statistics");
+            a.gn_in = gn->in; a.gn_in_slots = gn->in_slots; a.gamma = gn->gamma; a.beta = gn->beta; a.eps = gn->eps;
+        }
+        if (gn->out) {
+            const int cg = cout / 32;
+            SURS_REQUIRE(gn->out_slots && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0,
+                         "GroupNorm(32) output statistics: cout / 32 must be a power of two <= 32");
+            // one slot per pixel tile of the launch below (launch_conv_x3's choice, restated)
+            const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
+            const bool big = stride == 1 && (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= 512;
+            const int slots = ksize == 1 ? (int)(((long long)a.ho * a.wo + 127) / 128) : ceil_div(a.wo, TC) * ceil_div(a.ho, big ? 8 : 4);
+            SURS_REQUIRE(slots <= gn->out_capacity, "GroupNorm statistics buffer too small: %d slots needed", slots);
+            *gn->out_slots = slots;
+            a.gn_out = gn->out;
+        }
+    }
     if (ksize == 1) return launch_conv1x1_x2(a, (const unsigned short *)wsplit, as_stream(stream));   // (HBM-bound: two parts always)
     // stride 2 (the three down-sampling convolutions of the super-resolution net): the 4-row x 32-channel tile, whose 9 x 65 pixel
     // patch fits the LDS
@@ -1203,8 +1438,8 @@ extern "C" int surs_scale_shift_act(const float *x, int hw, int c, int x_ld, con
 extern "C" int surs_avgpool2(const float *x, int h, int w, int c, int x_ld, float *y, int y_ld, void *stream) {
     SURS_REQUIRE(x && y && h >= 2 && w >= 2, "bad argument");
     if (c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (size_t)(h / 2) * (w / 2) * (c / 4) < (1ull << 32))
-        hipLaunchKernelGGL(avgpool2_vec4_kernel, dim3(blocks_for((size_t)(h / 2) * (w / 2) * (c / 4))), dim3(256), 0, as_stream(stream), x,
-                           h, w, c, x_ld, y, y_ld);
+        hipLaunchKernelGGL(vec4_kernel<AvgPool2Op>, dim3(blocks_for((size_t)(h / 2) * (w / 2) * (c / 4))), dim3(256), 0, as_stream(stream),
+                           AvgPool2Op{x, h, w, c, x_ld, y, y_ld});
     else
         hipLaunchKernelGGL(avgpool2_kernel, dim3(blocks_for((size_t)(h / 2) * (w / 2) * c)), dim3(256), 0, as_stream(stream), x, h, w, c,
                            x_ld, y, y_ld);
@@ -1217,8 +1452,8 @@ extern "C" int surs_bicubic_up2(const float *x, int h, int w, int c, int x_ld, i
     SURS_REQUIRE(x && y && h > 0 && w > 0, "bad argument");
     if (c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (!addend || vec4_fits(addend, add_ld)) &&
         (size_t)4 * h * w * (c / 4) < (1ull << 32))
-        hipLaunchKernelGGL(bicubic_up2_vec4_kernel, dim3(blocks_for((size_t)4 * h * w * (c / 4))), dim3(256), 0, as_stream(stream), x, h,
-                           w, c, x_ld, align_corners, addend, add_ld, y, y_ld);
+        hipLaunchKernelGGL(vec4_kernel<BicubicUp2Op>, dim3(blocks_for((size_t)4 * h * w * (c / 4))), dim3(256), 0, as_stream(stream),
+                           BicubicUp2Op{x, h, w, c, x_ld, align_corners, addend, add_ld, y, y_ld});
     else
         hipLaunchKernelGGL(bicubic_up2_kernel, dim3(blocks_for((size_t)4 * h * w * c)), dim3(256), 0, as_stream(stream), x, h, w, c, x_ld,
                            align_corners, addend, add_ld, y, y_ld);
@@ -1244,13 +1479,57 @@ extern "C" int surs_add3(const float *a, int a_ld, const float *b, int b_ld, con
     SURS_REQUIRE(a && b && y, "bad argument");
     if (ch % 4 == 0 && vec4_fits(a, a_ld) && vec4_fits(b, b_ld) && (!c || vec4_fits(c, c_ld)) && vec4_fits(y, y_ld) &&
         (size_t)hw * (ch / 4) < (1ull << 32))
-        hipLaunchKernelGGL(add3_vec4_kernel, dim3(blocks_for((size_t)hw * (ch / 4))), dim3(256), 0, as_stream(stream), a, a_ld, b, b_ld,
-                           c, c_ld, (unsigned)hw, ch, y, y_ld);
+        hipLaunchKernelGGL(vec4_kernel<Add3Op>, dim3(blocks_for((size_t)hw * (ch / 4))), dim3(256), 0, as_stream(stream),
+                           Add3Op{a, a_ld, b, b_ld, c, c_ld, (unsigned)hw, ch, y, y_ld});
     else
         hipLaunchKernelGGL(add3_kernel, dim3(blocks_for((size_t)hw * ch)), dim3(256), 0, as_stream(stream), a, a_ld, b, b_ld, c, c_ld,
                            (size_t)hw, ch, y, y_ld);
     SURS_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- the three map-sized elementwise kernels of the hourglass, leaving the GroupNorm(32, c) statistics of their output for the
+// ConvBlock that follows (surs_conv2d_nhwc_gn's gn_in): partial sums [32][*slots][2], *slots <= capacity written to the host
+template <class Op>
+static int launch_vec4_stats(const Op &op, size_t items, int c, double *gn_out, int capacity, int *slots, void *stream) {
+    SURS_REQUIRE(gn_out && slots && capacity >= 1, "null statistics buffer");
+    SURS_REQUIRE(c % 32 == 0 && c <= 1024 && (c & (c - 1)) == 0, "GroupNorm(32) statistics: the channel count must be a power of two in [32, 1024]");
+    SURS_REQUIRE(items < (1ull << 32), "map too large");
+    const size_t want = (items + VS_THREADS - 1) / VS_THREADS;
+    size_t nn = want;
+    if (nn > (size_t)capacity) nn = (size_t)capacity;
+    if (nn > (size_t)GN_SPLIT) nn = (size_t)GN_SPLIT;
+    const int n = (int)nn;
+    *slots = n;
+    hipLaunchKernelGGL(vec4_stats_kernel<Op>, dim3(n), dim3(VS_THREADS), 0, as_stream(stream), op, c, gn_out);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int surs_avgpool2_gn(const float *x, int h, int w, int c, int x_ld, float *y, int y_ld, double *gn_out, int gn_out_capacity,
+                                int *gn_out_slots, void *stream) {
+    SURS_REQUIRE(x && y && h >= 2 && w >= 2, "bad argument");
+    SURS_REQUIRE(c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld), "the statistics form needs 16-byte aligned rows");
+    return launch_vec4_stats(AvgPool2Op{x, h, w, c, x_ld, y, y_ld}, (size_t)(h / 2) * (w / 2) * (c / 4), c, gn_out, gn_out_capacity,
+                             gn_out_slots, stream);
+}
+
+extern "C" int surs_bicubic_up2_gn(const float *x, int h, int w, int c, int x_ld, int align_corners, const float *addend, int add_ld,
+                                   float *y, int y_ld, double *gn_out, int gn_out_capacity, int *gn_out_slots, void *stream) {
+    SURS_REQUIRE(x && y && h > 0 && w > 0, "bad argument");
+    SURS_REQUIRE(c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (!addend || vec4_fits(addend, add_ld)),
+                 "the statistics form needs 16-byte aligned rows");
+    return launch_vec4_stats(BicubicUp2Op{x, h, w, c, x_ld, align_corners, addend, add_ld, y, y_ld}, (size_t)4 * h * w * (c / 4), c, gn_out,
+                             gn_out_capacity, gn_out_slots, stream);
+}
+
+extern "C" int surs_add3_gn(const float *a, int a_ld, const float *b, int b_ld, const float *c, int c_ld, int hw, int ch, float *y, int y_ld,
+                            double *gn_out, int gn_out_capacity, int *gn_out_slots, void *stream) {
+    SURS_REQUIRE(a && b && y && hw > 0, "bad argument");
+    SURS_REQUIRE(ch % 4 == 0 && vec4_fits(a, a_ld) && vec4_fits(b, b_ld) && (!c || vec4_fits(c, c_ld)) && vec4_fits(y, y_ld),
+                 "the statistics form needs 16-byte aligned rows");
+    return launch_vec4_stats(Add3Op{a, a_ld, b, b_ld, c, c_ld, (unsigned)hw, ch, y, y_ld}, (size_t)hw * (ch / 4), ch, gn_out,
+                             gn_out_capacity, gn_out_slots, stream);
 }
 
 extern "C" int surs_nchw_to_nhwc(const float *x, int c, int h, int w, float *y, int y_ld, void *stream) {

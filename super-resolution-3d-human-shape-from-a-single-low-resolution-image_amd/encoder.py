@@ -77,6 +77,13 @@ class EncoderWeights:
             if s < opt.num_stack_lr - 1:
                 add_conv(L + "bl%d" % s)
                 add_conv(L + "al%d" % s)
+                # previous + bl(t) + al(l(t)) (HGFilters.py:203-206) is ONE pointwise convolution of t - nothing non-linear sits
+                # between l and al: W = W_bl + W_al W_l, b = b_bl + W_al b_l + b_al, formed in float64 (filter_lr)
+                wl, bl_ = get(L + "l%d.weight" % s).astype(np.float64)[:, :, 0, 0], get(L + "l%d.bias" % s).astype(np.float64)
+                wa, ba = get(L + "al%d.weight" % s).astype(np.float64)[:, :, 0, 0], get(L + "al%d.bias" % s).astype(np.float64)
+                wb, bb = get(L + "bl%d.weight" % s).astype(np.float64)[:, :, 0, 0], get(L + "bl%d.bias" % s).astype(np.float64)
+                self.conv[L + "next%d" % s] = native.ConvWeights((wb + wa @ wl).astype(np.float32)[:, :, None, None],
+                                                                 (bb + wa @ bl_ + ba).astype(np.float32), device, reduced=self.reduced)
 
 
 LRELU = dict(act=1, slope=0.2)
@@ -155,18 +162,31 @@ def super_res_strip(W, x, a, b):
     return crop(img_sr, 4), crop(new2, 1), crop(new_fin, 4)
 
 
-def conv_block(W, prefix, x):
-    """ConvBlock with in_planes == out_planes: cat(o1, o2, o3) + x, GroupNorm+ReLU fused into each conv's staging."""
+def conv_block(W, prefix, x, want_stats=False):
+    """ConvBlock with in_planes == out_planes: cat(o1, o2, o3) + x, GroupNorm+ReLU fused into each conv's staging.
+
+    Four launches when x carries the statistics of its values (x.stats: the kernel that wrote x left them) and the block's
+    convolutions run on the split-f16 3x3 kernel: each convolution folds its input's statistics into the GroupNorm coefficients
+    itself and leaves its output's for the next one (native.conv2d_gn); want_stats: the closing sum leaves the block output's for
+    the ConvBlock that follows.  Otherwise (SURS_ENC_FUSED_GN=0, wide operands, a first block fed by the super-resolution net)
+    ten: two statistics launches in front of each convolution."""
     c = x.c
     out = Img(x.h, x.w, c, device=x.buf.device)
     o1, o2, o3 = out.slice(0, c // 2), out.slice(c // 2, c // 4), out.slice(3 * c // 4, c // 4)
+    cw = [W.conv[prefix + "conv%d" % i] for i in (1, 2, 3)]
+    fused = native.fused_groupnorm() and c % 128 == 0 and all(native.conv_gn_eligible(t, w) for t, w in zip((x, o1, o2), cw))
+    if fused and x.stats is not None:
+        native.conv2d_gn(x, cw[0], o1, gn=W.gn[prefix + "bn1"], want_stats=True)
+        native.conv2d_gn(o1, cw[1], o2, gn=W.gn[prefix + "bn2"], want_stats=True)
+        native.conv2d_gn(o2, cw[2], o3, gn=W.gn[prefix + "bn3"])
+        return native.add3(out, x, out=out, want_stats=want_stats)
     sc, sh = native.groupnorm_coeffs(x, *W.gn[prefix + "bn1"])
     native.conv2d(x, W.conv[prefix + "conv1"], out=o1, in_scale=sc, in_shift=sh)
     sc, sh = native.groupnorm_coeffs(o1, *W.gn[prefix + "bn2"])
     native.conv2d(o1, W.conv[prefix + "conv2"], out=o2, in_scale=sc, in_shift=sh)
     sc, sh = native.groupnorm_coeffs(o2, *W.gn[prefix + "bn3"])
     native.conv2d(o2, W.conv[prefix + "conv3"], out=o3, in_scale=sc, in_shift=sh)
-    return native.add3(out, x, out=out)
+    return native.add3(out, x, out=out, want_stats=want_stats and fused)
 
 
 _side_streams = {}
@@ -194,10 +214,12 @@ def hourglass(W, prefix, depth, x):
     cur0 = torch.cuda.current_stream()
     fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0" and cur0.cuda_stream == torch.cuda.default_stream(cur0.device).cuda_stream
 
+    st = native.fused_groupnorm()   # every map a ConvBlock reads is written with its GroupNorm statistics (conv_block)
+
     def fwd(level, inp):
         def low_branch():
-            low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp))
-            low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1)
+            low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp, want_stats=st), want_stats=True)
+            low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1, want_stats=True)
             return conv_block(W, prefix + "b3_%d." % level, low2)
         if fork:
             cur, side = torch.cuda.current_stream(), _side_stream(level)
@@ -209,7 +231,7 @@ def hourglass(W, prefix, depth, x):
         else:
             up1 = conv_block(W, prefix + "b1_%d." % level, inp)
             low3 = low_branch()
-        return native.bicubic_up2(low3, True, addend=up1)   # up1 + up2
+        return native.bicubic_up2(low3, True, addend=up1, want_stats=st)   # up1 + up2
     return fwd(depth, x)
 
 
@@ -218,11 +240,22 @@ def filter_lr(W, feature_lr, keep_all=False):
     opt, P = W.opt, "image_filter_lr."
     if feature_lr.h % (1 << opt.hg_depth) or feature_lr.w % (1 << opt.hg_depth):
         raise ValueError("feature_lr size must be a multiple of 2^hg_depth")
-    previous = conv_block(W, P + "conv2.", feature_lr)
+    previous = conv_block(W, P + "conv2.", feature_lr, want_stats=True)
     outs = []
     for i in range(opt.num_stack_lr):
         hg = hourglass(W, P + "m%d." % i, opt.hg_depth, previous)
         ll = conv_block(W, P + "top_m_%d." % i, hg)
+        last = i == opt.num_stack_lr - 1
+        if native.fused_groupnorm() and all(native.conv_gn_eligible(ll, W.conv[P + k % i]) for k in ("conv_last%d", "l%d")):
+            # the tail of a stack in two launches (three where the stack's output is wanted): conv_last leaves bn_end's statistics,
+            # the pointwise convolutions behind it fold them; the next stack's input from the merged convolution, its sum with
+            # `previous` in the epilogue, the statistics for the next hourglass with it
+            t = native.conv2d_gn(ll, W.conv[P + "conv_last%d" % i], want_stats=True)
+            if last or keep_all:
+                outs.append(native.conv2d_gn(t, W.conv[P + "l%d" % i], gn=W.gn[P + "bn_end%d" % i]))
+            if not last:
+                previous = native.conv2d_gn(t, W.conv[P + "next%d" % i], gn=W.gn[P + "bn_end%d" % i], residual=previous, want_stats=True)
+            continue
         t = native.conv2d(ll, W.conv[P + "conv_last%d" % i])
         sc, sh = native.groupnorm_coeffs(t, *W.gn[P + "bn_end%d" % i])
         # ll = relu(bn_end(conv_last(ll))) is consumed only by 1x1 convs: fused into their staging
@@ -231,7 +264,7 @@ def filter_lr(W, feature_lr, keep_all=False):
         if i < opt.num_stack_lr - 1:
             bl = native.conv2d(t, W.conv[P + "bl%d" % i], in_scale=sc, in_shift=sh)
             al = native.conv2d(tmp_out, W.conv[P + "al%d" % i])
-            previous = native.add3(previous, bl, al)
+            previous = native.add3(previous, bl, al, want_stats=native.fused_groupnorm())
     return outs if keep_all else outs[-1:]
 
 

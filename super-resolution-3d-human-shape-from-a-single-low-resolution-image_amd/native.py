@@ -47,13 +47,14 @@ def device_info():
 
 class Img:
     """NHWC fp32 device image: a view (h, w, c) into a buffer with channel pitch ld."""
-    __slots__ = ("buf", "h", "w", "c", "ld", "off")
+    __slots__ = ("buf", "h", "w", "c", "ld", "off", "stats")
 
     def __init__(self, h, w, c, ld=None, buf=None, off=0, device=None):
         ld = c if ld is None else ld
         if buf is None:
             buf = torch.empty(h * w * ld, dtype=torch.float32, device=device or require_gpu())
         self.buf, self.h, self.w, self.c, self.ld, self.off = buf, h, w, c, ld, off
+        self.stats = None   # GnStats of exactly these values, if the kernel that wrote them left any (conv2d_gn, *_gn below)
 
     def ptr(self):
         return C.c_void_p(self.buf.data_ptr() + 4 * self.off)
@@ -163,7 +164,61 @@ def conv2d(x, cw, out=None, stride=1, in_scale=None, in_shift=None, act=0, slope
              stride, _ptr(in_scale), _ptr(in_shift), act, slope,
              residual.ptr() if residual is not None else None,
              residual.ld if residual is not None else 0, _stream()))
+    out.stats = None
     return out
+
+
+class GnStats:
+    """GroupNorm(32) statistics of an image as the kernel that wrote it left them: partial sums [32 groups][slots][2] (sum, sum of
+    squares; float64), folded in a fixed order by the 3x3 convolution that applies the normalisation (conv2d_gn)."""
+    __slots__ = ("buf", "slots")
+
+    def __init__(self, capacity, device):
+        self.buf = torch.empty(32 * capacity * 2, dtype=torch.float64, device=device)
+        self.slots = 0
+
+
+def fused_groupnorm():
+    """SURS_ENC_FUSED_GN=0: GroupNorm coefficients by surs_groupnorm_coeffs' two launches per normalisation (rounds 1 - 3)."""
+    return os.environ.get("SURS_ENC_FUSED_GN", "1") != "0"
+
+
+def conv_gn_eligible(x, cw):
+    """Can conv2d_gn run this 3x3 convolution (two-part f16 weight image, 32 | cin, 16-byte aligned pixels)?"""
+    if cw.k not in (1, 3) or cw.w3 is None or x.c % 32 or x.ld % 4 or (x.buf.data_ptr() + 4 * x.off) % 16:
+        return False
+    w3, parts = cw.split_image()
+    return w3 is not None and parts == 2
+
+
+def conv2d_gn(x, cw, out=None, gn=None, want_stats=False, eps=1e-5, act=0, slope=0.0, residual=None):
+    """3x3 / 1x1 convolution, stride 1, with GroupNorm(32) handed over between kernels: gn = (gamma, beta) applies GroupNorm + ReLU to
+    x from x.stats (left by x's producer); want_stats leaves the statistics of the output (after activation and residual) in
+    out.stats."""
+    if out is None:
+        out = Img(x.h, x.w, cw.cout, device=x.buf.device)
+    assert x.c == cw.cin and (out.h, out.w, out.c) == (x.h, x.w, cw.cout)
+    w3, parts = cw.split_image()
+    assert parts == 2
+    if gn is not None and x.stats is None:
+        raise RuntimeError("conv2d_gn: the input carries no GroupNorm statistics")
+    cap = (out.h * out.w + 127) // 128 if cw.k == 1 else ((out.w + 31) // 32) * ((out.h + 3) // 4)
+    st = GnStats(cap, x.buf.device) if want_stats else None
+    slots = C.c_int(0)
+    check(lib().surs_conv2d_nhwc_gn(1 if cw.reduced else 2, x.ptr(), x.h, x.w, x.c, x.ld, _ptr(w3), _ptr(cw.b), out.ptr(), cw.cout, out.ld,
+                                    cw.k, 1, _ptr(x.stats.buf) if gn is not None else None, x.stats.slots if gn is not None else 0,
+                                    _ptr(gn[0]) if gn is not None else None, _ptr(gn[1]) if gn is not None else None, eps, act, slope,
+                                    residual.ptr() if residual is not None else None, residual.ld if residual is not None else 0,
+                                    _ptr(st.buf) if st is not None else None, st.buf.numel() // 64 if st is not None else 0,
+                                    C.byref(slots), _stream()))
+    if st is not None:
+        st.slots = slots.value
+    out.stats = st
+    return out
+
+
+def _ew_stats(n_items, device):
+    return GnStats(min(512, (n_items + 1023) // 1024), device)   # (workgroups of 1024 threads, at most 512 of them)
 
 
 def groupnorm_coeffs(x, gamma, beta, groups=32, eps=1e-5):
@@ -181,14 +236,31 @@ def scale_shift_act(x, scale, shift, relu, out=None):
     return out
 
 
-def avgpool2(x, out=None):
+def avgpool2(x, out=None, want_stats=False):
     out = out or Img(x.h // 2, x.w // 2, x.c, device=x.buf.device)
+    if want_stats:
+        st, slots = _ew_stats(out.h * out.w * (x.c // 4), x.buf.device), C.c_int(0)
+        check(lib().surs_avgpool2_gn(x.ptr(), x.h, x.w, x.c, x.ld, out.ptr(), out.ld, _ptr(st.buf), st.buf.numel() // 64, C.byref(slots),
+                                     _stream()))
+        st.slots = slots.value
+        out.stats = st
+        return out
     check(lib().surs_avgpool2(x.ptr(), x.h, x.w, x.c, x.ld, out.ptr(), out.ld, _stream()))
+    out.stats = None
     return out
 
 
-def bicubic_up2(x, align_corners, addend=None, out=None):
+def bicubic_up2(x, align_corners, addend=None, out=None, want_stats=False):
     out = out or Img(2 * x.h, 2 * x.w, x.c, device=x.buf.device)
+    if want_stats:
+        st, slots = _ew_stats(out.h * out.w * (x.c // 4), x.buf.device), C.c_int(0)
+        check(lib().surs_bicubic_up2_gn(x.ptr(), x.h, x.w, x.c, x.ld, int(bool(align_corners)),
+                                        addend.ptr() if addend is not None else None, addend.ld if addend is not None else 0,
+                                        out.ptr(), out.ld, _ptr(st.buf), st.buf.numel() // 64, C.byref(slots), _stream()))
+        st.slots = slots.value
+        out.stats = st
+        return out
+    out.stats = None
     check(lib().surs_bicubic_up2(x.ptr(), x.h, x.w, x.c, x.ld, int(bool(align_corners)),
                                  addend.ptr() if addend is not None else None, addend.ld if addend is not None else 0,
                                  out.ptr(), out.ld, _stream()))
@@ -201,10 +273,18 @@ def pixel_shuffle2(x, slope, out=None):
     return out
 
 
-def add3(a, b, c=None, out=None):
+def add3(a, b, c=None, out=None, want_stats=False):
     out = out or Img(a.h, a.w, a.c, device=a.buf.device)
+    if want_stats:
+        st, slots = _ew_stats(a.h * a.w * (a.c // 4), a.buf.device), C.c_int(0)
+        check(lib().surs_add3_gn(a.ptr(), a.ld, b.ptr(), b.ld, c.ptr() if c is not None else None, c.ld if c is not None else 0,
+                                 a.h * a.w, a.c, out.ptr(), out.ld, _ptr(st.buf), st.buf.numel() // 64, C.byref(slots), _stream()))
+        st.slots = slots.value
+        out.stats = st
+        return out
     check(lib().surs_add3(a.ptr(), a.ld, b.ptr(), b.ld, c.ptr() if c is not None else None, c.ld if c is not None else 0,
                           a.h * a.w, a.c, out.ptr(), out.ld, _stream()))
+    out.stats = None
     return out
 
 

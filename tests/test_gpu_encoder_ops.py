@@ -127,3 +127,100 @@ def test_split_operand_conv_equals_fp32_mfma_conv(env, parts, monkeypatch):
     y1 = _chw(nat.conv2d(X, cw, in_scale=sc, in_shift=sh, act=1, slope=0.2, residual=res))
     cw.w3 = w3
     assert common.rel_err(y3, y1) < (2e-6 if parts == 3 else 4e-6)
+
+
+def _fold(st):
+    """The partial sums of a GnStats, folded on the host: [32][2] float64."""
+    return st.buf[:64 * st.slots].view(32, st.slots, 2).sum(dim=1).cpu().numpy()
+
+
+@pytest.mark.parametrize("reduced", [False, True])
+def test_conv_block_with_groupnorm_statistics_handed_between_kernels(env, reduced):
+    """ConvBlock (lib/model/HGFilters.py:57-74) in four launches - every kernel leaves the GroupNorm statistics of the map it
+    writes, the next 3x3 convolution folds them itself (surs_conv2d_nhwc_gn, surs_add3_gn) - against the oracle's ConvBlock and
+    against the ten-launch form (surs_groupnorm_coeffs in front of each convolution); the statistics themselves against float64
+    sums of the stored values; two runs give the same bits (no atomics)."""
+    nat, orc, dev = env["native"], env["oracle"], env["dev"]
+    c, h, w = 256, 44, 72                     # ragged tiles in both directions (44 = 5.5 x 8 rows, 72 = 2.25 x 32 columns)
+    x = prng.uniform("bx", 1, (c, h, w), -2, 3)
+    wts = [prng.uniform("bw", i, s, -0.08, 0.08) for i, s in enumerate(((c // 2, c, 3, 3), (c // 4, c // 2, 3, 3), (c // 4, c // 4, 3, 3)))]
+    gns = [(prng.uniform("bg", i, (n,), 0.5, 1.5), prng.uniform("bb", i, (n,), -0.3, 0.3)) for i, n in enumerate((c, c // 2, c // 4))]
+    o1 = orc.conv2d(orc.relu(orc.group_norm(x, *gns[0])), wts[0])
+    o2 = orc.conv2d(orc.relu(orc.group_norm(o1, *gns[1])), wts[1])
+    o3 = orc.conv2d(orc.relu(orc.group_norm(o2, *gns[2])), wts[2])
+    ref = np.concatenate([o1, o2, o3]) + x
+    cws = [nat.ConvWeights(wt, None, dev, reduced=reduced) for wt in wts]
+    G = [(torch.from_numpy(g).to(dev), torch.from_numpy(b).to(dev)) for g, b in gns]
+
+    def fused():
+        X = nat.add3(_img(env, x), _img(env, np.zeros_like(x)), want_stats=True)     # x + 0, with the statistics of x
+        out = nat.Img(h, w, c, device=dev)
+        a, b_, d = out.slice(0, c // 2), out.slice(c // 2, c // 4), out.slice(3 * c // 4, c // 4)
+        nat.conv2d_gn(X, cws[0], a, gn=G[0], want_stats=True)
+        nat.conv2d_gn(a, cws[1], b_, gn=G[1], want_stats=True)
+        nat.conv2d_gn(b_, cws[2], d, gn=G[2])
+        pre = _chw(out)
+        return X, a, b_, pre, nat.add3(out, X, out=out, want_stats=True)
+
+    X, a, b_, pre, out = fused()
+    y = _chw(out)
+    tol = 2e-3 if reduced else 2e-5          # (one f16 product per MAC: 11 significant bits)
+    assert common.rel_err(y, ref) < tol
+    # the statistics are those of the stored values
+    for img, vals in ((X, x), (a, pre[:c // 2]), (b_, pre[c // 2:3 * c // 4]), (out, y)):
+        v = vals.astype(np.float64).reshape(32, -1)
+        want = np.stack([v.sum(1), (v * v).sum(1)], 1)
+        got = _fold(img.stats)
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-9), (img.c, np.abs(got - want).max())
+    # the ten-launch form on the same kernels: the coefficients differ by float rounding of differently ordered double sums at most
+    Xl = _img(env, x)
+    outl = nat.Img(h, w, c, device=dev)
+    al, bl, dl = outl.slice(0, c // 2), outl.slice(c // 2, c // 4), outl.slice(3 * c // 4, c // 4)
+    for src, dst, cw, g in ((Xl, al, cws[0], G[0]), (al, bl, cws[1], G[1]), (bl, dl, cws[2], G[2])):
+        sc, sh = nat.groupnorm_coeffs(src, *g)
+        nat.conv2d(src, cw, out=dst, in_scale=sc, in_shift=sh)
+    yl = _chw(nat.add3(outl, Xl, out=outl))
+    assert common.rel_err(y, yl) < 1e-6
+    # deterministic
+    assert np.array_equal(_chw(fused()[4]), y)
+
+
+def test_pool_and_bicubic_leave_groupnorm_statistics(env):
+    nat, dev = env["native"], env["dev"]
+    x = prng.uniform("sx", 9, (128, 36, 52), -1, 2)
+    add = prng.uniform("sa", 9, (128, 72, 104), -1, 1)
+    X, A = _img(env, x), _img(env, add)
+    for got, plain in ((nat.avgpool2(X, want_stats=True), nat.avgpool2(X)),
+                       (nat.bicubic_up2(X, True, addend=A, want_stats=True), nat.bicubic_up2(X, True, addend=A))):
+        assert plain.stats is None and got.stats is not None and 0 < got.stats.slots <= 512
+        v = _chw(got)
+        assert np.array_equal(v, _chw(plain))
+        v = v.astype(np.float64).reshape(32, -1)
+        assert np.allclose(_fold(got.stats), np.stack([v.sum(1), (v * v).sum(1)], 1), rtol=1e-12, atol=1e-9)
+
+
+def test_pointwise_conv_with_groupnorm_statistics(env):
+    """The tail of an hourglass stack (lib/model/HGFilters.py:196-206): conv_last leaves bn_end's statistics, the pointwise
+    convolution behind it folds them, adds `previous` in its epilogue and leaves the statistics of the sum."""
+    nat, orc, dev = env["native"], env["oracle"], env["dev"]
+    c, h, w = 256, 21, 37                       # 777 pixels: a ragged last 128-pixel block
+    x = prng.uniform("qx", 1, (c, h, w), -2, 2)
+    prev = prng.uniform("qp", 2, (c, h, w), -1, 1)
+    w1, b1 = prng.uniform("qw", 3, (c, c, 1, 1), -0.1, 0.1), prng.uniform("qb", 3, (c,), -0.2, 0.2)
+    w2, b2 = prng.uniform("qw", 4, (c, c, 1, 1), -0.1, 0.1), prng.uniform("qb", 4, (c,), -0.2, 0.2)
+    gamma, beta = prng.uniform("qg", 5, (c,), 0.5, 1.5), prng.uniform("qh", 5, (c,), -0.3, 0.3)
+    t_ref = orc.conv2d(x, w1, b1)
+    ref = orc.conv2d(orc.relu(orc.group_norm(t_ref, gamma, beta)), w2, b2) + prev
+    G = (torch.from_numpy(gamma).to(dev), torch.from_numpy(beta).to(dev))
+    t = nat.conv2d_gn(_img(env, x), nat.ConvWeights(w1, b1, dev), want_stats=True)
+    assert t.stats.slots == (h * w + 127) // 128
+    y = nat.conv2d_gn(t, nat.ConvWeights(w2, b2, dev), gn=G, residual=_img(env, prev), want_stats=True)
+    assert common.rel_err(_chw(t), t_ref) < 2e-5 and common.rel_err(_chw(y), ref) < 2e-5
+    for img in (t, y):
+        v = _chw(img).astype(np.float64).reshape(32, -1)
+        assert np.allclose(_fold(img.stats), np.stack([v.sum(1), (v * v).sum(1)], 1), rtol=1e-12, atol=1e-9)
+    # against the unfused launches on the same kernels
+    tl = nat.conv2d(_img(env, x), nat.ConvWeights(w1, b1, dev))
+    sc, sh = nat.groupnorm_coeffs(tl, *G)
+    yl = nat.conv2d(tl, nat.ConvWeights(w2, b2, dev), in_scale=sc, in_shift=sh, residual=_img(env, prev))
+    assert np.array_equal(_chw(tl), _chw(t)) and common.rel_err(_chw(y), _chw(yl)) < 1e-6
