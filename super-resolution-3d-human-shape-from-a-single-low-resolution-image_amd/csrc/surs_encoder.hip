@@ -314,6 +314,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     unsigned short *wsm = lds16 + NP * PR * PC * XS;    // [NP][T][NT3][XS]
     float *gn = reinterpret_cast<float *>(wsm + NP * T * NT3 * XS);   // [2][cin_pad]: GroupNorm scale, shift (if any)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SURS_CONV_TRACE
+    const unsigned long long t_kernel_start = __builtin_readcyclecounter();
+#endif
     const int ox0 = blockIdx.x * TC, oy0 = blockIdx.y * TR, n0 = blockIdx.z * NT3;
     const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD;
     const int nch = a.cin_pad / CK;
@@ -448,8 +451,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         __syncthreads();
     }
 #ifdef SURS_CONV_TRACE
-    unsigned long long tprev = __builtin_readcyclecounter();
+    unsigned long long tprev = t_kernel_start;
     if (blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && tid == 0) for (int i = 0; i < 8; ++i) g_conv_trace[i] = 0;
+    CSTAMP(5);
 #endif
     auto chunk = [&](int ch, int pb) {
         CSTAMP(4);
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         chunk(ch, 0);
         if (ch + 1 < nch) chunk(ch + 1, PD - 1);
     }
+    CSTAMP(4);   // (the interval since the last chunk's second barrier)
     // ---- epilogue: register q of a tile is pixel column (q&3) + 8*(q>>2) + 4*(lane>>5), lane&31 is the channel
     const int kh = lane >> 5, li = lane & 31;
     const bool stats = a.gn_out != nullptr;
@@ -521,6 +526,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             const int co = n0 + j * 32 + li;
             if (co >= a.cout) continue;
             const float b = a.bias ? a.bias[co] : 0.f;
+            // the tile's 16 residual values first, all in flight together: read one by one between the stores (which the compiler
+            // must keep in order: res and y may alias) every element cost a memory round trip
+            float rv[16];
+            if (a.res) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                    rv[q] = ox < a.wo ? a.res[((size_t)oy * a.wo + ox) * a.res_ld + co] : 0.f;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
                 t += b;
                 if (a.act == 1) t = t > 0.f ? t : a.slope * t;
                 const size_t pix = (size_t)oy * a.wo + ox;
-                if (a.res) t += a.res[pix * a.res_ld + co];
+                if (a.res) t += rv[q];
                 a.y[pix * a.y_ld + co] = t;
                 if (stats) {
                     const double d = (double)t;
@@ -571,6 +586,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             }
         }
     }
+    CSTAMP(6);
 }
 
 template <int KS, int STRIDE, int TR, int NT3, int NP>
@@ -585,12 +601,12 @@ static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, h
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3, NP>), grid, dim3(256), lds, st, a, wsplit);
     SURS_LAUNCH_CHECK();
 #ifdef SURS_CONV_TRACE
-    if (getenv("SURS_CONV_TRACE") && a.cin == 256 && a.cout == 128) {
+    if (getenv("SURS_CONV_TRACE")) {
         unsigned long long t[8];
         SURS_HIP_CHECK(hipStreamSynchronize(st));
         SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_conv_trace), sizeof(t)));
-        fprintf(stderr, "conv_x3 <%d,%d> %dx%d cin %d cout %d: per workgroup cycles: stage %llu, barrier %llu, fetch issue %llu, mfma %llu, barrier2 %llu\n",
-                TR, NT3, a.h, a.w, a.cin, a.cout, t[0], t[1], t[2], t[3], t[4]);
+        fprintf(stderr, "conv_x3 <%d,%d,np %d> %dx%d cin %d cout %d: cycles of workgroup (1,1,0) over %d chunks: stage %llu, barrier %llu, fetch issue %llu, taps %llu, barrier2 %llu; prologue %llu, epilogue %llu\n",
+                TR, NT3, NP, a.h, a.w, a.cin, a.cout, a.cin_pad / CK, t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
     }
 #endif
     return 0;
@@ -737,13 +753,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
             const int co = n0 + 32 * j + li;
             if (co >= a.cout) continue;
             const float b = a.bias ? a.bias[co] : 0.f;
+            float rv[16];   // (all 16 residual loads in flight together: see conv_x3_kernel)
+            if (a.res) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long long pix = p0 + 32 * t + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                    rv[q] = pix < npix ? a.res[(size_t)pix * a.res_ld + co] : 0.f;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const long long pix = p0 + 32 * t + (q & 3) + 8 * (q >> 2) + 4 * kh;
                 if (pix >= npix) continue;
                 float v = acc[t][j][q] + b;
                 if (a.act == 1) v = v > 0.f ? v : a.slope * v;
-                if (a.res) v += a.res[(size_t)pix * a.res_ld + co];
+                if (a.res) v += rv[q];
                 a.y[(size_t)pix * a.y_ld + co] = v;
                 if (stats) {
                     const double d = (double)v;
@@ -1052,7 +1076,8 @@ __global__ void add3_kernel(const float *__restrict__ a, int a_ld, const float *
 struct AvgPool2Op {
     const float *x; int h, w, c, x_ld; float *y; int y_ld;
     __device__ __forceinline__ unsigned items() const { return (unsigned)(h / 2) * (w / 2) * (c / 4); }
-    __device__ __forceinline__ f32x4 operator()(unsigned i) const {
+    __device__ __forceinline__ void store(unsigned i, f32x4 r) const { *reinterpret_cast<f32x4 *>(y + (size_t)i * 4 + (size_t)(i / (c / 4)) * (y_ld - c)) = r; }
+    __device__ __forceinline__ f32x4 compute(unsigned i) const {
     const int wo = w / 2, c4 = c / 4;
     const unsigned pix = i / c4, q = i - pix * c4, oy = pix / wo, ox = pix - oy * wo;
     const float *p = x + ((size_t)(2 * oy) * w + 2 * ox) * x_ld + 4 * q;
@@ -1061,7 +1086,6 @@ struct AvgPool2Op {
     f32x4 r;
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = (a[k] + b[k] + cc[k] + dd[k]) * 0.25f;
-    *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = r;
     return r;
     }
 };
@@ -1069,7 +1093,8 @@ struct AvgPool2Op {
 struct BicubicUp2Op {
     const float *x; int h, w, c, x_ld, align_corners; const float *addend; int add_ld; float *y; int y_ld;
     __device__ __forceinline__ unsigned items() const { return (unsigned)(2 * h) * (2 * w) * (c / 4); }
-    __device__ __forceinline__ f32x4 operator()(unsigned i) const {
+    __device__ __forceinline__ void store(unsigned i, f32x4 r) const { *reinterpret_cast<f32x4 *>(y + (size_t)i * 4 + (size_t)(i / (c / 4)) * (y_ld - c)) = r; }
+    __device__ __forceinline__ f32x4 compute(unsigned i) const {
     const int ho = 2 * h, wo = 2 * w, c4 = c / 4;
     const unsigned pix = i / c4, q = i - pix * c4;
     const int oy = (int)(pix / wo), ox = (int)(pix - (unsigned)oy * wo);
@@ -1101,7 +1126,6 @@ struct BicubicUp2Op {
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = ad[k] + acc[k];
     }
-    *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = acc;
     return acc;
     }
 };
@@ -1134,7 +1158,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_vec4_kernel(const float *_
 struct Add3Op {
     const float *a; int a_ld; const float *b; int b_ld; const float *c; int c_ld; unsigned hw; int ch; float *y; int y_ld;
     __device__ __forceinline__ unsigned items() const { return hw * (unsigned)(ch / 4); }
-    __device__ __forceinline__ f32x4 operator()(unsigned i) const {
+    __device__ __forceinline__ void store(unsigned i, f32x4 r) const { *reinterpret_cast<f32x4 *>(y + (size_t)i * 4 + (size_t)(i / (ch / 4)) * (y_ld - ch)) = r; }
+    __device__ __forceinline__ f32x4 compute(unsigned i) const {
     const int c4 = ch / 4;
     const unsigned pix = i / c4, q = i - pix * c4;
     const f32x4 va = *reinterpret_cast<const f32x4 *>(a + (size_t)pix * a_ld + 4 * q);
@@ -1147,7 +1172,6 @@ struct Add3Op {
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] += vc[k];
     }
-    *reinterpret_cast<f32x4 *>(y + (size_t)pix * y_ld + 4 * q) = t;
     return t;
     }
 };
@@ -1155,7 +1179,7 @@ struct Add3Op {
 template <class Op>
 __global__ __launch_bounds__(256) void vec4_kernel(Op op) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i < op.items()) op(i);
+    if (i < op.items()) op.store(i, op.compute(i));
 }
 
 // The same, and the GroupNorm(32, c) statistics of the output as partial sums [32][gridDim.x][2] (ConvArgs::gn_out): workgroups of
@@ -1169,13 +1193,23 @@ __global__ __launch_bounds__(VS_THREADS) void vec4_stats_kernel(Op op, int c, do
     const int tid = threadIdx.x, c4 = c / 4, cg = c / 32, ppl = VS_THREADS / c4;
     const unsigned n = op.items();
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    for (unsigned i = blockIdx.x * (unsigned)VS_THREADS + tid; i < n; i += gridDim.x * (unsigned)VS_THREADS) {
-        const f32x4 v = op(i);
+    // two items per trip: the loads of both are in flight before either is stored (x, the addend and y may alias for all the
+    // compiler knows: item by item, every trip was a full memory round trip)
+    const unsigned stride = gridDim.x * (unsigned)VS_THREADS;
+    for (unsigned i = blockIdx.x * (unsigned)VS_THREADS + tid; i < n; i += 2 * stride) {
+        const bool two = i + stride < n;
+        const f32x4 v0 = op.compute(i);
+        f32x4 v1 = {0.f, 0.f, 0.f, 0.f};
+        if (two) v1 = op.compute(i + stride);
+        op.store(i, v0);
+        if (two) op.store(i + stride, v1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const double d = v[k];
+            const double d = v0[k], e = v1[k];
             s[k] += d;
             ss[k] += d * d;
+            s[k] += e;       // (an item that does not exist adds zeros)
+            ss[k] += e * e;
         }
     }
 #pragma unroll

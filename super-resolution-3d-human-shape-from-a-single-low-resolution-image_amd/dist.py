@@ -295,7 +295,7 @@ def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transfor
     a, b = min(a, need_hr[0] // 4 // 2 * 2), max(b, -(-need_hr[1] // 4) + (-(-need_hr[1] // 4)) % 2)   # + what the slab samples of feature_hr (even bounds)
     b = min(b, wl)
     W = net._encoder_weights()
-    img_sr, new2, new_fin = encoder.super_res_strip(W, x, a, b)
+    _, new2, new_fin = encoder.super_res_strip(W, x, a, b, want_image=False)   # (img_SR is not part of what this returns)
     dev = x.buf.device
     # ---- feature_lr: every rank's share, gathered
     mine = new2.buf.view(new2.h, new2.w, new2.c)[:, rank * share - a:(rank + 1) * share - a, :].contiguous()

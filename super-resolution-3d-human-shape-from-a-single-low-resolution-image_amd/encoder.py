@@ -90,8 +90,10 @@ LRELU = dict(act=1, slope=0.2)
 RELU = dict(act=1, slope=0.0)
 
 
-def super_res(W, x):
-    """x: Img [H,W,3].  Returns (img_SR [2H,2W,3], new2 = feature_lr [H/2,W/2,256], new_fin = feature_hr [2H,2W,64])."""
+def super_res(W, x, want_image=True):
+    """x: Img [H,W,3].  Returns (img_SR [2H,2W,3], new2 = feature_lr [H/2,W/2,256], new_fin = feature_hr [2H,2W,64]).
+    want_image=False: img_SR (two convolutions at 2H x 2W that nothing on the reconstruction path reads: lib/train_util.py:57 drops
+    it) is not computed and None is returned in its place - for callers that do not hand it out."""
     opt, P, cv = W.opt, "super_resolution.", native.conv2d
     if x.h % 4 or x.w % 4:
         raise ValueError("input image height/width must be multiples of 4 (three stride-2 stages), got %dx%d" % (x.h, x.w))
@@ -122,7 +124,7 @@ def super_res(W, x):
     native.pixel_shuffle2(cv(new2, W.conv[P + "ups2.0"], **LRELU), 0.2, out=new3.slice(64, 64))
     native.pixel_shuffle2(cv(new3, W.conv[P + "ups3.0"], **LRELU), 0.2, out=fin.slice(32, 32))
     new_fin = cv(fin, W.conv[P + "ups4.0"], **LRELU)
-    img_sr = cv(cv(new_fin, W.conv[P + "last.0"], **LRELU), W.conv[P + "last.2"])
+    img_sr = cv(cv(new_fin, W.conv[P + "last.0"], **LRELU), W.conv[P + "last.2"]) if want_image else None
     return img_sr, new2, new_fin
 
 
@@ -133,7 +135,7 @@ def super_res(W, x):
 SR_HALO_LR = 32
 
 
-def super_res_strip(W, x, a, b):
+def super_res_strip(W, x, a, b, want_image=True):
     """super_res restricted to the columns [a, b) of feature_lr (= columns [4a, 4b) of feature_hr / img_SR): runs the net on the
     image columns that range depends on (a halo of SR_HALO_LR feature_lr columns on each side, clipped at the image border, where
     the convolutions' own zero padding applies) and returns (img_sr, new2, new_fin) cropped to the range.  Every value is computed
@@ -151,7 +153,7 @@ def super_res_strip(W, x, a, b):
     #  image's tiles)
     native.check(native.lib().surs_conv_tile_scale(x.w, xs.w))
     try:
-        img_sr, new2, new_fin = super_res(W, xs)
+        img_sr, new2, new_fin = super_res(W, xs, want_image=want_image)
     finally:
         native.check(native.lib().surs_conv_tile_scale(1, 1))
 
@@ -159,7 +161,7 @@ def super_res_strip(W, x, a, b):
         v = hwc(t)[:, scale * (a - a0):scale * (b - a0), :]
         return Img(t.h, scale * (b - a), t.c, buf=v.contiguous().reshape(-1), device=dev)
 
-    return crop(img_sr, 4), crop(new2, 1), crop(new_fin, 4)
+    return (crop(img_sr, 4) if img_sr is not None else None), crop(new2, 1), crop(new_fin, 4)
 
 
 def conv_block(W, prefix, x, want_stats=False):
@@ -199,7 +201,10 @@ def _side_stream(level):
     key = (cur.device.index, cur.cuda_stream, level)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=cur.device)
+        # (high priority: the low-resolution branch is the longer one - chains of small kernels - and the full-resolution block beside
+        #  it would otherwise take the CUs first; SURS_ENC_STREAM_PRIORITY=0: default priority)
+        prio = -1 if os.environ.get("SURS_ENC_STREAM_PRIORITY", "1") != "0" else 0
+        st = _side_streams[key] = torch.cuda.Stream(device=cur.device, priority=prio)
     return st
 
 

@@ -188,7 +188,7 @@ class SuRSNet:
         (Img feat_lr, Img feat_hr) the query kernels read.  gen_mesh_pipelined runs it for the next subject on a second
         stream while the current subject's features are still in use."""
         W = self._encoder_weights()
-        _, f_lr, f_hr = encoder.super_res(W, _as_img(image[0:1]))
+        _, f_lr, f_hr = encoder.super_res(W, _as_img(image[0:1]), want_image=False)
         return encoder.filter_lr(W, f_lr)[-1], encoder.filter_hr(W, f_hr)[0]
 
     def features(self, b=0):
