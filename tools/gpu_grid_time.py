@@ -18,4 +18,6 @@ t = time.time()
 for _ in range(3): f()
 torch.cuda.synchronize()
 dt = (time.time() - t) / 3
-print("%s  %.4f s  %.3e pts/s" % (os.environ.get("SURS_LIB_PATH", "default"), dt, R ** 3 / dt))
+import hashlib
+dg = hashlib.sha256(vh.cpu().numpy().tobytes() + vl.cpu().numpy().tobytes()).hexdigest()[:16]
+print("%s  %.4f s  %.3e pts/s  volumes %s" % (os.environ.get("SURS_LIB_PATH", "default"), dt, R ** 3 / dt, dg))
