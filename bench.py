@@ -72,12 +72,13 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
                          (args.gpus, world, args.gpus))
+    if world > 1:   # (before the first HIP call: the runtime reads it when it initialises)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.backend == "gloo":
         local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
