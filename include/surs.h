@@ -126,9 +126,10 @@ int surs_add3(const float *a, int a_ld, const float *b, int b_ld, const float *c
  * the HOST int; one slot per workgroup, so the layout is a function of the shapes alone); the 3x3 convolution that consumes the map
  * folds them - every workgroup, in the same fixed order - into surs_groupnorm_coeffs' coefficients (same formulas) and applies
  * GroupNorm(gamma, beta, eps) + ReLU while staging.  Deterministic: no atomics.
- *   surs_conv2d_nhwc_gn: surs_conv2d_nhwc_x2 (parts = 2) / _x1 (parts = 1), 3x3; gn_in (nullable) = the statistics of x with their
- *   slot count, gamma / beta [cin], 32 | cin; gn_out (nullable) as above, cout / 32 a power of two <= 32 (a buffer of
- *   ceil(w / 32) * ceil(h / 4) slots always suffices).
+ *   surs_conv2d_nhwc_gn: surs_conv2d_nhwc_x2 (parts = 2) / _x1 (parts = 1), 3x3 or 1x1 (1x1: the two-part kernel whatever `parts`),
+ *   activation and residual as there; gn_in (nullable) = the statistics of x with their slot count, gamma / beta [cin], 32 | cin;
+ *   gn_out (nullable) as above = the statistics of y after activation and residual, cout / 32 a power of two <= 32 (a buffer of
+ *   ceil(w / 32) * ceil(h / 4) slots always suffices for 3x3, ceil(h * w / 128) for 1x1).
  *   surs_avgpool2_gn / surs_bicubic_up2_gn / surs_add3_gn: the elementwise kernels, the same values bit for bit, plus gn_out
  *   (C a power of two in [32, 1024], 16-byte aligned rows; at most 512 slots). */
 int surs_conv2d_nhwc_gn(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias, float *y,
