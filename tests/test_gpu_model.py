@@ -530,3 +530,37 @@ def test_graft_entry_build_and_smoke_in_one_process():
         r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stderr[-3000:]
         assert "smoke ok" in r.stdout
+
+
+def test_filter_lr_launch_forms_agree_and_repeat(net, monkeypatch):
+    """filter_lr with the GroupNorm statistics handed from kernel to kernel and the merged stack tail (round 4: 4 launches per
+    ConvBlock, 2 per tail) against the rounds 1 - 3 form (SURS_ENC_FUSED_GN=0: two statistics launches in front of every convolution,
+    l / bl / al / sum apart) on a 256 x 256 image - every hourglass level takes part - in eval and in training mode (all three stack
+    outputs); the hand-over form run twice gives the same bits (no atomics in it); encode_image (no img_SR) = the facade's features."""
+    from surs_amd import model
+    img = torch.from_numpy(weights.synthetic_image(256, seed=3)).to("cuda:0")
+    _, f_lr, f_hr = net.super_res(img)
+
+    def run(training):
+        was = net.training
+        net.train(training)
+        net.filter_lr(f_lr)
+        net.train(was)
+        return [t.clone() for t in net.im_feat_list_lr]
+
+    monkeypatch.setenv("SURS_ENC_FUSED_GN", "1")
+    new_eval, new_train, again = run(False), run(True), run(False)
+    monkeypatch.setenv("SURS_ENC_FUSED_GN", "0")
+    old_eval, old_train = run(False), run(True)
+    monkeypatch.delenv("SURS_ENC_FUSED_GN")
+    assert len(new_eval) == 1 and len(new_train) == 3 and len(old_train) == 3
+    assert torch.equal(new_eval[0], again[0])
+    assert torch.equal(new_eval[0], new_train[2])        # the last stack's output does not depend on the mode
+    for a, b in zip(new_eval + new_train, old_eval + old_train):
+        # (merged weights W_bl + W_al W_l round differently from the three convolutions: 1e-5 of the tensor's range, ten times
+        #  inside the encoder's 1e-4 against the reference)
+        assert common.rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    fl, fh = net.encode_image(img)
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    assert torch.equal(model._as_nchw_view(fl), net.im_feat_list_lr[-1]) and torch.equal(model._as_nchw_view(fh), net.im_feat_list_hr[0])
