@@ -614,6 +614,12 @@ struct GridArgs {
     int zstride;
     const int *kcount;
     const unsigned short *klist;
+    // kernel v12 -> kernel v10: the (column, z tile) pairs v12 did not evaluate (ovf_list[2 t], [2 t + 1], t < *ovf_count); kernel v10
+    // with tile_list set walks those instead of whole columns
+    unsigned *ovf_count;
+    int *ovf_list;
+    const int *tile_list;
+    const unsigned *tile_count;
     double z0, dz;  // world z of voxel k = (float)(dz*k + z0)
     float c22, c23;  // Z(k) = c23 + c22 * z(k)   (calib[2][0] = calib[2][1] = 0 in column mode)
     float zmul, zdiv;
@@ -633,6 +639,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 #include "surs_grid_v5.inc"
 #include "surs_grid_restated.inc"
 #include "surs_grid_v10.inc"
+#include "surs_grid_v12.inc"
 #include "surs_grid_v11.inc"
 
 // Column kernel v7's per-column affine part, step 1: the vectors g . a0, g . w0z (lr) and g . a0, g . w0z, g . w0p (hr) of a
@@ -703,7 +710,7 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 #define SURS_DEFAULT_GRID_F32_KERNEL 11
 #endif
 static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
-static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 10 || v == 5 || v == 11; }
+static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 10 || v == 12 || v == 5 || v == 11; }
 extern "C" int surs_set_grid_kernel(int version) {
     SURS_REQUIRE(grid_kernel_known(version),
                  "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3 or 10, fp32-grade 5 or 11");
@@ -1028,6 +1035,8 @@ static int grid_set_attributes() {
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v11, hipFuncAttributeMaxDynamicSharedMemorySize, GRID11_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
     SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v10<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID10_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v12<SURS_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID12_LDS_BYTES));
+    SURS_HIP_CHECK(hipFuncSetAttribute((const void *)grid_mlp_kernel_v12<SURS_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, GRID12_LDS_BYTES));
     return 0;
 }
 
@@ -1179,7 +1188,7 @@ static void resolve_column_kernels(int kernel_call, int &kver, int &kver32) {
     if (kver_env < 0) {
         const char *e = getenv("SURS_GRID_KERNEL");
         const int v = e ? atoi(e) : 0;
-        kver_env = (v == 3 || v == 10) ? v : SURS_DEFAULT_GRID_KERNEL;
+        kver_env = (v == 3 || v == 10 || v == 12) ? v : SURS_DEFAULT_GRID_KERNEL;
     }
     static int kver32_env = -1;
     if (kver32_env < 0) {
@@ -1239,6 +1248,10 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     a.zstride = zstride;
     a.kcount = kcount;
     a.klist = klist;
+    a.ovf_count = nullptr;
+    a.ovf_list = nullptr;
+    a.tile_list = nullptr;
+    a.tile_count = nullptr;
     if (restated) {
         // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
         if ((rc = g3_set_attributes())) return rc;
@@ -1342,6 +1355,31 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             }
         } else
             hipLaunchKernelGGL(grid_mlp_kernel_v5, dim3(grid), dim3(256), GRID5_LDS_BYTES, st, a);
+    } else if (kver == 12) {
+        // two workgroups of four waves per compute unit
+        // (its overflow list lies over the g-scaled vectors' split image, which the R GEMMs above were the last to read)
+#ifdef SURS_V12_ONE_WG
+        const unsigned grid12 = (unsigned)((nc < cs.cus) ? nc : cs.cus);
+#else
+        const unsigned grid12 = (unsigned)((nc < 2 * cs.cus) ? nc : 2 * cs.cus);
+#endif
+        a.ovf_count = a.colctr + 1;
+        a.ovf_list = (int *)((char *)workspace + col_base_bytes(COL_BATCH));
+        const int lds12 = GRID12_LDS_BYTES;
+        if (dtype == SURS_BF16)
+            hipLaunchKernelGGL(grid_mlp_kernel_v12<SURS_BF16>, dim3(grid12), dim3(V12_THREADS), lds12, st, a);
+        else
+            hipLaunchKernelGGL(grid_mlp_kernel_v12<SURS_F16>, dim3(grid12), dim3(V12_THREADS), lds12, st, a);
+        SURS_LAUNCH_CHECK();
+        // the tiles it left: kernel v10 over the list (an empty list costs one launch of workgroups that leave at once)
+        GridArgs b = a;
+        b.tile_list = a.ovf_list;
+        b.tile_count = a.ovf_count;
+        b.colctr = a.colctr + 2;
+        if (dtype == SURS_BF16)
+            hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_BF16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, b);
+        else
+            hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_F16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, b);
     } else if (kver == 10) {
         if (dtype == SURS_BF16)
             hipLaunchKernelGGL(grid_mlp_kernel_v10<SURS_BF16>, dim3(grid), dim3(V10_THREADS), GRID10_LDS_BYTES, st, a);
@@ -1354,6 +1392,26 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             hipLaunchKernelGGL(grid_mlp_kernel_v3<SURS_F16>, dim3(grid), dim3(256), GRID3_LDS_BYTES, st, a);
     }
     SURS_LAUNCH_CHECK();
+#ifdef SURS_V12_HIST
+    if (kver == 12 && dtype != SURS_F32) {
+        static unsigned long long *hist = nullptr;
+        if (!hist) {
+            SURS_HIP_CHECK(hipMalloc((void **)&hist, 65 * 8));
+            SURS_HIP_CHECK(hipMemset(hist, 0, 65 * 8));
+            SURS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_v12_hist), &hist, sizeof(hist)));
+            static unsigned long long *h2 = hist;
+            atexit([] {
+                unsigned long long v[65];
+                if (hipMemcpy(v, h2, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return;
+                unsigned long long tot = 0;
+                for (int i = 0; i < 65; ++i) tot += v[i];
+                fprintf(stderr, "v12 tiles by residual k-steps (total %llu):", tot);
+                for (int i = 0; i < 65; ++i) if (v[i]) fprintf(stderr, " %d:%.4f", i, (double)v[i] / (double)tot);
+                fprintf(stderr, "\n");
+            });
+        }
+    }
+#endif
 #ifdef SURS_V3_TRACE
     if (trace_this && getenv("SURS_V3_TRACE")) {
         unsigned long long t[64];
@@ -1443,7 +1501,7 @@ static int query_grid_impl(int i0, int i1, int ry, int rz, const double *mat, co
     cs.h = h;
     cs.dtype = dtype;
     resolve_column_kernels(kernel_call, cs.kver, cs.kver32);
-    cs.restated = dtype == SURS_F32 ? cs.kver32 == 11 : cs.kver == 10;
+    cs.restated = dtype == SURS_F32 ? cs.kver32 == 11 : (cs.kver == 10 || cs.kver == 12);
     cs.feat_lr = feat_lr; cs.hl = hl; cs.wl = wl;
     cs.feat_hr = feat_hr; cs.hh = hh; cs.wh = wh;
     cs.mat = mat; cs.calib = calib; cs.zmul = zmul; cs.zdiv = zdiv;
