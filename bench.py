@@ -13,14 +13,18 @@ column kernel v11, split-f16 operands, logits within 1e-4 of the reference).  At
 the field and the meshes at full size against the fp32 sweep (tools/precision_report.py; asserted in
 tests/test_gpu_precision.py).
 
-N > 1, default `--mode replicas` (BASELINE configs[4], weak scaling): one subject per GPU (image seeds 1..N), every rank
-runs the whole reconstruction, no data-path collective - subjects are independent, which is how a batch of inputs
-is served; `value` = N x 512^3 queries per max-over-ranks step time.
-`--mode slab` (BASELINE configs[3], strong scaling of ONE subject): the grid is split into contiguous x-slabs, one per
-rank, every rank runs the (small) encoder redundantly and extracts the mesh of its own slab while it sweeps (marching
-cubes sharded with a one-plane halo); the ranks exchange the halo planes, the per-rank vertex / face counts and the
-vertex ids of the boundary planes, and rank 0 receives meshes, not volumes (dist.reconstruction_sharded).
-Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle - test infrastructure, the
+N > 1, default `--mode both`: BOTH configurations north_star names, in one invocation and one JSON line.
+  * the headline = `slab` (BASELINE configs[3], STRONG scaling of ONE subject - the number the ">= 6x at 8 GPUs" target is read
+    from): the grid is split into contiguous x-slabs, one per rank; super_res runs on the rank's image strip, feature_lr is
+    all-gathered, every rank extracts the mesh of its own slab while it sweeps (marching cubes sharded with a one-plane halo); the
+    ranks exchange the halo planes, the per-rank vertex / face counts and the vertex ids of the boundary planes, and rank 0
+    receives meshes, not volumes (dist.encode_sharded, dist.reconstruction_sharded).  `value` = 512^3 queries per max-over-ranks
+    step time, `scaling` = "strong", classifier precision = --precision (bf16).
+  * `config.replicas` = BASELINE configs[4] (weak scaling): one subject per GPU (image seeds 1..N), classifiers in FP16 as that
+    config names, every rank runs the whole reconstruction, no data-path collective; its own value (N x 512^3 per max-over-ranks
+    step), ms_per_step and stage_ms.
+`--mode slab` / `--mode replicas` run one of them as the headline (replicas then in --precision; the workload string says
+configs[4] only when that is fp16).  Rank 0 prints ONE JSON line.  The CPU baseline leg (rank 0, N=1 only) times the oracle - test infrastructure, the
 checker, never the thing measured - on a bounded sample of the same grid.
 """
 import argparse
@@ -53,8 +57,9 @@ def main():
     ap.add_argument("--resolution", type=int, default=RES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip config.fp32_mode and config.precision_acceptance (N=1)")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "slab"],
-                    help="N>1 only: one subject per GPU (weak) or one subject split into x-slabs, meshes extracted per slab (strong)")
+    ap.add_argument("--mode", default="both", choices=["both", "replicas", "slab"],
+                    help="N>1 only: slab = one subject split into x-slabs (strong scaling, configs[3]); replicas = one subject per GPU "
+                         "(weak, configs[4]); both (default) = slab as the headline + the fp16 replicas leg in config.replicas")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: nccl = RCCL, one rank per GPU (the measured configuration); gloo = host-staged exchange, ranks may share "
                          "a GPU (LOCAL_RANK modulo the device count) - lets the N>1 code paths run on a single-GPU box (tests)")
@@ -92,9 +97,10 @@ def main():
     net = model.SuRSNet(opt).to(device=dev)
     net.load_state_dict(sd)
     net.eval()
-    slab = world > 1 and args.mode == "slab"
+    slab = world > 1 and args.mode in ("slab", "both")      # the headline leg of this run
     make_image = weights.smooth_image if args.image == "smooth" else weights.synthetic_image
-    image = torch.from_numpy(make_image(IMG, seed=1 if slab else 1 + rank)).to(dev)
+    image_one = torch.from_numpy(make_image(IMG, seed=1)).to(dev)                 # slab: every rank the same subject
+    image_own = torch.from_numpy(make_image(IMG, seed=1 + rank)).to(dev)          # replicas: one subject per rank
     calib = train_util.gen_calib().to(dev)
     b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
     lib = _lib.lib()
@@ -104,10 +110,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(o, steps, warmup, net=net):
+    def run(o, steps, warmup, net=net, slab=slab):
         """warmup untimed steps, then `steps` timed ones between barriers; -> (seconds, per-stage ms, mesh sizes, kernel timing)."""
         stage_ms = {"encoder": 0.0, "query": 0.0, "exchange": 0.0, "mesh": 0.0}
         last = {}
+        image = image_one if (slab or world == 1) else image_own
 
         def step(timed):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -158,11 +165,13 @@ def main():
             dt = float(t.item())
         k_avg_ms = kms.value / max(launches.value, 1.0)
         kavg = ksteps.value / ktiles.value if ktiles.value > 0 else None
+        last["column_kernel"] = getattr(net._workspace(), "kernel_choice", (0, None))   # (version the probe picked, listed channels per tile)
         return dt, {k: v / steps for k, v in stage_ms.items()}, dict(last), (k_avg_ms, kpts.value / max(launches.value, 1.0), kavg)
 
-    def roofline(prec, k_avg_ms, k_pts, kavg=None):
+    def roofline(prec, k_avg_ms, k_pts, kavg=None, kver=0):
         """The column kernel of this precision, timed with HIP events around every launch on its launch stream."""
         nprod = PRODUCTS[prec]
+        kver = kver or int(os.environ.get("SURS_GRID_F32_KERNEL" if prec == "fp32" else "SURS_GRID_KERNEL", "11" if prec == "fp32" else "12"))
         alg = k_pts * FLOP_PER_QUERY / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         # what the matrix pipe executes per query: the dense cores of layers 1-3 (column-constant reduction, A.4); with column
         # kernels v10 / v11: layer 1 is one affine k-step + the measured residual k-steps (16 channels x 512 rows each) instead of 64
@@ -170,8 +179,8 @@ def main():
         flop_exec = FLOP_EXECUTED * nprod if kavg is None else 2 * (2 * (512 * 256 + 256 * 128) * nprod + (kavg * nprod + 1.0) * 16 * 512 * 2)
         exe = k_pts * flop_exec / (k_avg_ms * 1e-3) / 1e12 if k_avg_ms > 0 else 0.0
         peak = PEAK_MFMA / 1e12
-        r = {"kernel": "grid_mlp_kernel_v%s (split-f16, 3 products per MAC)" % os.environ.get("SURS_GRID_F32_KERNEL", "11") if prec == "fp32" else
-                       "grid_mlp_kernel_v%s<%s>" % (os.environ.get("SURS_GRID_KERNEL", "10"), prec),
+        r = {"kernel": "grid_mlp_kernel_v%d (split-f16, 3 products per MAC)" % kver if prec == "fp32" else
+                       "grid_mlp_kernel_v%d<%s>%s" % (kver, prec, " (+ grid_mlp_kernel_v10 on the tiles it hands over: inside the timed launches)" if kver == 12 else ""),
              "bound": "mfma", "unit": "TFLOP/s",
              # contract fields = what the matrix pipe EXECUTES per launch / the launch's duration against the dense f16 / bf16 MFMA
              # peak: a utilisation.  (The column kernels restate layer 1 exactly - DESIGN 4.1c - and execute far fewer FLOP than
@@ -208,6 +217,24 @@ def main():
         return r
 
     dt, stage_ms, last, (k_avg_ms, k_pts, k_ks) = run(opt, args.steps, args.warmup)
+    kver_head = int(last.pop("column_kernel", (0, None))[0] or 0)
+
+    replicas = None
+    if world > 1 and args.mode == "both":
+        # BASELINE configs[4]: one subject per GPU, classifiers in fp16 (a network object of its own: the blob is packed per precision)
+        o16 = options.BaseOptions().parse(flags + ["--precision", "fp16"])
+        net16 = model.SuRSNet(o16).to(device=dev)
+        net16.load_state_dict(sd)
+        net16.eval()
+        d16, st16, last16, (k16, p16, ks16) = run(o16, args.steps, args.warmup, net=net16, slab=False)
+        kv16 = int(last16.pop("column_kernel", (0, None))[0] or 0)
+        replicas = {"workload": "BASELINE configs[4]: %d subjects (one per GPU), %d^3 grid each, loadSize 1024 (SR path), fp16 classifier cores "
+                                "on MFMA, fp32-grade encoder, no data-path collective" % (world, R),
+                    "dtype": "fp16", "scaling": "weak", "value": float(R) ** 3 * world * args.steps / d16, "unit": "queries/s",
+                    "ms_per_step": d16 / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "queries_per_step": int(float(R) ** 3 * world),
+                    "stage_ms_rank0": st16, "mesh": last16, "encoder_precision": "fp32-grade (two f16 parts)", "sharded_encoder": False,
+                    "roofline": roofline("fp16", k16, p16, ks16, kv16)}
+        del net16
 
     extras = {}
     if world == 1 and not args.no_extras and args.precision != "fp32":
@@ -219,8 +246,10 @@ def main():
         net32.eval()
         d32, st32, last32, (k32, p32, ks32) = run(o32, 2, 2, net=net32)   # (a new object: one reconstruction sizes the mesh buffers, one warms the streamed path)
         del net32
+        kv32 = int(last32.pop("column_kernel", (0, None))[0] or 0)
+        extras["fp32_ms_per_step"] = d32 / 2 * 1e3      # (the parity-mode step, also at the top level of config)
         extras["fp32_mode"] = {"dtype": "fp32", "value": float(R) ** 3 * 2 / d32, "unit": "queries/s", "ms_per_step": d32 / 2 * 1e3,
-                               "steps": 2, "warmup": 2, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32),
+                               "steps": 2, "warmup": 2, "stage_ms": st32, "mesh": last32, "roofline": roofline("fp32", k32, p32, ks32, kv32),
                                "tolerance": "logits within 1e-4 of the reference's fp32 path (tests/test_gpu_query.py, test_gpu_model.py)"}
     if world == 1 and not args.no_extras:
         # The restated column kernels' cost depends on the weights and features (how many layer-0 channels change LeakyReLU branch
@@ -230,7 +259,7 @@ def main():
         # what native.grid_kernel_for picks.
         try:
             lib.surs_set_grid_kernel(5 if args.precision == "fp32" else 3)
-            dfl, stf, _, (kf, pf, _) = run(opt, 2, 1)
+            dfl, stf, lastf, (kf, pf, _) = run(opt, 2, 1)
             lib.surs_set_grid_kernel(0)
             extras["dense_floor"] = {"kernel": "grid_mlp_kernel_v5" if args.precision == "fp32" else "grid_mlp_kernel_v3<%s>" % args.precision,
                                      "value": float(R) ** 3 * 2 / dfl, "unit": "queries/s", "ms_per_step": dfl / 2 * 1e3, "stage_ms": stf,
@@ -254,8 +283,9 @@ def main():
                 lr, hr = native.probe_listed(R // 2, R, R, tile, mat, cal, zmul, zdiv, fl, fh, blob, ws)
                 pick = native.grid_kernel_for(R, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws)
                 row = {"gain": gain, "listed_lr_per_tile": lr, "listed_hr_per_tile_upper": hr,
-                       "host_picks": pick or (11 if args.precision == "fp32" else 10)}
-                for name, kern in (("restated_ms", 11 if args.precision == "fp32" else 10), ("dense_ms", 5 if args.precision == "fp32" else 3)):
+                       "host_picks": pick or (11 if args.precision == "fp32" else 12)}
+                kerns = (("restated_ms", 11), ("dense_ms", 5)) if args.precision == "fp32" else (("streamed_v12_ms", 12), ("restated_ms", 10), ("dense_ms", 3))
+                for name, kern in kerns:
                     native.query_grid(0, 32, R, R, mat, cal, zmul, zdiv, fl, fh, blob, args.precision, ws, vh[:32], vl[:32], kernel=kern)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -398,8 +428,8 @@ def main():
                                                                for s in ("to_ref", "from_ref")}}
                                  for t in ("hr", "lr")} for p in ("bf16", "fp16")}
                 acc[name]["sweep_s"] = rep["sweep_s"]
-            if args.precision != "fp32" and getattr(opt, "encoder_precision", "auto") != "fp32":
-                # the reduced modes also run the encoder's 3x3 convolutions on ONE f16 product per MAC (--encoder_precision auto):
+            if args.precision != "fp32" and getattr(opt, "encoder_precision", "auto") == "f16":
+                # --encoder_precision f16 (opt-in) runs the encoder's 3x3 convolutions on ONE f16 product per MAC:
                 # the whole reduced pipeline against the whole fp32-grade one (noise field)
                 er = pr.encoder_report(dev, R, precisions=(args.precision,))
                 acc["encoder_f16"] = {"im_feat_lr": er["im_feat_lr"], "im_feat_hr": er["im_feat_hr"],
@@ -417,24 +447,33 @@ def main():
         queries = float(R) ** 3 * (1 if (slab or world == 1) else world)   # replicas: one full grid per rank
         ms_per_step = dt / args.steps * 1e3
         value = queries * args.steps / dt
-        cfg_no = 2 if world == 1 else (3 if slab else 4)
+        # (configs[4] names fp16: a replicas run in another precision is the same code path, not that configuration)
+        cfg = "configs[2]" if world == 1 else ("configs[3]" if slab else ("configs[4]" if args.precision == "fp16" else
+                                                                         "configs[4]'s replicas in %s (configs[4] itself names fp16)" % args.precision))
+        enc_reduced = getattr(opt, "encoder_precision", "auto") == "f16"
         out = {
             "metric": "occupancy queries/sec (dense %d^3 reconstruction: encoder + query sweep + 2x marching cubes)" % R,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if slab else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %s 512x512 synthetic image%s, %d^3 grid each, %s classifier cores on MFMA, "
+            "config": {"workload": "BASELINE %s: %s 512x512 synthetic image%s, %d^3 grid each, %s classifier cores on MFMA, %s encoder, "
                                    "HIP marching cubes x2 pipelined into the sweep%s" %
-                                   (cfg_no, "one" if (slab or world == 1) else str(world),
+                                   (cfg, "one" if (slab or world == 1) else str(world),
                                     "" if (slab or world == 1) else "s (one subject per GPU, replicas)", R,
                                     "split-f16 (fp32-grade)" if args.precision == "fp32" else args.precision,
-                                    ", x-slab per rank, marching cubes per slab, meshes to rank 0" if slab else ""),
+                                    "f16-product (reduced, opt-in)" if enc_reduced else "fp32-grade",
+                                    ", x-slab per rank (super_res per image strip, feature_lr all-gathered), marching cubes per slab, meshes to rank 0" if slab else ""),
+                       "encoder_precision": "f16 (one product per MAC in the 3x3 convolutions)" if enc_reduced else "fp32-grade (two f16 parts, three products per MAC)",
+                       "sharded_encoder": bool(slab),
+                       "scaling_target_read_from": "this line's value at N = 1, 2, 4, 8 (slab, strong scaling): north_star's >= 6x at 8 GPUs" if (slab or world == 1) else None,
                        "resolution": R, "image": IMG, "image_kind": args.image, "queries_per_step": int(queries),
                        "reconstruction_s": ms_per_step / 1e3, "stage_ms_rank0": stage_ms,
                        "mesh": last, "parallelism": ("slab%d" % world) if slab else ("replicas%d" % world),
                        "backend": None if world == 1 else args.backend},
-            "roofline": roofline(args.precision, k_avg_ms, k_pts, k_ks),
+            "roofline": roofline(args.precision, k_avg_ms, k_pts, k_ks, kver_head),
         }
+        if replicas is not None:
+            out["config"]["replicas"] = replicas
         out["config"].update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, sd, R, b_min, b_max)

@@ -170,7 +170,8 @@ int surs_set_operand_split_local(int parts);
 
 /* Column kernel of surs_query_grid, process-wide (A/B comparisons and regression tests; a per-call choice goes through
  * surs_query_grid_opt): 0 = default (or the SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL environment variables); reduced precision
- * 3 (dense layer 1), 10 (layer 1 restated along the column); fp32-grade 5 (dense), 11 (restated) - DESIGN.md section 4. */
+ * 3 (dense layer 1), 10 (layer 1 restated along the column, eight waves), 12 (the default: 10's arithmetic and bits with layer 1
+ * streamed into layer 2, two workgroups per compute unit); fp32-grade 5 (dense), 11 (restated) - DESIGN.md section 4. */
 int surs_set_grid_kernel(int version);
 
 /* How many of the 1024 layer-0 channels the default column kernels (layer 1 restated along the column) would
@@ -231,7 +232,7 @@ int surs_query_grid(int i0, int i1, int ry, int rz, const double *mat, const flo
 size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype);
 
 /* The same sweep with per-call choices instead of process-wide ones (nothing global is read for a field that is set, nothing
- * global is written): `kernel` = column-kernel version (0 = the process setting / default; reduced precision 3, 10;
+ * global is written): `kernel` = column-kernel version (0 = the process setting / default; reduced precision 3, 10, 12;
  * fp32-grade 5, 11 - DESIGN.md 4), `operand_parts` = operand split of the fp32-grade GEMMs behind the sweep (0 = process
  * setting, 2 = two f16 parts, 3 = three bf16 parts).  opt == NULL behaves as surs_query_grid.  Safe to call from several host
  * threads on different streams. */

@@ -704,7 +704,7 @@ static int zero_pad_rows(hipStream_t st, const Fp32Workspace &w) {
 }
 
 #ifndef SURS_DEFAULT_GRID_KERNEL
-#define SURS_DEFAULT_GRID_KERNEL 10
+#define SURS_DEFAULT_GRID_KERNEL 12
 #endif
 #ifndef SURS_DEFAULT_GRID_F32_KERNEL
 #define SURS_DEFAULT_GRID_F32_KERNEL 11
@@ -713,7 +713,7 @@ static int g_grid_kernel_override = 0;   // surs_set_grid_kernel
 static bool grid_kernel_known(int v) { return v == 0 || v == 3 || v == 10 || v == 12 || v == 5 || v == 11; }
 extern "C" int surs_set_grid_kernel(int version) {
     SURS_REQUIRE(grid_kernel_known(version),
-                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3 or 10, fp32-grade 5 or 11");
+                 "column kernel: 0 (default / SURS_GRID_KERNEL), reduced precision 3, 10 or 12, fp32-grade 5 or 11");
     g_grid_kernel_override = version;
     return 0;
 }
@@ -1139,7 +1139,7 @@ extern "C" int surs_query_grid_opt(int i0, int i1, int ry, int rz, const double 
     if (opt) {
         kernel = opt->kernel;
         parts = opt->operand_parts;
-        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 10 (reduced precision), 5, 11 (fp32-grade)");
+        SURS_REQUIRE(grid_kernel_known(kernel), "SursGridOptions.kernel: 0, 3, 10, 12 (reduced precision), 5, 11 (fp32-grade)");
         SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "SursGridOptions.operand_parts: 0, 2 or 3");
     }
     // the operand split is read deep inside the launch helpers: scoped to this call and this thread, the process setting
@@ -1178,9 +1178,11 @@ struct ColumnSweep {
 };
 }  // namespace
 
-// Column kernel of a sweep.  Reduced precision: 10 (default) = layer 1 restated along the column as a per-column affine part +
-// the residuals of the channels whose LeakyReLU branch changes inside the z tile, eight waves per workgroup; 3 = dense layer 1
-// (what the host asks for on fields that list most channels; differs from 10 by a few 16-bit roundings of layer 0).  fp32-grade
+// Column kernel of a sweep.  Reduced precision: 12 (default) and 10 = layer 1 restated along the column as a per-column affine part +
+// the residuals of the channels whose LeakyReLU branch changes inside the z tile - 10 on eight waves per workgroup with y1 whole in
+// LDS, 12 as two workgroups of four waves per CU with layer 1 streamed into layer 2 (same bits; tiles that list more than it stages
+// go to 10's tile mode); 3 = dense layer 1 (what the host asks for on fields that list most channels; differs from 10 / 12 by a few
+// 16-bit roundings of layer 0).  fp32-grade
 // (SURS_F32): 11 (default: restated, eight waves) or 5 (dense).  Precedence: the call's SursGridOptions.kernel, then
 // surs_set_grid_kernel, then SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL, then the default.
 static void resolve_column_kernels(int kernel_call, int &kver, int &kver32) {
@@ -1428,6 +1430,24 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             }
         }
         fprintf(stderr, "v3 trace between MLPs: %llu\n", t[16] - t[9]);
+        if (kver == 12 && dtype != SURS_F32) {
+            unsigned long long acc[2][16];
+            SURS_HIP_CHECK(hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_v12_acc), sizeof(acc)));
+            for (int m = 0; m < 2; ++m) {
+                const double n = (double)(acc[m][0] ? acc[m][0] : 1);
+                double tot = 0;
+                fprintf(stderr, "v12 mean cycles per item, MLP %d (%llu items, %.2f residual k-steps): ", m, acc[m][0], (double)acc[m][15] / n);
+                for (int i = 1; i < 10; ++i) {
+                    fprintf(stderr, " %.0f", (double)acc[m][i] / n);
+                    tot += (double)acc[m][i] / n;
+                }
+                fprintf(stderr, "  total %.0f  [list | residuals + slices | acc2 init + barrier | stages 0-8 | stages 9-16 | y2 publish | barrier | layer 3 | layer 4]\n", tot);
+            }
+            fprintf(stderr, "v12 traced workgroup: %.0f cycles in %.1f us = %.3f GHz\n", (double)acc[0][13], (double)acc[0][14] / 100.0,
+                    (double)acc[0][13] / ((double)acc[0][14] / 100.0) * 1e-3);
+            unsigned long long zero[2][16] = {};
+            SURS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_v12_acc), zero, sizeof(zero)));
+        }
         const double cyc = (double)(t[42] - t[40]), us = (double)(t[43] - t[41]) / 100.0;
         const int tile = dtype == SURS_F32 ? 64 : 128;
         fprintf(stderr, "workgroup 0: %.0f cycles in %.1f us = %.3f GHz; %.0f cycles per %d-point tile\n", cyc, us,

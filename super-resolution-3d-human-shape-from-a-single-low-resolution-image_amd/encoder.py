@@ -24,12 +24,14 @@ class EncoderWeights:
         self.conv = {}
         self.gn = {}
         self.opt = opt
-        # --encoder_precision: "fp32" = two f16 parts, three products per MAC (parity mode); "f16" = one f16 product in the 3x3
-        # convolutions (features within 1.8e-3 / 4e-4 of their range); "auto" = f16 with --precision bf16 only: measured at 512^3
-        # (tools/precision_report.py encoder, tests/test_gpu_precision.py) it adds a quarter to the bf16 sweep's own error
-        # (mean |d logit| 1.0e-3 -> 1.3e-3) but would multiply the fp16 sweep's by nine (6e-5 -> 5.9e-4)
+        # --encoder_precision: "fp32" (= "auto", the default) = two f16 parts, three products per MAC: the parity-grade encoder, whatever
+        # --precision says about the classifiers (BASELINE configs[2] / [4] name a bf16 / fp16 MLP, not a reduced encoder); "f16" = one
+        # f16 product in the 3x3 convolutions (features within 1.8e-3 / 4e-4 of their range, 2 ms of 7 per 512^2 image): opt-in only.
+        # Measured at 512^3 (tools/precision_report.py encoder, tests/test_gpu_precision.py) it adds a quarter to the bf16 sweep's own
+        # error (mean |d logit| 1.0e-3 -> 1.3e-3) and would multiply the fp16 sweep's by nine (6e-5 -> 5.9e-4).  (Round 4 made it the
+        # default of --precision bf16; round 5 took that back.)
         ep = getattr(opt, "encoder_precision", "auto")
-        self.reduced = ep == "f16" or (ep == "auto" and getattr(opt, "precision", "fp32") == "bf16")
+        self.reduced = ep == "f16"
 
         def get(k):
             v = sd[k]

@@ -488,6 +488,10 @@ def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, d
 # the eight-wave bf16 / fp16 kernel still wins at 490 listed - 254 against 290 ms at 512^3 - and gains 0.3 ms per listed channel)
 LISTED_DENSE_THRESHOLD = 400.0
 LISTED_DENSE_THRESHOLDS = {"fp32": 400.0, "bf16": 600.0, "fp16": 600.0}
+# bf16 / fp16: mean listed channels per tile up to which the streamed two-workgroup kernel (12) is used; above it the eight-wave kernel
+# (10), whose chunks of 96 channels loop: kernel 12 stages 144 channels per tile and hands fuller tiles to kernel 10 one by one, which
+# pays only while they are rare (bench field: 70 listed, one tile in 10^4; layer-0 depth gain 16: 212 listed, 264 against 233 ms)
+LISTED_STREAM_THRESHOLD = 96.0
 
 
 def probe_listed(i_plane, ry, rz, tile, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws):
@@ -504,9 +508,10 @@ def probe_listed(i_plane, ry, rz, tile, mat, calib, zmul, zdiv, feat_lr, feat_hr
 
 
 def grid_kernel_for(rx, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws):
-    """Column-kernel version for a sweep of the rx x ry x rz grid `mat` describes: 0 (the library's default: layer 1 restated
-    along the column) unless the probe says the sweep lists so many channels per tile that the dense kernels (3 for bf16 /
-    fp16, 5 for fp32) are faster.  A deterministic function of the grid, the calibration, the features and
+    """Column-kernel version for a sweep of the rx x ry x rz grid `mat` describes.  fp32: 0 (the library's default, 11: layer 1
+    restated along the column) unless the probe says the sweep lists so many channels per tile that the dense kernel (5) is
+    faster.  bf16 / fp16: 12 (restated, layer 1 streamed into layer 2, two workgroups per CU) while the probe's mean stays under
+    LISTED_STREAM_THRESHOLD, 10 (restated, eight waves) above it, 3 (dense) above LISTED_DENSE_THRESHOLDS.  A deterministic function of the grid, the calibration, the features and
     the weights - the middle axis-0 plane of the WHOLE grid is probed, so every slab and every rank of a sharded sweep makes
     the same choice.  Probed on every call (one plane of column constants, about 0.3 ms and a stream synchronisation): the
     feature buffers are written through raw pointers into recycled allocator blocks, so nothing the host can see tells one
@@ -518,6 +523,8 @@ def grid_kernel_for(rx, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, 
         return 0
     lr, _ = probe_listed(rx // 2, ry, rz, 64 if dtype == "fp32" else 128, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
     kern = (5 if dtype == "fp32" else 3) if lr > LISTED_DENSE_THRESHOLDS[dtype] else 0
+    if kern == 0 and dtype != "fp32":
+        kern = 12 if lr <= LISTED_STREAM_THRESHOLD else 10
     ws.kernel_choice = (kern, lr)
     ws.probes = getattr(ws, "probes", 0) + 1
     return kern

@@ -67,9 +67,9 @@ _IGNORED = [
 # extensions of this package (not in the reference)
 _NATIVE = [
     ("precision", str, "fp32"),      # fp32 | bf16 | fp16 : arithmetic of the MLP contractions
-    ("encoder_precision", str, "auto"),   # fp32 (two f16 parts, three products per MAC: the parity mode) | f16 (one f16 product per
-                                          # MAC in the 3x3 convolutions: 11 significant bits) | auto = f16 with --precision bf16 (whose
-                                          # sweep rounds the features' contributions to 8 bits anyway), fp32 otherwise
+    ("encoder_precision", str, "auto"),   # fp32 = auto (two f16 parts, three products per MAC: the parity-grade encoder, with every
+                                          # --precision) | f16 (one f16 product per MAC in the 3x3 convolutions: 11 significant bits,
+                                          # opt-in; bounded by tests/test_gpu_precision.py with --precision bf16)
     ("no_octree", None, False),      # dense sweep (the parity target)
     ("synthetic", None, False),      # synthetic image + PRNG weights instead of dataroot / checkpoint
     ("pipeline", None, False),       # eval driver: subjects as a pipeline (train_util.gen_mesh_pipelined) instead of one by one

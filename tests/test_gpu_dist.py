@@ -59,27 +59,45 @@ def test_super_res_strip_equals_full_columns():
             assert torch.equal(hwc(g), hwc(f)[:, sc * a:sc * b, :]), (a, b, sc)
 
 
-@pytest.mark.parametrize("mode", ["slab", "replicas"])
+@pytest.mark.parametrize("mode", ["default", "slab", "replicas"])
 def test_bench_multi_rank_paths_on_one_gpu(mode):
-    """bench.py's N > 1 code paths (BASELINE configs[3] = slab, configs[4] = replicas), launched as the driver launches them
-    (torch.distributed.run, one process per rank) but with `--backend gloo` so that two ranks can share the one GPU of this box:
-    one JSON line from rank 0, the contract's keys, whole-job queries (slab: one grid; replicas: one grid per rank)."""
+    """bench.py's N > 1 code paths, launched as the driver launches them (torch.distributed.run, one process per rank, `--gpus N` and
+    nothing else - mode "default") but with `--backend gloo` so that two ranks can share the one GPU of this box: ONE JSON line from
+    rank 0 with the contract's keys.  The default launch measures BOTH configurations north_star names: the headline is the slab run
+    (BASELINE configs[3]: strong scaling, one grid for the whole job, sharded encoder, --precision bf16) and config.replicas holds the
+    one-subject-per-GPU leg in fp16 (configs[4]: weak scaling, one grid per rank) with its own step time and stage times.  `--mode slab`
+    / `--mode replicas` run one leg as the headline; a replicas run that is not fp16 must not call itself configs[4]."""
     import json
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--resolution", "64", "--mode", mode, "--backend", "gloo"]
+           "--resolution", "64", "--backend", "gloo"] + ([] if mode == "default" else ["--mode", mode])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
+    head = "replicas" if mode == "replicas" else "slab"
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["unit"] == "queries/s" and d["value"] > 0
-    assert d["scaling"] == ("strong" if mode == "slab" else "weak")
-    assert d["config"]["queries_per_step"] == 64 ** 3 * (1 if mode == "slab" else 2)
-    assert d["config"]["parallelism"] == mode + "2" and d["config"]["mesh"]["verts_hr"] > 0
+    assert d["scaling"] == ("strong" if head == "slab" else "weak")
+    assert d["config"]["queries_per_step"] == 64 ** 3 * (1 if head == "slab" else 2)
+    assert d["config"]["parallelism"] == head + "2" and d["config"]["mesh"]["verts_hr"] > 0
     assert abs(d["value"] - d["config"]["queries_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d and d["roofline"]["avg_launch_ms"] > 0
+    assert d["config"]["sharded_encoder"] is (head == "slab") and d["config"]["encoder_precision"].startswith("fp32-grade")
+    w = d["config"]["workload"]
+    if head == "slab":
+        assert d["dtype"] == "bf16" and "configs[3]" in w and d["config"]["scaling_target_read_from"]
+    else:
+        assert "configs[4] itself names fp16" in w        # (--precision bf16: the same code path, not that configuration)
+    if mode == "default":
+        rp = d["config"]["replicas"]
+        assert rp["dtype"] == "fp16" and rp["scaling"] == "weak" and "configs[4]" in rp["workload"] and rp["sharded_encoder"] is False
+        assert rp["queries_per_step"] == 2 * 64 ** 3 and rp["value"] > 0 and rp["mesh"]["verts_hr"] > 0
+        assert abs(rp["value"] - rp["queries_per_step"] / (rp["ms_per_step"] * 1e-3)) / rp["value"] < 1e-6
+        assert set(rp["stage_ms_rank0"]) >= {"encoder", "query", "mesh"} and rp["roofline"]["avg_launch_ms"] > 0
+    else:
+        assert "replicas" not in d["config"]
 
 
 def test_nccl_backend_world_size_one():

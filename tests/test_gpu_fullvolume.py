@@ -82,3 +82,26 @@ def test_restated_kernels_equal_dense_kernels_on_the_whole_volume(field):
         allf = json.load(open(dump)) if os.path.exists(dump) else {}
         allf[field] = out
         json.dump(allf, open(dump, "w"), indent=1)
+
+
+@pytest.mark.parametrize("field", ["noise", "body", "gain60"])
+def test_streamed_kernel_v12_equals_v10_bit_for_bit(field):
+    """Column kernel v12 (two workgroups of four waves per CU, layer 1 streamed into layer 2 by 32-row chunks: the default of the
+    reduced precisions) against v10 (eight waves, y1 whole in LDS), every voxel of both 512^3 fields, bf16 and fp16: the same list
+    order, the same k order in every layer, the same four layer-4 partial sums - the same bits.  The gain-60 field lists ~490
+    channels per tile: nearly every tile leaves v12 through its overflow list and is evaluated by v10's tile mode behind it, so
+    the hand-over (list, counter, second launch) is what that case holds to v10's plain sweep.  (A packed fma that hipcc formed in
+    v12's last phase lost its product in a quarter wave with two workgroups on a CU - NOTES R5.1; this is the test that found it.)"""
+    import precision_report as pr
+    from surs_amd import native
+    dev = native.require_gpu()
+    sd, Fl, Fh, keep = _inputs(field, dev)
+    for prec in (("bf16", "fp16") if field == "noise" else ("bf16",)):
+        ref, _, _ = pr.sweeps(sd, Fl, Fh, R, (prec,), dev, kernel=10)
+        new, _, _ = pr.sweeps(sd, Fl, Fh, R, (prec,), dev, kernel=12)
+        for i, tag in enumerate(("hr", "lr")):
+            assert bool(torch.isfinite(new[prec][i]).all())
+            nbad = int((new[prec][i] != ref[prec][i]).sum())
+            assert nbad == 0, (field, prec, tag, nbad, float((new[prec][i] - ref[prec][i]).abs().max()))
+        del ref, new
+

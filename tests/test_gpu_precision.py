@@ -65,12 +65,12 @@ def test_body_field_is_one_closed_surface(reports):
 
 
 def test_reduced_encoder_acceptance_512():
-    """--precision bf16 also runs the encoder's 3x3 convolutions on ONE f16 product per MAC (--encoder_precision auto).  The whole
+    """--encoder_precision f16 (opt-in) runs the encoder's 3x3 convolutions on ONE f16 product per MAC.  The whole
     reduced pipeline (f16-product encoder + bf16 sweep) against the whole fp32-grade one (two-part encoder + fp32-grade sweep) at
     512^3 on the bench's noise field, in the terms of the test above; bounds = about twice the values measured on MI355X (round 4:
     features within 1.8e-3 / 3.8e-4 of their range; max |d logit| 0.0074, mean 0.0013, 1.1e-3 of the voxels across 0.5 - the bf16
     sweep alone: 0.0049 / 0.0010 / 9e-4).  For fp16 the same encoder would be the dominant error (mean 5.9e-4 against the sweep's
-    6e-5): `auto` keeps the fp32-grade encoder there, asserted below."""
+    6e-5).  `auto` (the default) is the fp32-grade encoder with every --precision, asserted below."""
     import precision_report as pr
     from surs_amd import encoder, native, options
     dev = native.require_gpu()
@@ -87,9 +87,12 @@ def test_reduced_encoder_acceptance_512():
         for side in ("to_ref", "from_ref"):
             d = m[side]
             assert d["mean"] < b[4] and d["p999"] < b[5] and d["unmatched"] <= b[6] * d["n"], (tag, side, d)
-    # what `auto` selects
-    for prec, want in (("fp32", False), ("bf16", True), ("fp16", False)):
+    # what `auto` selects: the fp32-grade encoder, whatever the classifiers' precision; the reduced one only when asked for
+    from surs_amd import weights
+    for prec in ("fp32", "bf16", "fp16"):
         opt = options.BaseOptions().parse(pr.FLAGS + ["--precision", prec])
-        assert (getattr(opt, "encoder_precision") == "auto")
-        ep = opt.encoder_precision
-        assert (ep == "f16" or (ep == "auto" and opt.precision == "bf16")) == want
+        assert getattr(opt, "encoder_precision") == "auto"
+        sd = weights.synthetic_state_dict(opt, seed=0)
+        assert encoder.EncoderWeights(sd, opt, dev).reduced is False
+    opt = options.BaseOptions().parse(pr.FLAGS + ["--precision", "bf16", "--encoder_precision", "f16"])
+    assert encoder.EncoderWeights(weights.synthetic_state_dict(opt, seed=0), opt, dev).reduced is True

@@ -180,8 +180,8 @@ def test_grid_fp32_column_kernel_vs_layer_kernels(setup):
 
 
 def test_restated_kernels_match_dense_kernel(tmp_path):
-    """The restated column kernel (layer 1 as a per-column affine part + the residuals of the listed channels: v10;
-    R = 40 runs several chunks per tile) against the dense-layer-1 kernel v3 on the same inputs, each in
+    """The restated column kernels (layer 1 as a per-column affine part + the residuals of the listed channels: v10 on eight
+    waves, v12 streamed on two workgroups per CU; R = 40 runs several chunks per tile) against the dense-layer-1 kernel v3 on the same inputs, each in
     its own process selected by SURS_GRID_KERNEL: <= 4e-3 on the occupancies (v3 rounds every layer-0 activation to 16 bits,
     the restated kernels carry the affine part at fp32 grade).  Every launch of a kernel must reproduce its own bits
     (three launches per size: race screen), for ragged and multi-tile grids."""
@@ -189,7 +189,7 @@ def test_restated_kernels_match_dense_kernel(tmp_path):
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     ref = str(tmp_path / "v3.npz")
-    for ver, mode in (("3", "save"), ("10", "cmp")):
+    for ver, mode in (("3", "save"), ("10", "cmp"), ("12", "cmp")):
         env = dict(os.environ, SURS_GRID_KERNEL=ver)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_grid_cmp.py"), mode, ref], env=env,
                            capture_output=True, text=True, timeout=600)

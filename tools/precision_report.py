@@ -169,7 +169,7 @@ def noise_inputs(dev, H=512, encoder_precision="fp32"):
 
 
 def encoder_report(dev, R=512, precisions=("bf16", "fp16"), sample=1 << 20):
-    """What the reduced-precision ENCODER (--encoder_precision f16, the default of --precision bf16 / fp16) adds: the feature maps
+    """What the reduced-precision ENCODER (--encoder_precision f16, opt-in) adds: the feature maps
     against the fp32-grade encoder's, and the whole reduced pipeline (f16 encoder + 16-bit sweep) against the whole fp32-grade one
     (fp32-grade encoder + fp32-grade sweep) on the bench's noise field, in the terms of report()."""
     sd, Fl, Fh, keep = noise_inputs(dev, encoder_precision="fp32")
