@@ -88,6 +88,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        sdist.init_host_group()   # (the host-side row exchanges of slab mode: created now, collectively, not inside the first reconstruction)
 
     R = args.resolution
     flags = ["--loadSize", "1024", "--residual", "--b_min", "-0.5", "-0.5", "-0.5", "--b_max", "0.5", "0.5", "0.5",
@@ -362,30 +363,38 @@ def main():
             ijk = np.stack([idx // (R * R), (idx // R) % R, idx % R]).astype(np.float64)
             pts_all = np.matmul(mat4[:3, :3], ijk) + mat4[:3, 3:4]
 
-            def eval_func(points):   # lib/mesh_util.py:20-28 (np.repeat is what makes the strided chunk view contiguous)
+            def eval_func(nn, points):   # lib/mesh_util.py:20-28 (np.repeat is what makes the strided chunk view contiguous)
                 points = np.expand_dims(points, axis=0)
-                points = np.repeat(points, n32.num_views, axis=0)
+                points = np.repeat(points, nn.num_views, axis=0)
                 samples = torch.from_numpy(points).to(device=dev).float()
-                n32.query_mr(samples, calib)
-                n32.query_sr(samples, calib)
-                return n32.get_preds()[0][0].detach().cpu().numpy(), n32.get_preds()[1][0].detach().cpu().numpy()
+                nn.query_mr(samples, calib)
+                nn.query_sr(samples, calib)
+                return nn.get_preds()[0][0].detach().cpu().numpy(), nn.get_preds()[1][0].detach().cpu().numpy()
 
             out_hr, out_lr = np.zeros(pts_all.shape[1]), np.zeros(pts_all.shape[1])
 
-            def loop():                # lib/sdf.py:32-45
+            def loop(nn):                # lib/sdf.py:32-45
                 for i in range(pts_all.shape[1] // ns):
-                    out_hr[i * ns:(i + 1) * ns], out_lr[i * ns:(i + 1) * ns] = eval_func(pts_all[:, i * ns:(i + 1) * ns])
+                    out_hr[i * ns:(i + 1) * ns], out_lr[i * ns:(i + 1) * ns] = eval_func(nn, pts_all[:, i * ns:(i + 1) * ns])
 
-            loop()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            loop()
-            torch.cuda.synchronize()
-            tl = time.perf_counter() - t0
-            extras["reference_loop"] = {"what": "the reference's eval_grid loop (50 000-point chunks, host numpy in / out, lib/sdf.py:32-45) "
-                                                "around SuRSNet.query_mr / query_sr / get_preds, fp32",
-                                        "points": int(pts_all.shape[1] // ns * ns), "seconds": tl, "value": pts_all.shape[1] // ns * ns / tl,
-                                        "unit": "queries/s", "ms_per_50k_chunk": tl / (pts_all.shape[1] // ns) * 1e3}
+            for key, nn, what in (("reference_loop", n32, "fp32 (the facade's default: fp32-grade layer kernels, three products per MAC)"),
+                                  ("reference_loop_reduced", net, "--precision %s (one f16 product per MAC in the point path)" % args.precision)):
+                if key == "reference_loop_reduced" and args.precision == "fp32":
+                    continue
+                loop(nn)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(nn)
+                torch.cuda.synchronize()
+                tl = time.perf_counter() - t0
+                extras[key] = {"what": "the reference's eval_grid loop (50 000-point chunks, host numpy in / out, lib/sdf.py:32-45) "
+                                       "around SuRSNet.query_mr / query_sr / get_preds, " + what,
+                               "points": int(pts_all.shape[1] // ns * ns), "seconds": tl, "value": pts_all.shape[1] // ns * ns / tl,
+                               "unit": "queries/s", "ms_per_50k_chunk": tl / (pts_all.shape[1] // ns) * 1e3}
+                if key == "reference_loop":
+                    ref_hr = out_hr.copy()
+                else:
+                    extras[key]["max_abs_docc_vs_fp32_loop"] = float(np.abs(out_hr - ref_hr).max())
         except Exception as e:
             extras["reference_loop"] = {"error": repr(e)}
         try:

@@ -165,7 +165,10 @@ size_t surs_mlp_pack(const float *const w_lr[5], const float *const b_lr[5], con
  * range), 0 = back to the default (or the SURS_SPLIT environment variable).  Both meet the 1e-4 logit tolerance. */
 int surs_set_operand_split(int parts);
 /* The same for the calling host thread only (0 = back to the process-wide setting); takes precedence over it.  The host mirror
- * uses it to repeat a query or a sweep on three bf16 parts after an f16 overflow (non-finite results). */
+ * uses it to repeat a query or a sweep on three bf16 parts after an f16 overflow (non-finite results).  parts = 1 (this call only):
+ * surs_query_points / surs_query_points_hr run ONE f16 product per MAC (one f16 part per operand, 11 significant bits, a third of the
+ * matrix work) - NOT fp32-grade: what SuRSNet.query_mr / query_sr of `--precision bf16 | fp16` evaluate arbitrary points with, as the
+ * reference's MLP would in half precision (lib/model/SurfaceClassifier.py:53-81); every other entry point ignores it. */
 int surs_set_operand_split_local(int parts);
 
 /* Column kernel of surs_query_grid, process-wide (A/B comparisons and regression tests; a per-call choice goes through

@@ -420,7 +420,8 @@ static int split_parts() {
         const char *e = getenv("SURS_SPLIT");
         v = (e && e[0] == 'b') ? 3 : 2;
     }
-    const int want = t_split_call ? t_split_call : (g_split_override ? g_split_override : v);
+    // (a thread's 1 = the one-product point path, run_points_fp32 only: everything else that asks here stays fp32-grade)
+    const int want = t_split_call > 1 ? t_split_call : (g_split_override ? g_split_override : v);
     return (gemm_use_x3() && gemm_use_big()) ? want : 3;
 }
 
@@ -440,6 +441,9 @@ static int g3_set_attributes() {
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 2)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256)));
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32_T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 1)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_SPLIT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 1)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 256, G3_F32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(256, 1)));
+        SURS_HIP_CHECK(hipFuncSetAttribute((const void *)gemm_x3g_kernel<8, 128, G3_F32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds_bytes(128, 1)));
     }
     return 0;
 }
@@ -464,6 +468,24 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
                                w3, M, K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
         else
             hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32, 2>), dim3(gemm_grid(M / 128, nb256)), dim3(512), g3_lds_bytes(128, 2), st,
+                               w3, M, K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
+        SURS_LAUNCH_CHECK();
+        return 0;
+    }
+    if (parts == 1) {   // ONE f16 part per operand (11 significant bits: the reduced-precision point path), same kernels and tiles
+        SURS_REQUIRE(np % 256 == 0 && (M % 256 == 0 || !Ys), "the one-part layer kernels need 256-point tiles");
+        int rca = g3_set_attributes();
+        if (rca) return rca;
+        const int nb256 = (int)(np / 256);
+        const long long yp = (long long)M * np;
+        if (Ys)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_SPLIT, 1>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256, 1), st,
+                               w3, M, K1 + K2, s1, s2, np, bias, (float *)nullptr, 0LL, Ys, yp, nb256);
+        else if (M % 256 == 0)
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 256, G3_F32, 1>), dim3(gemm_grid(M / 256, nb256)), dim3(512), g3_lds_bytes(256, 1), st,
+                               w3, M, K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
+        else
+            hipLaunchKernelGGL((gemm_x3g_kernel<8, 128, G3_F32, 1>), dim3(gemm_grid(M / 128, nb256)), dim3(512), g3_lds_bytes(128, 1), st,
                                w3, M, K1 + K2, s1, s2, np, bias, Y, np, (unsigned short *)nullptr, 0LL, nb256);
         SURS_LAUNCH_CHECK();
         return 0;
@@ -516,13 +538,18 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
                            int parts = 0, const float *p_lr_in = nullptr) {
     const long long np = w.np;
     const bool x3 = gemm_use_x3();
-    if (parts == 0) parts = split_parts();
+    // (the calling thread asked for the one-product point path - surs_set_operand_split_local(1): one f16 part per operand, the
+    //  first plane of the two-part weight image; three times less matrix work than the fp32-grade path, 11 significant bits)
+    if (parts == 0) parts = (t_split_call == 1 && x3 && gemm_use_big()) ? 1 : split_parts();
     unsigned short *Fs = x3 ? w.Fs : nullptr;
     const long long fs_part = (long long)C0PAD * np;
     // rows 322..335 of F meet zero weights and must be finite: the caller zeroes them once (zero_pad_rows; the split
     // image gets them from gather_kernel); rows < 322 are fully written for t < n; columns n..np-1 only feed outputs
     // that are never read
-    if (parts == 2)
+    if (parts == 1)
+        hipLaunchKernelGGL(gather_kernel<1>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
+                           hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
+    else if (parts == 2)
         hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, n, feat_lr, hl, wl, feat_hr,
                            hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
     else
@@ -530,7 +557,10 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
                            hh, wh, w.F, np, w.mask, (float *)nullptr, Fs, fs_part);
     SURS_LAUNCH_CHECK();
     if (p_lr_in) {   // the hr classifier alone, on the caller's lr occupancies
-        if (parts == 2)
+        if (parts == 1)
+            hipLaunchKernelGGL(patch_plr_kernel<1>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, p_lr_in, np, n,
+                               w.F + (size_t)(C_G + 1) * np, Fs, fs_part);
+        else if (parts == 2)
             hipLaunchKernelGGL(patch_plr_kernel<2>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, p_lr_in, np, n,
                                w.F + (size_t)(C_G + 1) * np, Fs, fs_part);
         else
@@ -540,7 +570,7 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
     }
     for (int m = p_lr_in ? 1 : 0; m < 2; ++m) {
         auto WT = [&](int l) { return (const float *)(blob + h.wt[m][l]); };
-        auto W3 = [&](int l) { return (const void *)(blob + (parts == 2 ? h.wt2[m][l] : h.wt3[m][l])); };
+        auto W3 = [&](int l) { return (const void *)(blob + (parts <= 2 ? h.wt2[m][l] : h.wt3[m][l])); };   // (one part: the image's first plane, f16(w))
         auto BI = [&](int l) { return (const float *)(blob + h.bias[m][l]); };
         int rc;
         if (x3) {
@@ -554,7 +584,12 @@ static int run_points_fp32(hipStream_t st, const PointSource &src, long long n, 
             if ((rc = launch_gemm(st, false, WT(2), nullptr, D3, w.Y1, D2, np, w.F, C0PAD, np, BI(2), 1, w.Y2, np, np))) return rc;
             if ((rc = launch_gemm(st, false, WT(3), nullptr, D4, w.Y2, D3, np, w.F, C0PAD, np, BI(3), 1, w.Y3, np, np))) return rc;
         }
-        if (parts == 2)
+        if (parts == 1)
+            hipLaunchKernelGGL(mlp_last_kernel<1>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                               (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
+                               m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr,
+                               m == 0 ? Fs : (unsigned short *)nullptr, fs_part);
+        else if (parts == 2)
             hipLaunchKernelGGL(mlp_last_kernel<2>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                                (const float *)(blob + h.w4[m]), w.Y3, w.F, np, n, w.mask, m == 0 ? pred_lr : pred_hr,
                                m == 0 ? logit_lr : logit_hr, m == 0 ? w.F + (size_t)(C_G + 1) * np : (float *)nullptr,
@@ -721,7 +756,7 @@ extern "C" int surs_set_grid_kernel(int version) {
 // The same choice for the calling host thread only (0 = back to the process setting): what a retry after an f16 overflow uses,
 // without touching what other threads compute with.
 extern "C" int surs_set_operand_split_local(int parts) {
-    SURS_REQUIRE(parts == 0 || parts == 2 || parts == 3, "parts: 0 (process setting), 2 (f16 x 2) or 3 (bf16 x 3)");
+    SURS_REQUIRE(parts >= 0 && parts <= 3, "parts: 0 (process setting), 1 (one f16 part: the point path of the reduced precisions), 2 (f16 x 2) or 3 (bf16 x 3)");
     t_split_call = parts;
     return 0;
 }

@@ -103,6 +103,24 @@ def _host_group(group):
     return g
 
 
+def _warn_safely(msg, stacklevel=3):
+    """warnings.warn that never raises (-W error / filterwarnings = error): these warnings are issued on ONE rank behind a point where
+    the ranks have agreed what to do next - an exception there would leave the peers waiting in the step that follows."""
+    import warnings
+    try:
+        warnings.warn(msg, stacklevel=stacklevel + 1)
+    except Exception:   # noqa: BLE001
+        import sys
+        print("warning: " + msg, file=sys.stderr)
+
+
+def init_host_group(group=None):
+    """Create the host-side (gloo) group of an RCCL job NOW - collectively, right after init_process_group - instead of at the first
+    row exchange inside a reconstruction: new_group must be entered by every rank, and a rank that has already failed by then would
+    leave its peers waiting in it.  bench.py and the eval driver call it at start-up; without it the group is still created lazily."""
+    return _host_group(group)
+
+
 def all_gather_rows(row, device, group=None):
     """row: sequence of floats -> float64 array [world, len(row)] (one tiny all_gather, on the host: _host_group; a sub-group of an
     RCCL job gathers on the device)."""
@@ -186,6 +204,12 @@ class SharedMeshStore:
                     os.posix_fallocate(fd, 0, size)   # reserves the pages: ENOSPC here instead of SIGBUS in copy_
             except BaseException:
                 os.close(fd)
+                try:            # (no half-grown block left behind: the next reconstruction starts from nothing)
+                    os.unlink(path)
+                except OSError:
+                    pass
+                cls._owned.discard(path)
+                cls._maps.pop(path, None)
                 raise
         else:
             fd = os.open(path, os.O_RDWR | os.O_NOFOLLOW)
@@ -320,8 +344,10 @@ def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transfor
     net.im_feat_list_hr = [_as_nchw_view(hr)]
     net.im_SR = net.feature_hr = None
     net.feature_lr = _as_nchw_view(feature_lr)
-    net._last_images = None          # (nothing here can be re-encoded by reencode_wide: the features are not super_res()'s)
+    net._last_images = None          # (reencode_wide re-runs super_res on one device: not how these features came about)
     net._sr_out = net._lr_from = net._hr_from = None
+    # what reconstruction_sharded's retry after an f16 overflow re-runs on every rank, under native.wide_operands()
+    net._sharded_encode = (images, calib_tensor, resolution, b_min, b_max, transform, group, net.im_feat_list_lr[-1].data_ptr())
     return True
 
 
@@ -355,8 +381,14 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
             fl, fh = net.features()
             bad = not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all()))
             flags = all_gather_rows([1.0 if bad else 0.0], fl.buf.device, group)   # (the encoder is deterministic; agree anyway)
-            if flags.any() and not net.reencode_wide():
-                raise
+            if flags.any():
+                # features of the sharded encoder are re-made by the sharded encoder (every rank is here: the flag is agreed);
+                # those of the replicated one by reencode_wide
+                se = getattr(net, "_sharded_encode", None)
+                if se is not None and net.im_feat_list_lr and net.im_feat_list_lr[-1].data_ptr() == se[7]:
+                    encode_sharded(net, *se[:7])
+                elif not net.reencode_wide():
+                    raise
             return reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max, transform, dst, want_normals, timing,
                                                group, wide=True, copy_out=copy_out)
 
@@ -408,6 +440,21 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
                 e.recv(v[nloc], rank + 1)
         return e.start()
 
+    # the column-kernel choice probes the grid's MIDDLE plane: the rank whose slab holds it decides for everybody (with a sharded
+    # encoder - encode_sharded - the other ranks do not have that plane's feature_hr columns).  A one-element row exchange of its own,
+    # in FRONT of the guarded block: every rank enters it whatever happens later, and what is raised behind it travels with the
+    # 13-element status row of the counts exchange
+    owner = next(r for r in range(world) if slab_range(R, r, world)[0] <= R // 2 < slab_range(R, r, world)[1])
+    k, kern_err = 0.0, None
+    if rank == owner:
+        try:
+            k = float(native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws))
+        except Exception as e:   # noqa: BLE001 - the others are waiting in the gather below: tell them
+            k, kern_err = -1.0, e
+    k = all_gather_rows([k], dev, group)[owner, 0]
+    if k < 0:
+        raise kern_err or RuntimeError("the column-kernel probe failed on rank %d" % owner)
+    kern = int(k)
     try:
         # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
         import os
@@ -419,19 +466,6 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
         sched = mesh_util.sweep_schedule(nloc, max(1, 16384 // R), max(1, int(env) // R) if env else None)
         sweep = torch.cuda.current_stream(dev)
         done = []
-        # the column-kernel choice probes the grid's MIDDLE plane: the rank whose slab holds it decides for everybody (with a sharded
-        # encoder - encode_sharded - the other ranks do not have that plane's feature_hr columns)
-        owner = next(r for r in range(world) if slab_range(R, r, world)[0] <= R // 2 < slab_range(R, r, world)[1])
-        k, kern_err = 0.0, None
-        if rank == owner:
-            try:
-                k = float(native.grid_kernel_for(R, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws))
-            except Exception as e:   # noqa: BLE001 - the others are waiting in the gather below: tell them
-                k, kern_err = -1.0, e
-        k = all_gather_rows([k], dev, group)[owner, 0]
-        if k < 0:
-            raise kern_err or RuntimeError("the column-kernel probe failed on rank %d" % owner)
-        kern = int(k)
         for a, b in sched:
             try:
                 native.query_grid(i0 + a, i0 + b, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, vols[0][a:b], vols[1][a:b],
@@ -539,7 +573,7 @@ def _deliver_shared(res, allc, voff, owner_pid, owner_token, dev, dst, group, co
             ok, why = False, e
     if not _agree(ok, dev, group):        # the blocks exist (and are reserved) before anybody maps them
         if why is not None:
-            warnings.warn("slab meshes: shared-memory delivery unavailable (%s); sending point to point" % (why,), stacklevel=3)
+            _warn_safely("slab meshes: shared-memory delivery unavailable (%s); sending point to point" % (why,))
         return False
     out = []
     try:
@@ -551,7 +585,7 @@ def _deliver_shared(res, allc, voff, owner_pid, owner_token, dev, dst, group, co
         ok, why = False, e
     if not _agree(ok, dev, group):
         if why is not None:
-            warnings.warn("slab meshes: rank %d cannot map dst's shared block (%s); sending point to point" % (rank, why), stacklevel=3)
+            _warn_safely("slab meshes: rank %d cannot map dst's shared block (%s); sending point to point" % (rank, why))
         return False
     try:
         for f, (nv, nf, vb, fb) in enumerate(stores):
@@ -567,8 +601,7 @@ def _deliver_shared(res, allc, voff, owner_pid, owner_token, dev, dst, group, co
         ok, why = False, e
     if not _agree(ok, dev, group):        # every part has landed
         if why is not None:
-            warnings.warn("slab meshes: copy into the shared block failed on rank %d (%s); sending point to point" % (rank, why),
-                          stacklevel=3)
+            _warn_safely("slab meshes: copy into the shared block failed on rank %d (%s); sending point to point" % (rank, why))
         return False
     if rank != dst:
         return None

@@ -212,14 +212,24 @@ class SuRSNet:
         which is PIFu's `transforms[:, :2, :2]`; the eval path never passes transforms.)"""
         # (the reference's sweep loop passes the same device tensors 2 684 times per 512^3 grid: a device-to-host copy - a host
         #  synchronisation - per call is what the loop then spends its time in; cached on the tensors' identity and version)
-        key = (calibs.data_ptr(), calibs._version, tuple(calibs.shape), None if transforms is None else (transforms.data_ptr(), transforms._version),
-               self.projection_mode)
+        # Limits of that key: a write through `.data` or through a numpy alias of a CPU tensor does not bump the version - callers that
+        # edit calibrations that way pass a new tensor or call invalidate_calib_cache(); inference-mode tensors have no version counter
+        # (reading it raises): they are converted on every call.
+        try:
+            key = (calibs.data_ptr(), calibs._version, tuple(calibs.shape),
+                   None if transforms is None else (transforms.data_ptr(), transforms._version), self.projection_mode)
+        except RuntimeError:
+            return self._calib_rows_uncached(calibs, transforms)
         hit = getattr(self, "_calib_cache", None)
         if hit is not None and hit[0] == key and hit[1] is calibs and hit[2] is transforms:
             return hit[3]
         rows = self._calib_rows_uncached(calibs, transforms)
         self._calib_cache = (key, calibs, transforms, rows)
         return rows
+
+    def invalidate_calib_cache(self):
+        """Forget the cached host copy of the last calibration (see _calib_rows: needed only after an edit that no version counter sees)."""
+        self._calib_cache = None
 
     def _calib_rows_uncached(self, calibs, transforms):
         cal = calibs.detach().to("cpu", torch.float64).numpy()[:, :3, :].copy()
@@ -259,7 +269,11 @@ class SuRSNet:
                     pl = p_lr[b].to(dev, torch.float32).reshape(-1).contiguous()
                     run = lambda: (native.query_points_hr(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(),
                                                           self._workspace(), pl), pl)
-                outs.append(self._finite_or_wide(run, b))
+                # --precision bf16 | fp16: the points go through the one-product f16 layer kernels (the reference's MLP in half
+                # precision); non-finite results are repeated fp32-grade on three bf16 parts like every other overflow
+                with native.reduced_point_operands(self.precision in ("bf16", "fp16")):
+                    first = run()
+                outs.append(self._finite_or_wide(run, b, first=first))
             phr = torch.stack([o[0] for o in outs]).view(B, 1, -1)
             plr = torch.stack([o[1] for o in outs]).view(B, 1, -1)
             return phr, plr
@@ -284,12 +298,12 @@ class SuRSNet:
         phr, plr = self._finite_or_wide(run)
         return phr.view(V, 1, -1), plr.view(V, 1, -1)
 
-    def _finite_or_wide(self, run, b=0):
+    def _finite_or_wide(self, run, b=0, first=None):
         """run() -> (pred_hr, pred_lr).  The fp32 point kernels carry their operands as two f16 parts (|x| < 65504); the reference
         is plain fp32.  Non-finite predictions (the callers copy them to the host next, so the check costs no extra
         synchronisation) are computed again on three bf16 parts - fp32's exponent range -, after re-running the encoder the same
         way if its features are what overflowed."""
-        phr, plr = run()
+        phr, plr = run() if first is None else first
         if bool(torch.isfinite(phr).all() & torch.isfinite(plr).all()):   # (one host synchronisation, not two)
             return phr, plr
         import warnings

@@ -104,6 +104,22 @@ def wide_operands_active():
     return getattr(_wide, "on", False)
 
 
+@contextlib.contextmanager
+def reduced_point_operands(on=True):
+    """Inside, surs_query_points / surs_query_points_hr of this thread run ONE f16 product per MAC (one f16 part per operand: 11
+    significant bits, a third of the matrix work of the fp32-grade point path): the arbitrary-point evaluator of `--precision bf16 |
+    fp16` (SuRSNet.query_mr / query_sr).  No effect inside wide_operands() (the retry after an overflow is fp32-grade) or with
+    on=False."""
+    if not on or wide_operands_active():
+        yield
+        return
+    check(lib().surs_set_operand_split_local(1))
+    try:
+        yield
+    finally:
+        check(lib().surs_set_operand_split_local(3 if wide_operands_active() else 0))
+
+
 class ConvWeights:
     """Packed conv weights ([tap][cin_pad][cout_pad]) + bias on the device."""
 
@@ -233,6 +249,7 @@ def scale_shift_act(x, scale, shift, relu, out=None):
     out = out or Img(x.h, x.w, x.c, device=x.buf.device)
     check(lib().surs_scale_shift_act(x.ptr(), x.h * x.w, x.c, x.ld, _ptr(scale), _ptr(shift), int(relu), out.ptr(), out.ld,
                                      _stream()))
+    out.stats = None   # (whatever GroupNorm statistics travelled with `out` described other values)
     return out
 
 
@@ -270,6 +287,7 @@ def bicubic_up2(x, align_corners, addend=None, out=None, want_stats=False):
 def pixel_shuffle2(x, slope, out=None):
     out = out or Img(2 * x.h, 2 * x.w, x.c // 4, device=x.buf.device)
     check(lib().surs_pixel_shuffle2(x.ptr(), x.h, x.w, x.c, x.ld, slope, out.ptr(), out.ld, _stream()))
+    out.stats = None
     return out
 
 

@@ -52,6 +52,22 @@ def test_query_50k_full_size_features_vs_reference(setup_full, golden_dir):
     assert ((phr == 0) == (g["pred_hr"] == 0)).all()
 
 
+def test_query_50k_full_size_features_one_product_path(setup_full, golden_dir):
+    """The one-product point path (surs_set_operand_split_local(1): one f16 part per operand) on BASELINE configs[1]'s points over
+    full-size feature maps, against the reference's outputs (tests/golden/query_h512.npz) at the fp16 bound of the column kernels
+    (4e-3 on the occupancies); the fp32-grade test above is untouched by it."""
+    from surs_amd import native, weights
+    g = np.load(os.path.join(golden_dir, "query_h512.npz"))
+    with native.reduced_point_operands():
+        phr, plr, lhr, llr = _q(setup_full, weights.synthetic_points(50000, seed=2), common.CALIB)
+    eh, el = np.abs(phr - g["pred_hr"]).max(), np.abs(plr - g["pred_lr"]).max()
+    print("one-product point path, full-size features: max |d occupancy| hr %.3e lr %.3e; max |d logit| hr %.3e" % (eh, el, np.abs(lhr - g["logit_hr"]).max()))
+    assert 1e-6 < eh < 4e-3 and el < 4e-3
+    assert ((phr == 0) == (g["pred_hr"] == 0)).all()
+    phr2, plr2, _, _ = _q(setup_full, weights.synthetic_points(50000, seed=2), common.CALIB)     # (outside: fp32-grade again)
+    assert np.abs(phr2 - g["pred_hr"]).max() < 1e-4 and np.abs(plr2 - g["pred_lr"]).max() < 1e-4
+
+
 def test_query_general_calib_ragged_and_edges(setup, golden_dir):
     from surs_amd import weights
     g = np.load(os.path.join(golden_dir, "query.npz"))
@@ -371,8 +387,9 @@ def test_sweep_edge_geometries_vs_point_path(setup, dtype, tol):
 
 
 def test_dense_kernels_chosen_where_most_channels_are_listed(setup):
-    """native.grid_kernel_for (what reconstruction / reconstruction_streamed / reconstruction_sharded ask before a sweep): the
-    library default (layer 1 restated along the column) for the ordinary field; for a field in which about half of the layer-0
+    """native.grid_kernel_for (what reconstruction / reconstruction_streamed / reconstruction_sharded ask before a sweep): a
+    restated kernel for the ordinary field (fp32: the library default; bf16: the streamed kernel 12 up to LISTED_STREAM_THRESHOLD
+    listed channels per tile, the eight-wave kernel 10 above); for a field in which about half of the layer-0
     channels change branch inside a z tile (the depth weights of layer 0 scaled by 60) the dense fp32-grade kernel (5), while the
     eight-wave bf16 kernel is still the faster one there (profiles/r03_listed_sensitivity.json).  The probe looks at the middle plane of the whole grid, so a slab gets the same
     answer; the chosen kernel's result equals the explicitly selected kernel's bit for bit."""
@@ -388,10 +405,12 @@ def test_dense_kernels_chosen_where_most_channels_are_listed(setup):
     mat2 = oracle.coords_matrix(R2, [-0.5] * 3, [0.5] * 3)[:3].reshape(-1)
     for prec in ("bf16", "fp32"):
         blob = g.blob("bf16")
-        assert nat.grid_kernel_for(R2, R2, R2, mat2, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws) == 0
+        pick = nat.grid_kernel_for(R2, R2, R2, mat2, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws)
         lr, hr = nat.probe_listed(R2 // 2, R2, R2, 64 if prec == "fp32" else 128, mat2, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, ws)
-        print(prec, "listed per tile at R=256: lr %.1f, hr bound %.1f" % (lr, hr))
+        print(prec, "listed per tile at R=256: lr %.1f, hr bound %.1f -> kernel %d" % (lr, hr, pick))
         assert 0 < lr < 300 and hr >= lr * 0.5, (lr, hr)
+        # fp32: the library's default (11).  bf16: the streamed kernel (12) while few channels are listed, the eight-wave one (10) above
+        assert pick == (0 if prec == "fp32" else (12 if lr <= nat.LISTED_STREAM_THRESHOLD else 10)), (prec, pick, lr)
     sd = {k: np.array(v, copy=True) for k, v in common.state_dict().items() if k.startswith("mlp_")}
     for m in ("mlp_lr.", "mlp_hr."):
         sd[m + "conv0.weight"][:, 320] *= 60.0
@@ -400,7 +419,7 @@ def test_dense_kernels_chosen_where_most_channels_are_listed(setup):
         kern = nat.grid_kernel_for(R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws)
         listed = ws.kernel_choice[1]
         # (the eight-wave bf16 kernel stays ahead of the dense one up to ~600 listed channels, the fp32-grade pair crosses at 400)
-        assert kern == (dense if listed > nat.LISTED_DENSE_THRESHOLDS[prec] else 0) and listed > 300, (prec, kern, ws.kernel_choice)
+        assert kern == (dense if listed > nat.LISTED_DENSE_THRESHOLDS[prec] else (0 if prec == "fp32" else 10)) and listed > 300, (prec, kern, ws.kernel_choice)
         if prec == "fp32":
             assert kern == dense, ws.kernel_choice
         a = [v.clone() for v in nat.query_grid(8, 40, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], blob, prec, ws, kernel=dense)]
