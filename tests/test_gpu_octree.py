@@ -127,10 +127,21 @@ def test_octree_walk_equals_oracle_walk_bit_for_bit(field, R, columns):
     del vh, vl
     levels = []
 
+    indep = []
+
     def index_func(reso, ii, jj, kk):
         idx = torch.from_numpy((ii.astype(np.int64) * R + jj) * R + kk).to(dev)
         a, b = native.octree_level_values(R, reso, idx, mat, cal, 512, 200.0, Fl, Fh, blob, ws, columns=columns)
         levels.append((reso, len(ii)))
+        if columns:
+            # the INDEPENDENT check of the column kernel's strided / item-list form: the same lattice points on
+            # the per-point layer kernels (held to the reference's goldens at 1e-4), in logit space, every level, at this size
+            pa, pb = native.octree_level_values(R, reso, idx, mat, cal, 512, 200.0, Fl, Fh, blob, ws, columns=False)
+            for x, y in ((a, pa), (b, pb)):
+                x64, y64 = x.double(), y.double()
+                ok = (x64 > 0.0067) & (x64 < 0.9933) & (y64 > 0.0067) & (y64 < 0.9933)      # (|logit| < 5: see precision_report.field_stats)
+                dl = (torch.log(x64 / (1 - x64)) - torch.log(y64 / (1 - y64))).abs()[ok]
+                indep.append((reso, float(dl.max()) if dl.numel() else 0.0, float((x64 - y64).abs().max())))
         return a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
 
     o_hr, o_lr = oracle.eval_grid_octree(R, [-0.5] * 3, [0.5] * 3, None, thr, init, index_func=index_func)
@@ -141,3 +152,6 @@ def test_octree_walk_equals_oracle_walk_bit_for_bit(field, R, columns):
     assert len(levels) >= 2 and sum(n for _, n in levels) < R ** 3
     assert np.array_equal(got_hr, o_hr)
     assert np.array_equal(got_lr, o_lr)
+    if columns:
+        print("   column kernel vs per-point kernels per level (reso, max |d logit|, max |d occupancy|):", indep)
+        assert indep and all(dl < 1e-4 and dp < 3e-5 for _, dl, dp in indep), indep
