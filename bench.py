@@ -260,7 +260,11 @@ def main():
         # what native.grid_kernel_for picks.
         try:
             lib.surs_set_grid_kernel(5 if args.precision == "fp32" else 3)
-            dfl, stf, lastf, (kf, pf, _) = run(opt, 2, 1)
+            os.environ["SURS_GRID_AUTO"] = "0"      # (the host's per-sweep choice - a per-call option - would override the process setting)
+            try:
+                dfl, stf, lastf, (kf, pf, _) = run(opt, 2, 1)
+            finally:
+                os.environ.pop("SURS_GRID_AUTO", None)
             lib.surs_set_grid_kernel(0)
             extras["dense_floor"] = {"kernel": "grid_mlp_kernel_v5" if args.precision == "fp32" else "grid_mlp_kernel_v3<%s>" % args.precision,
                                      "value": float(R) ** 3 * 2 / dfl, "unit": "queries/s", "ms_per_step": dfl / 2 * 1e3, "stage_ms": stf,

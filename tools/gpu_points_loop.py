@@ -1,0 +1,29 @@
+"""The reference's 50 000-point chunk loop (lib/sdf.py:32-45 around lib/mesh_util.py:20-28) on the facade, for profiling:
+    python tools/gpu_points_loop.py [precision] [chunks]          (rocprofv3 --kernel-trace --stats -- python3 tools/gpu_points_loop.py bf16)"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common
+from surs_amd import model, options, weights, train_util
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+nch = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+dev = torch.device("cuda:0")
+net = model.SuRSNet(options.BaseOptions().parse(common.FLAGS + ["--precision", prec])).to(device=dev)
+net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+net.eval()
+fl, fh = common.synth_features(hl=256, hh=1024)
+net.im_feat_list_lr = [torch.from_numpy(fl[None]).to(dev)]
+net.im_feat_list_hr = [torch.from_numpy(fh[None]).to(dev)]
+calib = train_util.gen_calib().to(dev)
+pts = weights.synthetic_points(50000 * nch, seed=2).astype(np.float64)
+def chunk(i):
+    p = np.repeat(np.expand_dims(pts[:, i * 50000:(i + 1) * 50000], 0), 1, axis=0)
+    s = torch.from_numpy(p).to(device=dev).float()
+    net.query_mr(s, calib); net.query_sr(s, calib)
+    return net.get_preds()[0][0].detach().cpu().numpy()
+for i in range(3): chunk(i)
+torch.cuda.synchronize(); t = time.perf_counter()
+for i in range(nch): chunk(i)
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+print("%s: %.3f ms per 50k chunk, %.3e queries/s" % (prec, dt / nch * 1e3, 50000 * nch / dt))
