@@ -279,7 +279,7 @@ def slab_feature_columns(i0, i1, mat, calib, width):
 
 def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transform=None, group=None):
     """The encoder for ONE subject on all ranks of a slab-mode reconstruction (call it instead of super_res -> filter_hr ->
-    filter_lr; every rank passes the same image).  What is sharded and what is not, and why:
+    filter_lr; every rank passes the same image).  What is sharded and what is not, and why (NOTES.md R4.0a item 1):
 
       super_res  (SuRSSR_v3.py:143-181, no normalisation, receptive field 119 columns of the 2W map): rank r runs it on the image
                  strip its share of the columns depends on (encoder.super_res_strip: share + a 128-column halo each side, recomputed,
