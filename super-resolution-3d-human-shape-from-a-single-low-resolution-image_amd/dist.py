@@ -458,12 +458,19 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     try:
         # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
         import os
-        # 16 384 columns per launch here (half of what one GPU sweeps per launch: a rank of eight holds 64 planes of a 512^3 grid, and
-        # with one launch its marching cubes would all follow the sweep instead of running under its second half), the last launch's
-        # planes as a taper (mesh_util.sweep_schedule): what follows the sweep on every rank - the extraction of the last launch's cell
-        # layers - is the serial tail of the strong-scaling step.  SURS_SLAB_COLUMNS: equal launches of that many columns (tests)
+        # Launches of one column batch (32 768 columns), the last batch's planes as a taper (mesh_util.sweep_schedule); a slab that
+        # is no more than one batch - a rank of eight at 512^3 - goes out as ONE launch: with the two-workgroup column kernel (512
+        # workgroups) the small launches of a taper cost more than the shorter extraction tail gives back (round 5, one rank of
+        # eight on a dedicated GPU: 16 384 + taper 15.9 ms of sweep + 0.76 of tail, one launch 15.0 + 0.85).  SURS_SLAB_COLUMNS:
+        # equal launches of that many columns (tests)
         env = os.environ.get("SURS_SLAB_COLUMNS")
-        sched = mesh_util.sweep_schedule(nloc, max(1, 16384 // R), max(1, int(env) // R) if env else None)
+        big = max(1, 32768 // R)
+        if env:
+            sched = mesh_util.sweep_schedule(nloc, big, max(1, int(env) // R))
+        elif nloc <= big:
+            sched = [(0, nloc)]
+        else:
+            sched = mesh_util.sweep_schedule(nloc, big)
         sweep = torch.cuda.current_stream(dev)
         done = []
         for a, b in sched:
