@@ -207,6 +207,23 @@ int surs_query_points_hr(const float *points, int n, const float *calib, float z
                          int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace,
                          size_t workspace_bytes, const float *p_lr, float *pred_hr, float *logit_hr, void *stream);
 
+/* surs_query_points for point arrays that come as RUNS of equal (x, y): what the reference's dense sweep loop hands
+ * query_mr / query_sr - 50 000 consecutive points of the flattened grid per call, z fastest (lib/sdf.py:32-45 batch_eval,
+ * lib/mesh_util.py:20-28 eval_func) - i.e. ~ 98 columns of up to 512 points with one image position each.  Such a run is a column of
+ * the sweep: the restated column kernels of surs_query_grid evaluate it (per-run constants from one gather + GEMM, layer 1 as the
+ * affine part + the residuals of the listed channels), every point with its own z read from `points`.  No grid is assumed: runs are
+ * found in the data (bit-equal x and y, z monotonic inside a run, cut at 4096 points).
+ *   points [3][n] with row pitch ld >= n (a piece of a longer array), n <= 262 144; dtype = the blob's use: SURS_F32 (kernel v11,
+ *   fp32-grade: logits within 1e-4 of surs_query_points'), SURS_BF16 / SURS_F16 (kernel v10: surs_query_grid's arithmetic);
+ *   *columns = the number of runs evaluated, or 0 - NOTHING WAS WRITTEN, call surs_query_points - when the array holds fewer than
+ *   2048 points or more than one run per 32 points, z is not monotonic inside the runs, or the calibration lets the image position
+ *   depend on z (calib[2], calib[6]) or the depth on x, y (calib[8], calib[9]).  Synchronises the stream once (the run count). */
+size_t surs_query_points_columns_workspace_bytes(void);
+int surs_query_points_columns(const float *points, long long ld, int n, const float *calib, float zmul, float zdiv,
+                              const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,
+                              int dtype, void *workspace, size_t workspace_bytes, float *pred_hr, float *pred_lr, int *columns,
+                              void *stream);
+
 /* The same for num_views > 1 and / or the perspective projection (SurfaceClassifier.forward's view mean after layer 2,
  * lib/model/SurfaceClassifier.py:70-76; reshape_sample_tensor, lib/train_util.py:40-51; perspective,
  * lib/geometry.py:34-48).  One subject (batch 1), V views:

@@ -76,6 +76,9 @@ _SIGS = {
     "surs_set_grid_kernel": (C.c_int, [_i]),
     "surs_query_workspace_bytes": (_sz, [_i]),
     "surs_query_points": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "surs_query_points_columns": (C.c_int, [_vp, C.c_longlong, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp,
+                                            C.POINTER(C.c_int), _vp]),
+    "surs_query_points_columns_workspace_bytes": (_sz, []),
     "surs_query_points_hr": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "surs_query_points_views": (C.c_int, [_vp, _i, _i, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp,
                                           _vp, _vp]),

@@ -44,6 +44,7 @@ struct PointSource {
     // mode 0: explicit points [3][n] (ld = n_total);  mode 1: grid voxels, flat index base+t, z fastest;
     // mode 2: grid columns, flat column index base+t = i*ry + j (k = 0);  mode 3: grid voxels listed in idx[t];
     // mode 4: grid columns listed in cols[t] (column index i*ry + j, k = 0): the octree levels' lattice columns
+    // mode 5: the explicit points listed in cols[t] (indices into pts): the first point of every run of surs_query_points_columns
     int mode;
     const float *pts;
     const long long *idx;
@@ -58,7 +59,8 @@ struct PointSource {
 };
 
 __device__ __forceinline__ void make_point(const PointSource &s, long long t, float &px, float &py, float &pz) {
-    if (s.mode == 0) {
+    if (s.mode == 0 || s.mode == 5) {
+        if (s.mode == 5) t = (long long)s.cols[t];
         px = s.pts[t];
         py = s.pts[s.ld + t];
         pz = s.pts[2 * s.ld + t];
@@ -649,6 +651,11 @@ struct GridArgs {
     int zstride;
     const int *kcount;
     const unsigned short *klist;
+    // point runs (surs_query_points_columns; kernels v10 / v11): column c's items are the POINTS colstart[c] + e, e < kcount[c], of a
+    // caller's point array - world z from zpts[colstart[c] + e] instead of the grid's (z0, dz), outputs at vol[colstart[c] + e]
+    // (the callers' prediction arrays); klist null.  Dense and lattice sweeps: both null.
+    const int *colstart;
+    const float *zpts;
     // kernel v12 -> kernel v10: the (column, z tile) pairs v12 did not evaluate (ovf_list[2 t], [2 t + 1], t < *ovf_count); kernel v10
     // with tile_list set walks those instead of whole columns
     unsigned *ovf_count;
@@ -1210,6 +1217,12 @@ struct ColumnSweep {
     void *workspace;
     int cus;
     int kmid;             // axis-2 voxel index at which the restated kernels take the per-column LeakyReLU branches g_c
+    // point runs (surs_query_points_columns): the columns are runs of a caller's point array, the work items (column, z tile) pairs
+    const int *run_colstart = nullptr;
+    const float *run_z = nullptr;
+    const int *run_tiles = nullptr;
+    const unsigned *run_ntiles = nullptr;
+    long long run_ntiles_host = 0;
 };
 }  // namespace
 
@@ -1287,8 +1300,10 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     a.klist = klist;
     a.ovf_count = nullptr;
     a.ovf_list = nullptr;
-    a.tile_list = nullptr;
-    a.tile_count = nullptr;
+    a.tile_list = cs.run_tiles;
+    a.tile_count = cs.run_ntiles;
+    a.colstart = cs.run_colstart;
+    a.zpts = cs.run_z;
     if (restated) {
         // the affine part of layer 1: R = W1 (g . [a0 | w0z | w0p]) for the batch's columns, on the layer GEMM kernel
         if ((rc = g3_set_attributes())) return rc;
@@ -1299,7 +1314,8 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
         SURS_HIP_CHECK(hipMemsetAsync(zero_bias, 0, D2 * 4 + 256, st));   // + the column counter behind it
         a.colctr = (unsigned *)(zero_bias + D2);
         {
-            const float zw = (float)(mat[10] * (double)cs.kmid + mat[11]);
+            // (any depth serves - the restated layer 1 is an identity for every choice -; point runs have no grid: world z = 0)
+            const float zw = cs.run_z ? 0.0f : (float)(mat[10] * (double)cs.kmid + mat[11]);
             a.zmid = (calib[11] + calib[10] * zw) * cs.zmul / cs.zdiv;
         }
         const long long part_lr = 2LL * ncp * D1, part_hr = 3LL * ncp * D1;
@@ -1348,13 +1364,14 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     a.vol_lr = vol_lr;
     a.ncols = (int)nc;
     a.rz = items;
-    a.z0 = mat[11];
-    a.dz = mat[10];
+    a.z0 = mat ? mat[11] : 0.0;
+    a.dz = mat ? mat[10] : 0.0;
     a.c22 = calib[10];
     a.c23 = calib[11];
     a.zmul = cs.zmul;
     a.zdiv = cs.zdiv;
-    const unsigned grid = (unsigned)((nc < cs.cus) ? nc : cs.cus);
+    const long long nwork = cs.run_tiles ? cs.run_ntiles_host : nc;   // work items the column counter hands out
+    const unsigned grid = (unsigned)((nwork < cs.cus) ? nwork : cs.cus);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool prof;
     a.kstat = nullptr;
@@ -1385,7 +1402,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             // HBM.  Only with whole 64-voxel tiles (the hr pass reads its tile's lr occupancies back from vol_lr, which has no
             // room for the voxels beyond the column's end that the one-pass form computes and classifies on); same bits.
             static const int passes_env = getenv("SURS_GRID_F32_PASSES") ? atoi(getenv("SURS_GRID_F32_PASSES")) : 2;
-            const bool two = passes_env == 2 && items % 64 == 0;
+            const bool two = passes_env == 2 && items % 64 == 0 && !cs.run_tiles;
             for (int ph = two ? 1 : 0; ph <= (two ? 2 : 0); ++ph) {
                 a.phase = ph;
                 hipLaunchKernelGGL(grid_mlp_kernel_v11, dim3(grid), dim3(V11_THREADS), GRID11_LDS_BYTES, st, a);
@@ -1835,5 +1852,213 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
                            sdf_lr, dirty);
         SURS_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Point runs: the column kernels behind surs_query_points' signature.
+//
+// The reference's dense sweep (lib/sdf.py:32-45 batch_eval -> eval_func -> query_mr / query_sr, lib/mesh_util.py:20-28) hands the
+// facade consecutive pieces of the flattened grid: 50 000 points per call, z fastest, i.e. ~ 98 runs of up to 512 points that share
+// their (x, y).  A run is a column of the sweep - same projected image position, same 320 gathered features - so the restated
+// column kernels (v10 / v11) serve it: per-column constants from ONE gather + GEMM per run instead of per point, layer 1 as the
+// affine part + the listed channels' residuals.  Nothing about a grid is assumed: the runs are found in the data (maximal sequences
+// of points with bit-equal x and y, cut at PR_CAP points, z monotonic inside every run - the kernels take a tile's z range from its
+// ends), every point's own z is read from the caller's array, results go straight to the caller's prediction arrays.  Arrays
+// without such runs (random samples: fewer than 32 points per run on average) are refused (*columns = 0, nothing written) and
+// the caller takes surs_query_points.
+// ------------------------------------------------------------------------------------------------
+static const int PR_CHUNK = 262144;   // points per call
+static const int PR_CAP = 4096;       // points per column: a longer run is cut into several (one more gather row each)
+static const int PR_THREADS = 1024;
+
+__device__ __forceinline__ int pr_wave_scan_sum(int v, int lane) {   // inclusive, 64 lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ int pr_wave_scan_max(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d);
+        if (lane >= d) v = max(v, o);
+    }
+    return v;
+}
+// inclusive scans over the PR_THREADS threads of the workgroup (tmp: 16 ints of LDS); total = the last thread's value
+__device__ __forceinline__ int pr_block_scan_sum(int v, int *tmp, int &total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v = pr_wave_scan_sum(v, lane);
+    __syncthreads();
+    if (lane == 63) tmp[wave] = v;
+    __syncthreads();
+    int add = 0, tot = 0;
+    for (int w = 0; w < PR_THREADS / 64; ++w) {
+        const int x = tmp[w];
+        if (w < wave) add += x;
+        tot += x;
+    }
+    total = tot;
+    return v + add;
+}
+__device__ __forceinline__ int pr_block_scan_max(int v, int *tmp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    v = pr_wave_scan_max(v, lane);
+    __syncthreads();
+    if (lane == 63) tmp[wave] = v;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) v = max(v, tmp[w]);
+    return v;
+}
+
+// ONE workgroup.  Thread t owns the points [t m, (t + 1) m).  colstart[c] / kcount[c]: first point and length of column c;
+// tiles[2 j], tiles[2 j + 1]: column and z tile (of `tile` points) of work item j; meta = {columns, tiles, ascending violated,
+// descending violated}.
+__global__ __launch_bounds__(PR_THREADS) void point_runs_kernel(const float *__restrict__ px, const float *__restrict__ py,
+                                                                const float *__restrict__ pz, int n, int cap, int tile,
+                                                                int *__restrict__ colstart, int *__restrict__ kcount,
+                                                                int *__restrict__ tiles, int *__restrict__ meta) {
+    __shared__ int tmp[PR_THREADS / 64];
+    __shared__ int viol[2];
+    const int tid = threadIdx.x;
+    const int m = (n + PR_THREADS - 1) / PR_THREADS;
+    const int lo = min(n, tid * m), hi = min(n, lo + m);
+    if (tid < 2) viol[tid] = 0;
+    auto natural_head = [&](int i) { return i == 0 || px[i] != px[i - 1] || py[i] != py[i - 1]; };
+    // 1. where the run that holds a point starts: the last natural head at or before it
+    int last = -1;
+    for (int i = lo; i < hi; ++i)
+        if (natural_head(i)) last = i;
+    const int incl = pr_block_scan_max(last, tmp);
+    int rs = __shfl_up(incl, 1);                      // exclusive: what the threads before this one saw
+    if ((tid & 63) == 0) rs = -1;
+    __syncthreads();
+    if ((tid & 63) == 63) tmp[tid >> 6] = incl;
+    __syncthreads();
+    if ((tid & 63) == 0 && tid > 0) rs = tmp[(tid >> 6) - 1];
+    // 2. heads (natural, or PR_CAP points into a run), monotonicity of z inside the columns
+    int heads = 0, va = 0, vd = 0;
+    {
+        int r = rs;
+        for (int i = lo; i < hi; ++i) {
+            const bool nh = natural_head(i);
+            if (nh) r = i;
+            const bool head = nh || ((i - r) % cap == 0);
+            heads += head ? 1 : 0;
+            if (!head) {
+                const float z0 = pz[i - 1], z1 = pz[i];
+                va |= (z1 < z0) ? 1 : 0;
+                vd |= (z1 > z0) ? 1 : 0;
+                va |= (z1 != z1) ? 1 : 0;   // (NaN: neither order holds)
+                vd |= (z1 != z1) ? 1 : 0;
+            }
+        }
+    }
+    if (va) atomicOr(&viol[0], 1);
+    if (vd) atomicOr(&viol[1], 1);
+    int ncols = 0;
+    const int hincl = pr_block_scan_sum(heads, tmp, ncols);
+    {
+        int c = hincl - heads, r = rs;
+        for (int i = lo; i < hi; ++i) {
+            const bool nh = natural_head(i);
+            if (nh) r = i;
+            if (nh || ((i - r) % cap == 0)) colstart[c++] = i;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // 3. lengths and the work items
+    const int mc = (ncols + PR_THREADS - 1) / PR_THREADS;
+    const int clo = min(ncols, tid * mc), chi = min(ncols, clo + mc);
+    int nt = 0;
+    for (int c = clo; c < chi; ++c) {
+        const int k = (c + 1 < ncols ? colstart[c + 1] : n) - colstart[c];
+        kcount[c] = k;
+        nt += (k + tile - 1) / tile;
+    }
+    int ntiles = 0;
+    const int tincl = pr_block_scan_sum(nt, tmp, ntiles);
+    int j = tincl - nt;
+    for (int c = clo; c < chi; ++c) {
+        const int k = (c + 1 < ncols ? colstart[c + 1] : n) - colstart[c];
+        for (int zc = 0; zc * tile < k; ++zc) {
+            tiles[2 * j] = c;
+            tiles[2 * j + 1] = zc;
+            ++j;
+        }
+    }
+    if (tid == 0) {
+        meta[0] = ncols;
+        meta[1] = ntiles;
+        meta[2] = viol[0];
+        meta[3] = viol[1];
+    }
+}
+
+static size_t point_runs_list_bytes() { return align_up((size_t)PR_CHUNK * 4 * sizeof(int) + 256, 256); }
+
+extern "C" size_t surs_query_points_columns_workspace_bytes(void) { return col_ws_bytes(COL_BATCH) + point_runs_list_bytes(); }
+
+extern "C" int surs_query_points_columns(const float *points, long long ld, int n, const float *calib, float zmul, float zdiv,
+                                         const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                                         const void *mlp_blob, int dtype, void *workspace, size_t workspace_bytes, float *pred_hr,
+                                         float *pred_lr, int *columns, void *stream) {
+    SURS_REQUIRE(columns, "null argument");
+    *columns = 0;
+    SURS_REQUIRE(n >= 0 && n <= PR_CHUNK && ld >= n, "at most %d points per call, [3][n] with row pitch ld >= n", PR_CHUNK);
+    if (n == 0) return 0;
+    SURS_REQUIRE(points && calib && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
+    SURS_REQUIRE(dtype == SURS_F32 || dtype == SURS_BF16 || dtype == SURS_F16, "unknown dtype %d", dtype);
+    SURS_REQUIRE(workspace_bytes >= surs_query_points_columns_workspace_bytes(), "workspace too small");
+    // a run is a column only if its image position does not depend on z and its depth only on z
+    if (calib[2] != 0.0f || calib[6] != 0.0f || calib[8] != 0.0f || calib[9] != 0.0f) return 0;
+    if (n < 2048) return 0;   // (the per-call preparation outweighs the point kernels' work below that)
+    hipStream_t st = as_stream(stream);
+    int rc = 0;
+    char *lists = (char *)workspace + col_ws_bytes(COL_BATCH);
+    int *colstart = (int *)lists, *kcount = colstart + PR_CHUNK, *tiles = kcount + PR_CHUNK;
+    int *meta = (int *)(lists + point_runs_list_bytes() - 256);
+    const int tile = dtype == SURS_F32 ? 64 : 128;
+    hipLaunchKernelGGL(point_runs_kernel, dim3(1), dim3(PR_THREADS), 0, st, points, points + ld, points + 2 * ld, n, PR_CAP, tile, colstart,
+                       kcount, tiles, meta);
+    SURS_LAUNCH_CHECK();
+    int host[4] = {0, 0, 0, 0};
+    SURS_HIP_CHECK(hipMemcpyAsync(host, meta, sizeof(host), hipMemcpyDeviceToHost, st));
+    SURS_HIP_CHECK(hipStreamSynchronize(st));
+    const long long ncols = host[0];
+    if (ncols <= 0 || ncols * 32 > n || ncols > COL_BATCH || (host[2] && host[3])) return 0;
+    ColumnSweep cs;
+    cs.st = st;
+    cs.blob = (const char *)mlp_blob;
+    cs.h = blob_layout((uint32_t)dtype);
+    cs.dtype = dtype;
+    cs.kver = 10;    // (tile mode: the work items are (column, z tile) pairs - a call holds ~ 100 columns, fewer than the chip has CUs)
+    cs.kver32 = 11;
+    cs.restated = true;
+    cs.feat_lr = feat_lr; cs.hl = hl; cs.wl = wl;
+    cs.feat_hr = feat_hr; cs.hh = hh; cs.wh = wh;
+    cs.mat = nullptr; cs.calib = calib; cs.zmul = zmul; cs.zdiv = zdiv;
+    cs.workspace = workspace;
+    cs.cus = device_cus();
+    cs.kmid = 0;
+    cs.run_colstart = colstart;
+    cs.run_z = points + 2 * ld;
+    cs.run_tiles = tiles;
+    cs.run_ntiles = (const unsigned *)(meta + 1);
+    cs.run_ntiles_host = host[1];
+    if ((rc = grid_set_attributes())) return rc;
+    PointSource src;
+    memset(&src, 0, sizeof(src));
+    src.mode = 5;
+    src.pts = points;
+    src.ld = ld;
+    src.cols = colstart;
+    fill_calib(src, calib, zmul, zdiv);
+    if ((rc = run_column_batch(cs, src, ncols, PR_CAP, 1, kcount, nullptr, pred_hr, pred_lr, false))) return rc;
+    *columns = (int)ncols;
     return 0;
 }

@@ -271,8 +271,13 @@ class SuRSNet:
                                                           self._workspace(), pl), pl)
                 # --precision bf16 | fp16: the points go through the one-product f16 layer kernels (the reference's MLP in half
                 # precision); non-finite results are repeated fp32-grade on three bf16 parts like every other overflow
-                with native.reduced_point_operands(self.precision in ("bf16", "fp16")):
-                    first = run()
+                # points that come as runs of equal (x, y) - the reference's sweep loop: consecutive grid points, z fastest - are
+                # columns: the restated column kernels take them (same arithmetic as reconstruction()'s sweep in this precision)
+                first = native.query_points_columns(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(), self.precision,
+                                                    self._workspace()) if p_lr is None else None
+                if first is None:
+                    with native.reduced_point_operands(self.precision in ("bf16", "fp16")):
+                        first = run()
                 outs.append(self._finite_or_wide(run, b, first=first))
             phr = torch.stack([o[0] for o in outs]).view(B, 1, -1)
             plr = torch.stack([o[1] for o in outs]).view(B, 1, -1)

@@ -442,6 +442,45 @@ def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_log
     return tuple(outs)
 
 
+POINT_RUNS_CHUNK = 262144   # points per surs_query_points_columns call
+
+
+def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws):
+    """surs_query_points_columns: both classifiers on points [3,N] THROUGH THE COLUMN KERNELS where the points come as runs that share
+    their (x, y) - what the reference's sweep loop (lib/sdf.py:32-45: 50 000 consecutive grid points per call, z fastest) hands the
+    facade.  dtype: the blob's ("fp32": kernel v11, fp32-grade; "bf16" / "fp16": kernel v10).  Returns (pred_hr, pred_lr), or None
+    when the array holds no such runs (random samples; a general calibration; fewer than 2048 points; inside wide_operands()) - the
+    caller then takes query_points.  One host synchronisation (the run count)."""
+    if wide_operands_active() or os.environ.get("SURS_POINT_RUNS", "1") == "0":
+        return None
+    points = _f32c(points)
+    n = points.shape[1]
+    if n < 2048:
+        return None
+    dev = points.device
+    phr = torch.empty(n, dtype=torch.float32, device=dev)
+    plr = torch.empty(n, dtype=torch.float32, device=dev)
+    cal = (C.c_float * 12)(*[float(v) for v in calib])
+    code = DTYPES[dtype] if isinstance(dtype, str) else dtype
+    w = ws.get(lib().surs_query_points_columns_workspace_bytes())
+    assert feat_lr.ld == feat_lr.c == 256 and feat_hr.ld == feat_hr.c == 64
+    ncols = C.c_int(0)
+    for p0 in range(0, n, POINT_RUNS_CHUNK):
+        nb = min(POINT_RUNS_CHUNK, n - p0)
+        check(lib().surs_query_points_columns(C.c_void_p(points.data_ptr() + 4 * p0), n, nb, cal, float(zmul), float(zdiv),
+                                              feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
+                                              code, _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * p0),
+                                              C.c_void_p(plr.data_ptr() + 4 * p0), C.byref(ncols), _stream()))
+        if ncols.value == 0:
+            if p0 == 0 and nb == n:
+                return None
+            # this piece holds no runs: the point kernels for it
+            a, b = query_points(points[:, p0:p0 + nb], calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
+            phr[p0:p0 + nb] = a
+            plr[p0:p0 + nb] = b
+    return phr, plr
+
+
 def query_points_hr(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, p_lr):
     """surs_query_points_hr: the hr classifier on points [3,N] with the lr occupancies p_lr [N] given (query_sr on points other than
     query_mr's).  Returns pred_hr [N]."""

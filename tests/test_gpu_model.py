@@ -125,6 +125,37 @@ def test_query_facade_vs_reference(net, golden_dir):
     assert np.array_equal(alone.cpu().numpy(), phr[0, 0].cpu().numpy())
 
 
+def test_query_facade_takes_grid_chunks_through_the_column_kernels(net, monkeypatch):
+    """The reference's sweep loop (lib/sdf.py:32-45, lib/mesh_util.py:20-28) hands query_mr / query_sr 50 000 consecutive points of
+    the flattened grid per call: runs of points with one image position.  The facade evaluates them on the column kernels
+    (surs_query_points_columns); with SURS_POINT_RUNS=0 on the point kernels: the two agree to 1e-4, random samples are not affected."""
+    import oracle
+    from surs_amd import native
+    fl, fh = common.synth_features()
+    net.im_feat_list_lr = [torch.from_numpy(fl[None]).to("cuda:0")]
+    net.im_feat_list_hr = [torch.from_numpy(fh[None]).to("cuda:0")]
+    calib = torch.from_numpy(common.CALIB[None]).to("cuda:0")
+    R = 128
+    a = 61 * R * R + 17 * R + 5
+    chunk = oracle.grid_points(R, [-0.5] * 3, [0.5] * 3, a, a + 50000)
+    pts = torch.from_numpy(chunk[None]).to("cuda:0")
+    calls = []
+    real = native.query_points_columns
+    monkeypatch.setattr(native, "query_points_columns", lambda *a_, **k_: calls.append(real(*a_, **k_)) or calls[-1])
+    net.query_mr(pts, calib)
+    net.query_sr(pts, calib)
+    phr, plr = [t.detach().cpu().numpy()[0, 0] for t in net.get_preds()]
+    assert len(calls) == 1 and calls[0] is not None
+    monkeypatch.setenv("SURS_POINT_RUNS", "0")
+    net.query_mr(pts.clone(), calib)
+    net.query_sr(pts.clone(), calib)
+    qhr, qlr = [t.detach().cpu().numpy()[0, 0] for t in net.get_preds()]
+    assert len(calls) == 2 and calls[1] is None
+    assert np.abs(phr - qhr).max() < 1e-4 and np.abs(plr - qlr).max() < 1e-4 and np.abs(phr - qhr).max() > 0
+    ohr, olr = oracle.query(common.state_dict(), chunk[:, ::17], common.CALIB, fl, fh, 1024, 200.0)
+    assert np.abs(phr[::17] - ohr).max() < 1e-4 and np.abs(plr[::17] - olr).max() < 1e-4
+
+
 @pytest.mark.parametrize("prec,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
 def test_query_facade_reduced_precision_point_path(golden_dir, prec, tol):
     """--precision bf16 | fp16: SuRSNet.query_mr / query_sr evaluate arbitrary points on ONE f16 product per MAC (the one-part layer

@@ -440,3 +440,99 @@ def test_dense_kernels_chosen_where_most_channels_are_listed(setup):
     nat.grid_kernel_for(R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], g.blob("bf16"), "bf16", ws)
     nat.grid_kernel_for(R, R, R, mat, cal, ZMUL, ZDIV, setup["Fl"], setup["Fh"], g.blob("bf16"), "bf16", ws)
     assert ws.probes == n0 + 2
+
+
+# ------------------------------------------------------------------ point runs: the column kernels behind the point signature
+
+def _run_points(seed=5, ncols=110, lo=180, hi=512, descending=False, outside=3):
+    """Points as the reference's sweep loop hands them over (lib/sdf.py:32-45): runs of points that share (x, y), z monotonic
+    inside a run - here with ragged run lengths, a first and a last run that are cut (a chunk starts and ends mid-column), a few
+    runs outside the image, and (x, y) that are NOT on a lattice."""
+    rng = np.random.RandomState(seed)
+    xs, ys, zs = [], [], []
+    for c in range(ncols):
+        k = int(rng.randint(lo, hi + 1))
+        x, y = rng.uniform(-0.45, 0.45, 2)
+        if c < outside:
+            x += 1.0   # projects outside [-1, 1]: masked runs
+        z = np.sort(rng.uniform(-0.5, 0.5, k))
+        if descending:
+            z = z[::-1]
+        xs.append(np.full(k, x)); ys.append(np.full(k, y)); zs.append(z)
+    return np.stack([np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)]).astype(np.float32)
+
+
+def _qc(s, pts, dtype, calib=None):
+    nat = s["native"]
+    p = torch.from_numpy(np.ascontiguousarray(pts)).to(s["g"].dev())
+    cal = np.asarray(common.CALIB if calib is None else calib, np.float32).reshape(-1)[:12]
+    return nat.query_points_columns(p, cal, ZMUL, ZDIV, s["Fl"], s["Fh"], s["g"].blob("f16" if dtype == "fp16" else "bf16"), dtype, s["ws"])
+
+
+@pytest.mark.parametrize("descending", [False, True])
+def test_point_runs_fp32_vs_point_path_and_oracle(setup, descending):
+    """surs_query_points_columns (kernel v11 on the runs of a point array) against surs_query_points on the same points - 1e-4 on
+    the occupancies, the zero set (the in-image mask) identical - and against the oracle itself on a sample."""
+    import oracle
+    pts = _run_points(descending=descending)
+    got = _qc(setup, pts, "fp32")
+    assert got is not None
+    phr, plr = [o.cpu().numpy() for o in got]
+    rhr, rlr, _, _ = _q(setup, pts, common.CALIB)
+    print("point runs fp32 (%d points): max |d occupancy| hr %.3e lr %.3e" % (pts.shape[1], np.abs(phr - rhr).max(), np.abs(plr - rlr).max()))
+    assert np.abs(phr - rhr).max() < 1e-4 and np.abs(plr - rlr).max() < 1e-4
+    assert ((phr == 0) == (rhr == 0)).all() and (phr == 0).sum() > 100
+    sel = np.random.RandomState(1).choice(pts.shape[1], 3000, replace=False)
+    ohr, olr = oracle.query(common.state_dict(), pts[:, sel], common.CALIB, setup["fl"], setup["fh"], 1024, 200.0)
+    assert np.abs(phr[sel] - ohr).max() < 1e-4 and np.abs(plr[sel] - olr).max() < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("fp16", 4e-3)])
+def test_point_runs_reduced_precision(setup, dtype, tol):
+    """The 16-bit column kernel (v10, tile mode) on point runs, at the bounds of the sweep's own test (test_grid_column_kernel_vs_fp32)."""
+    pts = _run_points(seed=6)
+    got = _qc(setup, pts, dtype)
+    assert got is not None
+    phr, plr = [o.cpu().numpy() for o in got]
+    rhr, rlr, _, _ = _q(setup, pts, common.CALIB)
+    eh, el = np.abs(phr - rhr).max(), np.abs(plr - rlr).max()
+    print("point runs %s: max |d occupancy| hr %.3e lr %.3e" % (dtype, eh, el))
+    assert 1e-7 < eh < tol and el < tol
+    assert ((phr == 0) == (rhr == 0)).all()
+
+
+def test_point_runs_grid_chunk_equals_the_sweep(setup):
+    """A 50 000-point piece of a flattened grid (what lib/sdf.py:32-45 passes per call), starting and ending mid-column: the runs
+    path returns the fp32 sweep's values (same kernel, same per-column constants, the points' z read from the array instead of
+    generated from (z0, dz): equal floats; the depth at which the per-column branches are taken differs, so the listed channels
+    and the last bits do) - and a run longer than 4096 points is cut, not refused."""
+    import oracle
+    R = 96
+    vh, vl = _grid(setup, R, "fp32")
+    pts = oracle.grid_points(R, [-0.5] * 3, [0.5] * 3).astype(np.float32)
+    a = 37 * R * R + 11 * R + 40
+    piece = np.ascontiguousarray(pts[:, a:a + 50000])
+    phr, plr = [o.cpu().numpy() for o in _qc(setup, piece, "fp32")]
+    assert np.abs(phr - vh.reshape(-1)[a:a + 50000]).max() < 2e-5 and np.abs(plr - vl.reshape(-1)[a:a + 50000]).max() < 2e-5
+    long_run = np.stack([np.full(10000, 0.123, np.float32), np.full(10000, -0.2, np.float32), np.linspace(-0.5, 0.5, 10000, dtype=np.float32)])
+    got = _qc(setup, long_run, "fp32")
+    assert got is not None
+    rhr, rlr, _, _ = _q(setup, long_run, common.CALIB)
+    assert np.abs(got[0].cpu().numpy() - rhr).max() < 1e-4 and np.abs(got[1].cpu().numpy() - rlr).max() < 1e-4
+
+
+def test_point_runs_refused_where_there_are_none(setup):
+    """Random samples, short arrays, z that goes both ways inside the runs, a calibration whose image position depends on z: the
+    entry point writes nothing and says so; the caller takes the point kernels."""
+    from surs_amd import weights
+    assert _qc(setup, weights.synthetic_points(50000, seed=2), "fp32") is None
+    assert _qc(setup, _run_points(ncols=4, lo=300, hi=400), "fp32") is None            # fewer than 2048 points
+    pts = _run_points(seed=8)
+    zig = pts.copy()
+    zig[2, 5000:5100] = zig[2, 5000:5100][::-1].copy()                                   # a stretch that descends among ascending runs
+    assert _qc(setup, zig, "fp32") is None
+    cal = np.array(common.CALIB, np.float32).copy()
+    cal[0, 2] = 0.05
+    assert _qc(setup, pts, "fp32", calib=cal) is None
+    short = _run_points(seed=9, ncols=3000, lo=8, hi=24)                                 # ~ 16 points per run
+    assert _qc(setup, short, "fp32") is None
