@@ -381,8 +381,9 @@ def main():
                 for i in range(pts_all.shape[1] // ns):
                     out_hr[i * ns:(i + 1) * ns], out_lr[i * ns:(i + 1) * ns] = eval_func(nn, pts_all[:, i * ns:(i + 1) * ns])
 
-            for key, nn, what in (("reference_loop", n32, "fp32 (the facade's default: fp32-grade layer kernels, three products per MAC)"),
-                                  ("reference_loop_reduced", net, "--precision %s (one f16 product per MAC in the point path)" % args.precision)):
+            for key, nn, what in (("reference_loop", n32, "fp32 (the facade's default; the chunks are runs of grid points with one image position each: "
+                                                           "surs_query_points_columns, the fp32-grade column kernel v11 in tile mode)"),
+                                  ("reference_loop_reduced", net, "--precision %s (the same runs on the 16-bit column kernel v10)" % args.precision)):
                 if key == "reference_loop_reduced" and args.precision == "fp32":
                     continue
                 loop(nn)

@@ -1888,108 +1888,142 @@ __device__ __forceinline__ int pr_wave_scan_max(int v, int lane) {
     }
     return v;
 }
-// inclusive scans over the PR_THREADS threads of the workgroup (tmp: 16 ints of LDS); total = the last thread's value
-__device__ __forceinline__ int pr_block_scan_sum(int v, int *tmp, int &total) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    v = pr_wave_scan_sum(v, lane);
-    __syncthreads();
-    if (lane == 63) tmp[wave] = v;
-    __syncthreads();
-    int add = 0, tot = 0;
-    for (int w = 0; w < PR_THREADS / 64; ++w) {
-        const int x = tmp[w];
-        if (w < wave) add += x;
-        tot += x;
-    }
-    total = tot;
-    return v + add;
-}
-__device__ __forceinline__ int pr_block_scan_max(int v, int *tmp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    v = pr_wave_scan_max(v, lane);
-    __syncthreads();
-    if (lane == 63) tmp[wave] = v;
-    __syncthreads();
-    for (int w = 0; w < wave; ++w) v = max(v, tmp[w]);
-    return v;
-}
 
-// ONE workgroup.  Thread t owns the points [t m, (t + 1) m).  colstart[c] / kcount[c]: first point and length of column c;
-// tiles[2 j], tiles[2 j + 1]: column and z tile (of `tile` points) of work item j; meta = {columns, tiles, ascending violated,
-// descending violated}.
+// ONE workgroup walks the array in blocks of 4096 points: wave w takes 256 consecutive points of a block as four steps of 64 (lane =
+// point: coalesced loads, and a wave's scans are ballots and bit counts - no cross-lane traffic); what crosses the waves goes
+// through 16 LDS words twice per block (the last natural head, then the number of heads), what crosses the blocks is carried in
+// registers.  colstart[c] / kcount[c]: first point and length of column c; tiles[2 j], tiles[2 j + 1]: column and z tile (of `tile`
+// points) of work item j; meta = {columns, tiles, ascending violated, descending violated}.  An array with more than one column
+// per 32 points is not worth the column kernels: lengths and work items are skipped.
 __global__ __launch_bounds__(PR_THREADS) void point_runs_kernel(const float *__restrict__ px, const float *__restrict__ py,
-                                                                const float *__restrict__ pz, int n, int cap, int tile,
+                                                                const float *__restrict__ pz, int n, int tile,
                                                                 int *__restrict__ colstart, int *__restrict__ kcount,
                                                                 int *__restrict__ tiles, int *__restrict__ meta) {
-    __shared__ int tmp[PR_THREADS / 64];
+    constexpr int V = 4, NW = PR_THREADS / 64, BS = PR_THREADS * V;
+    static_assert((PR_CAP & (PR_CAP - 1)) == 0, "the cut is a bit mask");
+    __shared__ int tmpm[NW], tmps[NW];
     __shared__ int viol[2];
-    const int tid = threadIdx.x;
-    const int m = (n + PR_THREADS - 1) / PR_THREADS;
-    const int lo = min(n, tid * m), hi = min(n, lo + m);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long lt = (1ull << lane) - 1ull, le = lt | (1ull << lane);
     if (tid < 2) viol[tid] = 0;
-    auto natural_head = [&](int i) { return i == 0 || px[i] != px[i - 1] || py[i] != py[i - 1]; };
-    // 1. where the run that holds a point starts: the last natural head at or before it
-    int last = -1;
-    for (int i = lo; i < hi; ++i)
-        if (natural_head(i)) last = i;
-    const int incl = pr_block_scan_max(last, tmp);
-    int rs = __shfl_up(incl, 1);                      // exclusive: what the threads before this one saw
-    if ((tid & 63) == 0) rs = -1;
-    __syncthreads();
-    if ((tid & 63) == 63) tmp[tid >> 6] = incl;
-    __syncthreads();
-    if ((tid & 63) == 0 && tid > 0) rs = tmp[(tid >> 6) - 1];
-    // 2. heads (natural, or PR_CAP points into a run), monotonicity of z inside the columns
-    int heads = 0, va = 0, vd = 0;
-    {
-        int r = rs;
-        for (int i = lo; i < hi; ++i) {
-            const bool nh = natural_head(i);
-            if (nh) r = i;
-            const bool head = nh || ((i - r) % cap == 0);
-            heads += head ? 1 : 0;
-            if (!head) {
-                const float z0 = pz[i - 1], z1 = pz[i];
-                va |= (z1 < z0) ? 1 : 0;
-                vd |= (z1 > z0) ? 1 : 0;
-                va |= (z1 != z1) ? 1 : 0;   // (NaN: neither order holds)
-                vd |= (z1 != z1) ? 1 : 0;
-            }
+    int carry_r = -1, carry_c = 0, va = 0, vd = 0;
+    // The next block's loads fly while this block is scanned (the blocks are a serial chain of memory round trips otherwise).
+    // __syncthreads() would wait for them - its release fence drains the vector-memory counter -, so the barriers inside the loop
+    // are bare: what crosses the waves there lives in LDS only.
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    float xn[V], yn[V], zn[V], xq[V], yq[V], zq[V];   // the points of the wave's four steps and their predecessors
+    auto fetch = [&](int b0) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int i = b0 + wave * 256 + q * 64 + lane;
+            const bool ok = i < n, okp = i >= 1 && i < n;
+            xn[q] = ok ? px[i] : 0.0f;
+            yn[q] = ok ? py[i] : 0.0f;
+            zn[q] = ok ? pz[i] : 0.0f;
+            xq[q] = okp ? px[i - 1] : 0.0f;
+            yq[q] = okp ? py[i - 1] : 0.0f;
+            zq[q] = okp ? pz[i - 1] : 0.0f;
         }
+    };
+    fetch(0);
+    __syncthreads();   // viol zeroed
+    for (int b0 = 0; b0 < n; b0 += BS) {
+        const int w0 = b0 + wave * 256;
+        // natural heads: the point's (x, y) differs from its predecessor's
+        unsigned long long mnh[V];
+        bool zup[V], zdn[V];
+        int lastnh = -1;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int i = w0 + q * 64 + lane;
+            const bool nh = i < n && (i == 0 || xn[q] != xq[q] || yn[q] != yq[q]);
+            mnh[q] = __ballot(nh);
+            zup[q] = zn[q] < zq[q] || zn[q] != zn[q];   // (NaN: neither order holds)
+            zdn[q] = zn[q] > zq[q] || zn[q] != zn[q];
+            if (mnh[q]) lastnh = w0 + q * 64 + 63 - __clzll(mnh[q]);
+        }
+        if (b0 + BS < n) fetch(b0 + BS);
+        if (lane == 0) tmpm[wave] = lastnh;
+        lds_barrier();
+        int r = carry_r, blockmax = -1;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int t = tmpm[w];
+            if (w < wave) r = max(r, t);
+            blockmax = max(blockmax, t);
+        }
+        // heads: natural, or PR_CAP points into a run; z monotonic inside the columns
+        unsigned long long mh[V];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int i = w0 + q * 64 + lane;
+            const unsigned long long mine = mnh[q] & le;
+            const int rl = mine ? w0 + q * 64 + 63 - __clzll(mine) : r;     // the run that holds this lane's point starts here
+            const bool head = i < n && (((i - rl) & (PR_CAP - 1)) == 0);   // (a natural head: i == rl)
+            mh[q] = __ballot(head);
+            cnt += __popcll(mh[q]);
+            if (i < n && !head) {
+                va |= zup[q] ? 1 : 0;
+                vd |= zdn[q] ? 1 : 0;
+            }
+            if (mnh[q]) r = w0 + q * 64 + 63 - __clzll(mnh[q]);
+        }
+        if (lane == 0) tmps[wave] = cnt;
+        lds_barrier();
+        int c = carry_c, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int t = tmps[w];
+            if (w < wave) c += t;
+            total += t;
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            if ((mh[q] >> lane) & 1ull) colstart[c + __popcll(mh[q] & lt)] = w0 + q * 64 + lane;
+            c += __popcll(mh[q]);
+        }
+        carry_r = max(carry_r, blockmax);
+        carry_c += total;
+        lds_barrier();   // tmpm / tmps are written again in the next block
     }
     if (va) atomicOr(&viol[0], 1);
     if (vd) atomicOr(&viol[1], 1);
-    int ncols = 0;
-    const int hincl = pr_block_scan_sum(heads, tmp, ncols);
-    {
-        int c = hincl - heads, r = rs;
-        for (int i = lo; i < hi; ++i) {
-            const bool nh = natural_head(i);
-            if (nh) r = i;
-            if (nh || ((i - r) % cap == 0)) colstart[c++] = i;
-        }
-    }
+    const int ncols = carry_c;
     __threadfence_block();
-    __syncthreads();
-    // 3. lengths and the work items
-    const int mc = (ncols + PR_THREADS - 1) / PR_THREADS;
-    const int clo = min(ncols, tid * mc), chi = min(ncols, clo + mc);
-    int nt = 0;
-    for (int c = clo; c < chi; ++c) {
-        const int k = (c + 1 < ncols ? colstart[c + 1] : n) - colstart[c];
-        kcount[c] = k;
-        nt += (k + tile - 1) / tile;
-    }
+    __syncthreads();   // colstart (global) and viol visible to the workgroup
     int ntiles = 0;
-    const int tincl = pr_block_scan_sum(nt, tmp, ntiles);
-    int j = tincl - nt;
-    for (int c = clo; c < chi; ++c) {
-        const int k = (c + 1 < ncols ? colstart[c + 1] : n) - colstart[c];
-        for (int zc = 0; zc * tile < k; ++zc) {
-            tiles[2 * j] = c;
-            tiles[2 * j + 1] = zc;
-            ++j;
+    if ((long long)ncols * 32 <= n) {
+        int carry_t = 0;
+        for (int c0 = 0; c0 < ncols; c0 += PR_THREADS) {
+            const int c = c0 + tid;
+            int k = 0, nt = 0;
+            if (c < ncols) {
+                k = (c + 1 < ncols ? colstart[c + 1] : n) - colstart[c];
+                kcount[c] = k;
+                nt = (k + tile - 1) / tile;
+            }
+            const int vs = pr_wave_scan_sum(nt, lane);
+            if (lane == 63) tmps[wave] = vs;
+            __syncthreads();
+            int addt = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int t = tmps[w];
+                if (w < wave) addt += t;
+                total += t;
+            }
+            int j = carry_t + addt + vs - nt;
+            for (int zc = 0; zc < nt; ++zc) {
+                tiles[2 * j] = c;
+                tiles[2 * j + 1] = zc;
+                ++j;
+            }
+            carry_t += total;
+            __syncthreads();
         }
+        ntiles = carry_t;
     }
     if (tid == 0) {
         meta[0] = ncols;
@@ -2023,7 +2057,7 @@ extern "C" int surs_query_points_columns(const float *points, long long ld, int 
     int *colstart = (int *)lists, *kcount = colstart + PR_CHUNK, *tiles = kcount + PR_CHUNK;
     int *meta = (int *)(lists + point_runs_list_bytes() - 256);
     const int tile = dtype == SURS_F32 ? 64 : 128;
-    hipLaunchKernelGGL(point_runs_kernel, dim3(1), dim3(PR_THREADS), 0, st, points, points + ld, points + 2 * ld, n, PR_CAP, tile, colstart,
+    hipLaunchKernelGGL(point_runs_kernel, dim3(1), dim3(PR_THREADS), 0, st, points, points + ld, points + 2 * ld, n, tile, colstart,
                        kcount, tiles, meta);
     SURS_LAUNCH_CHECK();
     int host[4] = {0, 0, 0, 0};

@@ -11,6 +11,8 @@ no training path (backward is out of scope) and no CPU path: methods raise witho
 """
 from collections import OrderedDict
 
+import math
+
 import numpy as np
 import torch
 
@@ -61,6 +63,7 @@ class SuRSNet:
         self.intermediate_preds_list_lr = []
         self.intermediate_preds_list_hr = []
         self._mr_points = None
+        self._feat_cache = None
         self._mr_version = 0
         self._last_images = None      # what super_res() last ran on, and which buffers came out of that run (reencode_wide)
         self._sr_out = self._lr_from = self._hr_from = None
@@ -197,7 +200,17 @@ class SuRSNet:
             raise RuntimeError("filter_lr / filter_hr must run before a query")
         if b >= self.im_feat_list_lr[-1].shape[0] or b >= self.im_feat_list_hr[0].shape[0]:
             raise RuntimeError("the encoder ran on %d images, the query asks for image %d" % (self.im_feat_list_lr[-1].shape[0], b))
-        return _as_img(self.im_feat_list_lr[-1][b:b + 1]), _as_img(self.im_feat_list_hr[0][b:b + 1])
+        # (feature maps assigned by hand as NCHW tensors are converted once, not once per query: the reference's loop asks 2 684
+        #  times per 512^3 grid; the encoder's own outputs are NHWC views and cost nothing either way)
+        tl, th = self.im_feat_list_lr[-1], self.im_feat_list_hr[0]
+        key = (b, tl.data_ptr(), th.data_ptr(), tuple(tl.shape), tuple(th.shape), tl.stride(), th.stride(),
+               getattr(tl, "_version", None) if not tl.is_inference() else None,
+               getattr(th, "_version", None) if not th.is_inference() else None)
+        if self._feat_cache is not None and self._feat_cache[0] == key:
+            return self._feat_cache[1]
+        out = _as_img(tl[b:b + 1]), _as_img(th[b:b + 1])
+        self._feat_cache = (key, out)
+        return out
 
     # ------------------------------------------------------------------ query
     def _zscale(self):
@@ -309,7 +322,9 @@ class SuRSNet:
         synchronisation) are computed again on three bf16 parts - fp32's exponent range -, after re-running the encoder the same
         way if its features are what overflowed."""
         phr, plr = run() if first is None else first
-        if bool(torch.isfinite(phr).all() & torch.isfinite(plr).all()):   # (one host synchronisation, not two)
+        # (occupancies lie in [0, 1]: their sum is finite exactly when every one of them is - two reductions and one host
+        #  synchronisation instead of twelve small kernels per call)
+        if math.isfinite((phr.sum() + plr.sum()).item()):
             return phr, plr
         import warnings
         warnings.warn("query: non-finite predictions from the two-part f16 operand split; repeating on three bf16 parts", stacklevel=3)
