@@ -108,6 +108,11 @@ size_t surs_conv_pack_weights(const float *w, int cout, int cin, int ksize, floa
  * scale[c] = gamma[c]*rstd[g(c)], shift[c] = beta[c] - mean[g]*rstd[g]*gamma[c]   (biased variance, eps). */
 int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
                           const float *beta, float *scale, float *shift, void *stream);
+/* The same with the scratch of the partial sums supplied by the caller (surs_groupnorm_scratch_bytes() bytes, device): nothing is
+ * allocated inside, so the two launches can be captured into a HIP graph (hipMalloc is not permitted on a capturing stream). */
+size_t surs_groupnorm_scratch_bytes(void);
+int surs_groupnorm_coeffs_ws(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
+                             const float *beta, float *scale, float *shift, void *scratch, void *stream);
 /* y = relu?(x*scale + shift) elementwise (GroupNorm apply when it is not followed by a conv) */
 int surs_scale_shift_act(const float *x, int hw, int c, int x_ld, const float *scale, const float *shift, int relu,
                          float *y, int y_ld, void *stream);

@@ -51,6 +51,8 @@ _SIGS = {
     "surs_conv2d_nhwc": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),
     "surs_conv_pack_weights": (_sz, [_vp, _i, _i, _i, _vp]),
     "surs_groupnorm_coeffs": (C.c_int, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "surs_groupnorm_coeffs_ws": (C.c_int, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "surs_groupnorm_scratch_bytes": (_sz, []),
     "surs_scale_shift_act": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "surs_avgpool2": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "surs_bicubic_up2": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -1407,6 +1407,9 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
     return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 
+extern "C" int surs_groupnorm_coeffs_ws(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
+                                        const float *beta, float *scale, float *shift, void *scratch, void *stream);
+
 extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
                                      const float *beta, float *scale, float *shift, void *stream) {
     SURS_REQUIRE(x && gamma && beta && scale && shift, "null argument");
@@ -1426,8 +1429,22 @@ extern "C" int surs_groupnorm_coeffs(const float *x, int hw, int c, int x_ld, in
         if (!slot) SURS_HIP_CHECK(hipMalloc((void **)&slot, sizeof(double) * 64 * GN_SPLIT * 2));
         buf = slot;
     }
+    return surs_groupnorm_coeffs_ws(x, hw, c, x_ld, groups, eps, gamma, beta, scale, shift, buf, stream);
+}
+
+// The same with the scratch for the partial sums supplied by the caller (surs_groupnorm_scratch_bytes() bytes of device memory):
+// no allocation inside - what a caller that captures its launches into a HIP graph needs (hipMalloc is not permitted on a
+// capturing stream) - and no state shared between streams.
+extern "C" size_t surs_groupnorm_scratch_bytes(void) { return sizeof(double) * 64 * GN_SPLIT * 2; }
+
+extern "C" int surs_groupnorm_coeffs_ws(const float *x, int hw, int c, int x_ld, int groups, float eps, const float *gamma,
+                                        const float *beta, float *scale, float *shift, void *scratch, void *stream) {
+    SURS_REQUIRE(x && gamma && beta && scale && shift && scratch, "null argument");
+    SURS_REQUIRE(groups > 0 && groups <= 64 && c % groups == 0 && hw > 0, "bad GroupNorm shape");
     SURS_REQUIRE(c % 4 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0 && c <= 1024,
                  "GroupNorm statistics: channels and pitch must be multiples of 4 (16-byte aligned rows), at most 1024 channels");
+    hipStream_t st = as_stream(stream);
+    double *buf = (double *)scratch;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_SPLIT), dim3(256), 0, st, x, hw, c, x_ld, groups, buf);
     SURS_LAUNCH_CHECK();
     hipLaunchKernelGGL(gn_finish_kernel, dim3(groups), dim3(64), 0, st, buf, hw, c, groups, eps, gamma, beta,

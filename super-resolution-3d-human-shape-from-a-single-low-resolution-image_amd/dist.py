@@ -319,7 +319,7 @@ def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transfor
     a, b = min(a, need_hr[0] // 4 // 2 * 2), max(b, -(-need_hr[1] // 4) + (-(-need_hr[1] // 4)) % 2)   # + what the slab samples of feature_hr (even bounds)
     b = min(b, wl)
     W = net._encoder_weights()
-    _, new2, new_fin = encoder.super_res_strip(W, x, a, b, want_image=False)   # (img_SR is not part of what this returns)
+    _, new2, new_fin = encoder.super_res_strip_g(W, x, a, b, want_image=False)   # (img_SR is not part of what this returns)
     dev = x.buf.device
     # ---- feature_lr: every rank's share, gathered
     mine = new2.buf.view(new2.h, new2.w, new2.c)[:, rank * share - a:(rank + 1) * share - a, :].contiguous()
@@ -330,10 +330,15 @@ def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transfor
         parts = [h.to(dev) for h in host]
     else:
         dist.all_gather(parts, mine, group=group)
-    f_lr = torch.cat(parts, dim=1).contiguous()
+    # (gathered into a buffer the network keeps: filter_lr's captured graph reads its input in place - encoder.filter_lr_g)
+    f_lr = getattr(net, "_gathered_lr", None)
+    if f_lr is None or tuple(f_lr.shape) != (new2.h, wl, new2.c) or f_lr.device != dev:
+        f_lr = net._gathered_lr = torch.empty((new2.h, wl, new2.c), dtype=torch.float32, device=dev)
+    torch.cat(parts, dim=1, out=f_lr)
     feature_lr = native.Img(new2.h, wl, new2.c, buf=f_lr.reshape(-1), device=dev)
+    encoder.persistent(feature_lr)
     # ---- filter_lr replicated, filter_hr on the strip (placed in a zeroed full-size map: the sweep addresses absolute columns)
-    outs = encoder.filter_lr(W, feature_lr, keep_all=net.training)
+    outs = encoder.filter_lr_g(W, feature_lr, keep_all=net.training)
     net._feat_lr_imgs = [[o] for o in outs]
     net.im_feat_list_lr = [_as_nchw_view(o) for o in outs]
     strip = encoder.filter_hr(W, new_fin)[0]

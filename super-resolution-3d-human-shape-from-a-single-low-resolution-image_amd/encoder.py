@@ -219,11 +219,30 @@ def hourglass(W, prefix, depth, x):
     #  stream under the current sweep, where two more streams of small kernels cost the sweep more than they save - 6.6 against 7.4
     #  subjects/s at 512^3)
     cur0 = torch.cuda.current_stream()
-    fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0" and cur0.cuda_stream == torch.cuda.default_stream(cur0.device).cuda_stream
+    # (... or one that is being captured into a HIP graph - graphed() below -, where the fork and the join become graph edges)
+    fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0" and (
+        cur0.cuda_stream == torch.cuda.default_stream(cur0.device).cuda_stream or torch.cuda.is_current_stream_capturing())
 
     st = native.fused_groupnorm()   # every map a ConvBlock reads is written with its GroupNorm statistics (conv_block)
 
+    capturing = torch.cuda.is_current_stream_capturing()
+
     def fwd(level, inp):
+        if fork and capturing:
+            # Captured into a HIP graph (graphed forms below): every fork leaves and rejoins the CAPTURE stream - the full-resolution
+            # ConvBlock of a level goes to the side stream, the low-resolution chain (with the next level's fork inside it) stays.
+            # A fork off a forked stream - the eager form's level 1 inside level 2's side stream - ends ROCm 7.2's
+            # hipStreamEndCapture in a segmentation fault (tools/dev/graph_probe.py nested).
+            cur, side = torch.cuda.current_stream(), _side_stream(level)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                up1 = conv_block(W, prefix + "b1_%d." % level, inp)
+            low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp, want_stats=st), want_stats=True)
+            low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1, want_stats=True)
+            low3 = conv_block(W, prefix + "b3_%d." % level, low2)
+            cur.wait_stream(side)
+            return native.bicubic_up2(low3, True, addend=up1, want_stats=st)
+
         def low_branch():
             low1 = conv_block(W, prefix + "b2_%d." % level, native.avgpool2(inp, want_stats=st), want_stats=True)
             low2 = fwd(level - 1, low1) if level > 1 else conv_block(W, prefix + "b2_plus_%d." % level, low1, want_stats=True)
@@ -277,3 +296,125 @@ def filter_lr(W, feature_lr, keep_all=False):
 
 def filter_hr(W, feature_hr):
     return [native.conv2d(feature_hr, W.conv["image_filter_hr.conv5"])]
+
+
+# ------------------------------------------------------------------ HIP graphs (opt-in: --encoder_graph 1 / SURS_ENC_GRAPH=1)
+# The encoder is ~ 160 launches of fixed shapes per image, a third of them a few microseconds long on the low-resolution branch of
+# the hourglasses, issued by Python through ctypes.  Captured ONCE per (weights, image size, options) into a HIP graph and replayed,
+# the chain does not depend on the host between kernels and the fork / join of the hourglass levels are graph edges.
+# MEASURED (round 5, one MI355X, 512^2 image, fp32-grade): 7.33 ms replayed against 7.17 ms eager (filter_lr 4.12 / 3.99) - the
+# eager launches are asynchronous and already GPU-bound (back-to-back kernels on each stream in the rocprofv3 trace), the graph only
+# removes the ~ 12 us event hand-overs between streams and pays for them with ROCm's own graph scheduling.  Hence opt-in.
+# What a replay hands out are the graph's own buffers: the tensors of the previous call with the same key are OVERWRITTEN (the
+# reference returns fresh tensors; everything on the reconstruction path consumes the features before the next image is encoded);
+# gen_mesh_pipelined's second encoder (off the default stream) and multi-view batches always run eagerly.
+_graphs = {}
+_stable = {}   # input addresses filter_lr_g may capture on: the super-resolution graphs' feature_lr buffers and addresses seen before
+GRAPH_CACHE = 8   # captured graphs kept per process (each holds the encoder's intermediates: ~ 1.5 GB at 512^2)
+
+
+def graphs_enabled(W=None):
+    """--encoder_graph 1 switches the graphs on for a network, SURS_ENC_GRAPH=1 / 0 for the process whatever the networks say."""
+    env = os.environ.get("SURS_ENC_GRAPH")
+    if env is not None:
+        return env != "0"
+    return W is not None and str(getattr(W.opt, "encoder_graph", "0")) != "0"
+
+
+def drop_graphs(W=None):
+    """Forget the captured graphs (of the weights W; all of them without an argument) and free their buffers."""
+    for k in [k for k in _graphs if W is None or k[1] == id(W)]:
+        del _graphs[k]
+    _stable.clear()
+
+
+def _graph_ok(W):
+    cur = torch.cuda.current_stream()
+    return (graphs_enabled(W) and not torch.cuda.is_current_stream_capturing()
+            and cur.cuda_stream == torch.cuda.default_stream(cur.device).cuda_stream)
+
+
+def _flags():
+    return (native.wide_operands_active(), native.fused_groupnorm(), os.environ.get("SURS_ENC_STREAMS", "1"))
+
+
+def _hwc(t):
+    return torch.as_strided(t.buf, (t.h, t.w, t.c), (t.w * t.ld, t.ld, 1), t.buf.storage_offset() + t.off)
+
+
+def _run_graphed(key, build, static_in=None, x=None):
+    """build(xin) -> outputs, captured on first use and replayed afterwards.  static_in: x is copied into a buffer of the graph's
+    own first (inputs that arrive at a new address every call); otherwise the key holds x's address and the graph reads x in place."""
+    ent = _graphs.get(key)
+    if ent is None:
+        if len(_graphs) >= GRAPH_CACHE:
+            _graphs.pop(next(iter(_graphs)))
+        xin = x
+        if static_in:
+            xin = Img(x.h, x.w, x.c, device=x.buf.device)
+            _hwc(xin).copy_(_hwc(x))
+        build(xin)                      # eager once: kernel attributes, lazily packed weights, side streams
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(device=x.buf.device)
+        with torch.cuda.stream(cap):       # (the hourglass levels' side streams of the capture stream exist before the capture starts)
+            for level in range(1, 8):
+                _side_stream(level)
+        with torch.cuda.graph(g, stream=cap):
+            outs = build(xin)
+        ent = _graphs[key] = (g, xin, outs)
+    g, xin, outs = ent
+    if static_in:
+        _hwc(xin).copy_(_hwc(x))
+    g.replay()
+    return outs
+
+
+def super_res_g(W, x, want_image=True):
+    """super_res through a captured graph where that is allowed (see above), eagerly otherwise."""
+    if not _graph_ok(W):
+        return super_res(W, x, want_image=want_image)
+    key = ("sr", id(W), x.h, x.w, x.c, want_image, _flags())
+    outs = _run_graphed(key, lambda xin: super_res(W, xin, want_image=want_image), static_in=True, x=x)
+    _stable[_addr_key(outs[1])] = outs[1].buf
+    return outs
+
+
+def super_res_strip_g(W, x, a, b, want_image=True):
+    if not _graph_ok(W):
+        return super_res_strip(W, x, a, b, want_image=want_image)
+    key = ("srs", id(W), x.h, x.w, x.c, a, b, want_image, _flags())
+    return _run_graphed(key, lambda xin: super_res_strip(W, xin, a, b, want_image=want_image), static_in=True, x=x)
+
+
+def _addr_key(t):
+    return (t.buf.data_ptr() + 4 * t.off, t.h, t.w, t.c, t.ld)
+
+
+def persistent(img):
+    """Tells filter_lr_g that `img` lives at an address its caller keeps across calls (a gather buffer): captured at first sight."""
+    _stable[_addr_key(img)] = img.buf
+
+
+def filter_lr_g(W, feature_lr, keep_all=False):
+    """filter_lr through a graph captured on the ADDRESS of its input (the super-resolution graph's feature_lr buffer, or a
+    caller's persistent one): an input at a new address is captured anew, at most GRAPH_CACHE graphs are kept."""
+    if not _graph_ok(W):
+        return filter_lr(W, feature_lr, keep_all=keep_all)
+    key = ("lr", id(W), _addr_key(feature_lr), keep_all, _flags())
+    if key not in _graphs and _addr_key(feature_lr) not in _stable:
+        # an address seen for the first time and not a graph's own buffer: a caller that allocates per call would have every call
+        # captured (an eager run + a capture each); the second sighting is taken as "persistent"
+        _stable[_addr_key(feature_lr)] = feature_lr.buf
+        if len(_stable) > 64:
+            _stable.pop(next(iter(_stable)))
+        return filter_lr(W, feature_lr, keep_all=keep_all)
+
+    def build(xin):
+        xin.stats = None
+        return filter_lr(W, xin, keep_all=keep_all)
+    return _run_graphed(key, build, static_in=False, x=feature_lr)
+
+
+def filter_hr_g(W, feature_hr):
+    return filter_hr(W, feature_hr)   # one launch: nothing to capture

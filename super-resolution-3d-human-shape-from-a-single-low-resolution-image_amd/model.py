@@ -113,6 +113,8 @@ class SuRSNet:
             else:
                 new[k] = self._sd[k]
         self._sd = new
+        if self._enc is not None:
+            encoder.drop_graphs(self._enc)
         self._enc = self._blob = None
         return self
 
@@ -143,7 +145,9 @@ class SuRSNet:
         """images [V,3,H,W] -> (img_SR [V,3,2H,2W], feature_lr [V,256,H/2,W/2], feature_hr [V,64,2H,2W])."""
         W = self._encoder_weights()
         self._last_images = images   # (kept for reencode_wide: the retry after an f16 overflow)
-        outs = [encoder.super_res(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
+        # (one view: through the captured HIP graph - encoder.graphed; several views would share the graph's output buffers)
+        sr = encoder.super_res_g if images.shape[0] == 1 else encoder.super_res
+        outs = [sr(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
         cat = lambda i: torch.cat([_as_nchw_view(o[i]) for o in outs], 0) if len(outs) > 1 else _as_nchw_view(outs[0][i])
         self.im_SR, self.feature_lr, self.feature_hr = cat(0), cat(1), cat(2)
         self._sr_out = (self.feature_lr.data_ptr(), self.feature_hr.data_ptr())
@@ -152,7 +156,8 @@ class SuRSNet:
 
     def filter_lr(self, images):
         W = self._encoder_weights()
-        per_view = [encoder.filter_lr(W, _as_img(images[v:v + 1]), keep_all=self.training) for v in range(images.shape[0])]
+        flr = encoder.filter_lr_g if images.shape[0] == 1 else encoder.filter_lr
+        per_view = [flr(W, _as_img(images[v:v + 1]), keep_all=self.training) for v in range(images.shape[0])]
         n_out = len(per_view[0])
         self._feat_lr_imgs = [[pv[i] for pv in per_view] for i in range(n_out)]
         self.im_feat_list_lr = [torch.cat([_as_nchw_view(pv[i]) for pv in per_view], 0) if len(per_view) > 1
@@ -191,8 +196,9 @@ class SuRSNet:
         (Img feat_lr, Img feat_hr) the query kernels read.  gen_mesh_pipelined runs it for the next subject on a second
         stream while the current subject's features are still in use."""
         W = self._encoder_weights()
-        _, f_lr, f_hr = encoder.super_res(W, _as_img(image[0:1]), want_image=False)
-        return encoder.filter_lr(W, f_lr)[-1], encoder.filter_hr(W, f_hr)[0]
+        # (the graphed forms run eagerly off the device's default stream: gen_mesh_pipelined's second encoder keeps its own buffers)
+        _, f_lr, f_hr = encoder.super_res_g(W, _as_img(image[0:1]), want_image=False)
+        return encoder.filter_lr_g(W, f_lr)[-1], encoder.filter_hr(W, f_hr)[0]
 
     def features(self, b=0):
         """(Img feat_lr, Img feat_hr) of image b of the encoded batch, last stack: what the query kernels read."""

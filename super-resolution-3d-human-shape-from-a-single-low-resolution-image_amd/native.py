@@ -240,8 +240,11 @@ def _ew_stats(n_items, device):
 def groupnorm_coeffs(x, gamma, beta, groups=32, eps=1e-5):
     scale = torch.empty(x.c, dtype=torch.float32, device=x.buf.device)
     shift = torch.empty_like(scale)
-    check(lib().surs_groupnorm_coeffs(x.ptr(), x.h * x.w, x.c, x.ld, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale),
-                                      _ptr(shift), _stream()))
+    # (the partial sums' scratch from the caching allocator: nothing is allocated inside the library, so the launches can be
+    #  captured into a HIP graph - encoder.py)
+    scratch = torch.empty(lib().surs_groupnorm_scratch_bytes(), dtype=torch.uint8, device=x.buf.device)
+    check(lib().surs_groupnorm_coeffs_ws(x.ptr(), x.h * x.w, x.c, x.ld, groups, eps, _ptr(gamma), _ptr(beta), _ptr(scale),
+                                         _ptr(shift), _ptr(scratch), _stream()))
     return scale, shift
 
 

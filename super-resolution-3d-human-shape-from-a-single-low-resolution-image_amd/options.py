@@ -70,6 +70,9 @@ _NATIVE = [
     ("encoder_precision", str, "auto"),   # fp32 = auto (two f16 parts, three products per MAC: the parity-grade encoder, with every
                                           # --precision) | f16 (one f16 product per MAC in the 3x3 convolutions: 11 significant bits,
                                           # opt-in; bounded by tests/test_gpu_precision.py with --precision bf16)
+    ("encoder_graph", str, "0"),     # 1 = the encoder of a single view replays a captured HIP graph (its outputs are the graph's buffers,
+                                     # overwritten by the next call: encoder.py "HIP graphs"; measured 2 % SLOWER than the eager launches
+                                     # at 512^2: opt-in) | 0 = eager launches, fresh tensors per call
     ("no_octree", None, False),      # dense sweep (the parity target)
     ("synthetic", None, False),      # synthetic image + PRNG weights instead of dataroot / checkpoint
     ("pipeline", None, False),       # eval driver: subjects as a pipeline (train_util.gen_mesh_pipelined) instead of one by one

@@ -46,6 +46,40 @@ def test_encoder_vs_reference(net, H, golden_dir):
     assert common.rel_err(s4(im_hr), g["im_feat_hr_sub"]) < tol
 
 
+def test_encoder_hip_graph_replays_the_eager_bits(monkeypatch):
+    """--encoder_graph 1: super_res and filter_lr captured into HIP graphs (hourglass forks as graph edges) return the eager
+    launches' bits, and a replay on another image returns that image's - in the SAME buffers (the documented aliasing)."""
+    from surs_amd import encoder, model, options
+    monkeypatch.delenv("SURS_ENC_GRAPH", raising=False)
+    H = 128
+
+    def make(flag):
+        n = model.SuRSNet(options.BaseOptions().parse(common.FLAGS + ["--encoder_graph", flag])).to(device=torch.device("cuda:0"))
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+        return n.eval()
+
+    def run(n, img):
+        _, f_lr, f_hr = n.super_res(img)
+        n.filter_hr(f_hr)
+        n.filter_lr(f_lr)
+        return f_lr, f_hr, n.im_feat_list_lr[-1], n.im_feat_list_hr[0]
+
+    imgs = [torch.from_numpy(weights.synthetic_image(H, seed=s)).to("cuda:0") for s in (1, 2)]
+    eager, graphed = make("0"), make("1")
+    want = [[t.clone() for t in run(eager, im)] for im in imgs]
+    n0 = len(encoder._graphs)
+    first = run(graphed, imgs[0])
+    assert len(encoder._graphs) == n0 + 2                      # super_res + filter_lr captured
+    assert all(torch.equal(a, b) for a, b in zip(first, want[0]))
+    ptrs = [t.data_ptr() for t in first]
+    second = run(graphed, imgs[1])                             # replays
+    assert len(encoder._graphs) == n0 + 2
+    assert [t.data_ptr() for t in second][:3] == ptrs[:3]      # (filter_hr is one launch: not captured, fresh tensor)
+    assert all(torch.equal(a, b) for a, b in zip(second, want[1]))
+    assert not torch.equal(want[0][2], want[1][2])
+    encoder.drop_graphs()
+
+
 def test_encoder_full_size_vs_reference(net, golden_dir):
     """BASELINE's image size (512 x 512: feature maps 256 x 256^2 and 64 x 1024^2, GroupNorm groups of 2 M elements) against
     the reference's own outputs: strided sub-samples of every output and of every stack's output, per-channel means of the

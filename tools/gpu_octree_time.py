@@ -29,7 +29,7 @@ def main():
     fl, fh = weights.body_features(256, 1024)
     feats = (pr._upload(fl, dev), pr._upload(fh, dev))
     calib = torch.from_numpy(pr.CALIB).to(dev)[None]
-    for use_oct in (False, True):
+    for use_oct in ((True,) if os.environ.get("OCTREE_ONLY") else (False, True)):
         for rep in range(3):
             torch.cuda.synchronize()
             t = time.perf_counter()
