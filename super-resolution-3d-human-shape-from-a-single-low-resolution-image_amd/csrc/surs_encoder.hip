@@ -630,6 +630,10 @@ template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
     const long long wg_big = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64);
+    // (A 16-row tile - every weight fragment read from LDS serves four rows instead of two, 501 registers with the accumulators in
+    //  AGPRs - was measured in round 5: super_res 2.93 -> 2.84 ms, filter_lr unchanged, and im_feat_lr wrong by up to 2.3 when four
+    //  processes share the GPU (tests/test_gpu_dist.py: the waves are preempted there; identical results in every single-process
+    //  run).  Not shipped: NOTES R5.7.)
     if (wg_big >= 512) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }

@@ -47,6 +47,11 @@ def encoder_leg(rank, world, R, H, dev):
     lo, hi = sdist.slab_feature_columns(i0, i1, create_grid(R, R, R, b_min, b_max)[1][:3], common.CALIB, 2 * H)
     same_lr = bool(torch.equal(rep.im_feat_list_lr[-1], shd.im_feat_list_lr[-1]))
     same_hr = bool(torch.equal(rep.im_feat_list_hr[0][..., lo:hi], shd.im_feat_list_hr[0][..., lo:hi]))
+    if not same_lr:   # where: the gathered feature_lr itself, or filter_lr on it
+        g = getattr(shd, "_gathered_lr", None)
+        print("rank %d: gathered feature_lr == replicated feature_lr: %s; max |d im_feat_lr| %.3e" %
+              (rank, None if g is None else bool(torch.equal(g.permute(2, 0, 1), rep.feature_lr[0])),
+               float((rep.im_feat_list_lr[-1] - shd.im_feat_list_lr[-1]).abs().max())), flush=True)
     print("rank %d: sharded encoder %s; im_feat_lr %s, im_feat_hr columns [%d, %d) %s" %
           (rank, "used" if used else "NOT used (fallback)", "identical" if same_lr else "DIFFERENT", lo, hi,
            "identical" if same_hr else "DIFFERENT"), flush=True)
