@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
     __shared__ float sx[64], sy[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long n0 = (long long)blockIdx.x * 64;
+    // gridDim.y > 1: the five channel chunks of a point group are shared among gridDim.y workgroups (small launches - the ~ 100 columns of
+    // a point-runs call - are a chain of load latencies: 33 us in one workgroup per 64 points); the first of them writes mask, z and the z tile
+    const bool lead = blockIdx.y == 0;
     if (tid < 64) {
         long long t = n0 + tid;
         float X = 2.0f, Y = 2.0f;  // outside
@@ -138,11 +141,13 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
                 Y = Y / Z;
             }
             const float in = (X >= -1.0f && X <= 1.0f && Y >= -1.0f && Y <= 1.0f) ? 1.0f : 0.0f;
-            mask[t] = in;
-            if (zproj) zproj[t] = Z;
-            F[(long long)C_G * ldf + t] = Z * src.zmul / src.zdiv;
-            F[(long long)(C_G + 1) * ldf + t] = 0.0f;
-            if (Fs) {   // k-tile 20 = rows 320..335: z, the p_lr slot (mlp_last_kernel fills it), zero padding
+            if (lead) {
+                mask[t] = in;
+                if (zproj) zproj[t] = Z;
+                F[(long long)C_G * ldf + t] = Z * src.zmul / src.zdiv;
+                F[(long long)(C_G + 1) * ldf + t] = 0.0f;
+            }
+            if (Fs && lead) {   // k-tile 20 = rows 320..335: z, the p_lr slot (mlp_last_kernel fills it), zero padding
                 unsigned short zp[NP];
                 SplitKind<NP>::split(Z * src.zmul / src.zdiv, zp);
 #pragma unroll
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void gather_kernel(PointSource src, long long 
     }
     __syncthreads();
     // 5 channel chunks of 64: 4 from the lr map, 1 from the hr map
-    for (int chunk = 0; chunk < 5; ++chunk) {
+    for (int chunk = blockIdx.y; chunk < 5; chunk += gridDim.y) {
         const bool is_hr = chunk == 4;
         const float *feat = is_hr ? feat_hr : feat_lr;
         const int H = is_hr ? hh : hl, W = is_hr ? wh : wl, C = is_hr ? C_HR : C_LR;
@@ -1093,11 +1098,12 @@ static int column_constants(hipStream_t st, const PointSource &src, long long nc
     const int parts = split_parts();
     unsigned short *Fs = (unsigned short *)(cmask + COL_BATCH);
     const long long fs_part = (long long)C0PAD * COL_BATCH;
+    const dim3 gg((unsigned)ceil_div(nc, 64), nc <= 4096 ? 5u : 1u);
     if (parts == 2)
-        hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+        hipLaunchKernelGGL(gather_kernel<2>, gg, dim3(256), 0, st, src, nc, feat_lr, hl, wl,
                            feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
     else
-        hipLaunchKernelGGL(gather_kernel<3>, dim3((unsigned)ceil_div(nc, 64)), dim3(256), 0, st, src, nc, feat_lr, hl, wl,
+        hipLaunchKernelGGL(gather_kernel<3>, gg, dim3(256), 0, st, src, nc, feat_lr, hl, wl,
                            feat_hr, hh, wh, F, COL_BATCH, cmask, (float *)nullptr, split ? Fs : (unsigned short *)nullptr, fs_part);
     SURS_LAUNCH_CHECK();
     if (split) {
@@ -1260,6 +1266,26 @@ static int device_cus() {
     return 256;
 }
 
+// A second stream of the library's own per (device, host thread) with the two events of a fork / join: run_column_batch's small batches.
+namespace {
+struct SideLane {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+}  // namespace
+static SideLane *side_lane() {
+    static thread_local std::map<int, SideLane> lanes;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideLane &l = lanes[dev];
+    if (!l.s) {
+        if (hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) != hipSuccess) { l.s = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) { l.s = nullptr; return nullptr; }
+    }
+    return &l;
+}
+
 // One batch of nc <= COL_BATCH columns described by src (mode 2: consecutive columns from src.base; mode 4: listed columns):
 // gather + column constants, the restated kernels' per-column affine part, then the column kernel over `items` z items per column
 // (dense: the voxels 0 .. items - 1; lattice sweeps: the kcount[column] listed voxels klist[column][.] * zstride).  vol_*: [nc][items].
@@ -1335,7 +1361,15 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             hipLaunchKernelGGL(colsum_prepare_kernel<3>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
                                g_lr, part_lr, g_hr, part_hr);
         SURS_LAUNCH_CHECK();
+        // small batches (the ~ 100 columns of a point-runs call: 4 - 6 workgroups per GEMM walking K = 1024, a latency chain of 33 - 62 us
+        // each): the two classifiers' GEMMs side by side, the hr one on a stream of the library's own
+        SideLane *lane2 = ncp <= 1024 ? side_lane() : nullptr;
+        if (lane2) {
+            SURS_HIP_CHECK(hipEventRecord(lane2->fork, st));
+            SURS_HIP_CHECK(hipStreamWaitEvent(lane2->s, lane2->fork, 0));
+        }
         for (int m = 0; m < 2; ++m) {
+            hipStream_t st = (m == 1 && lane2) ? lane2->s : cs.st;
             const int nvec = m ? 3 : 2;
             const long long npm = (long long)nvec * ncp;
             SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
@@ -1355,6 +1389,10 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
                                    st, (const unsigned short *)(blob + h.wt3[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
                                    (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
             SURS_LAUNCH_CHECK();
+        }
+        if (lane2) {
+            SURS_HIP_CHECK(hipEventRecord(lane2->join, lane2->s));
+            SURS_HIP_CHECK(hipStreamWaitEvent(st, lane2->join, 0));
         }
         a.rvec_lr = r_lr;
         a.rvec_hr = r_hr;
@@ -2060,8 +2098,11 @@ extern "C" int surs_query_points_columns(const float *points, long long ld, int 
     hipLaunchKernelGGL(point_runs_kernel, dim3(1), dim3(PR_THREADS), 0, st, points, points + ld, points + 2 * ld, n, tile, colstart,
                        kcount, tiles, meta);
     SURS_LAUNCH_CHECK();
-    int host[4] = {0, 0, 0, 0};
-    SURS_HIP_CHECK(hipMemcpyAsync(host, meta, sizeof(host), hipMemcpyDeviceToHost, st));
+    // (the four words land in pinned memory: a copy into pageable memory is staged and costs another ~ 15 us of the call's round trip)
+    static thread_local int *host = nullptr;
+    if (!host) SURS_HIP_CHECK(hipHostMalloc((void **)&host, 4 * sizeof(int), hipHostMallocDefault));
+    host[0] = host[1] = host[2] = host[3] = 0;
+    SURS_HIP_CHECK(hipMemcpyAsync(host, meta, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     SURS_HIP_CHECK(hipStreamSynchronize(st));
     const long long ncols = host[0];
     if (ncols <= 0 || ncols * 32 > n || ncols > COL_BATCH || (host[2] && host[3])) return 0;
