@@ -223,6 +223,10 @@ int surs_query_points_hr(const float *points, int n, const float *calib, float z
  *   *columns = the number of runs evaluated, or 0 - NOTHING WAS WRITTEN, call surs_query_points - when the array holds fewer than
  *   2048 points or more than one run per 32 points, z is not monotonic inside the runs, or the calibration lets the image position
  *   depend on z (calib[2], calib[6]) or the depth on x, y (calib[8], calib[9]).  Synchronises the stream once (the run count). */
+/* Its run finder alone (tests, diagnostics): colstart[c] / kcount[c] = first point and length of run c (ints, room for n each), tiles =
+ * (run, z tile) pairs of `tile` = 64 | 128 points (room for 2 n ints), meta[4] = {runs, work items - 0 and no lengths / work items when the
+ * array holds more than one run per 32 points -, z ascending violated, z descending violated}.  Device pointers; no synchronisation. */
+int surs_point_runs(const float *points, long long ld, int n, int tile, int *colstart, int *kcount, int *tiles, int *meta, void *stream);
 size_t surs_query_points_columns_workspace_bytes(void);
 int surs_query_points_columns(const float *points, long long ld, int n, const float *calib, float zmul, float zdiv,
                               const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,

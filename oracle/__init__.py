@@ -432,5 +432,32 @@ def eval_grid_octree(res, b_min, b_max, eval_func, threshold=0.05, init_resoluti
     return sdf_hr, sdf_lr
 
 
+
+def point_runs(points, tile=64, cap=4096):
+    """The runs of a point array [3, N] as surs_query_points_columns' run finder defines them (csrc/surs_query.hip point_runs_kernel;
+    what lib/sdf.py:32-45 hands lib/mesh_util.py:20-28 per call: consecutive grid points, z fastest): a run starts where (x, y)
+    differs from the predecessor's, or `cap` points into a run.  Returns colstart, kcount, tiles [(run, z tile)], and
+    (ascending violated, descending violated): whether z goes down / up anywhere inside a run (NaN violates both).  Plain loops."""
+    p = np.asarray(points, np.float32)
+    z = p[2]   # (x, y compared as floats, like the kernel: -0.0 == 0.0, NaN != NaN)
+    n = p.shape[1]
+    colstart, r = [], 0
+    asc_v = desc_v = False
+    for i in range(n):
+        nh = i == 0 or not (p[0, i] == p[0, i - 1]) or not (p[1, i] == p[1, i - 1])
+        if nh:
+            r = i
+        head = nh or (i - r) % cap == 0
+        if head:
+            colstart.append(i)
+        else:
+            asc_v |= bool(z[i] < z[i - 1]) or bool(z[i] != z[i])
+            desc_v |= bool(z[i] > z[i - 1]) or bool(z[i] != z[i])
+    colstart = np.asarray(colstart, np.int32)
+    kcount = np.diff(np.append(colstart, n)).astype(np.int32)
+    tiles = np.asarray([(c, t) for c, k in enumerate(kcount) for t in range((k + tile - 1) // tile)], np.int32).reshape(-1, 2)
+    return colstart, kcount, tiles, (asc_v, desc_v)
+
+
 def num_threads():
     return int(lib().orc_num_threads())

@@ -2073,6 +2073,19 @@ __global__ __launch_bounds__(PR_THREADS) void point_runs_kernel(const float *__r
 
 static size_t point_runs_list_bytes() { return align_up((size_t)PR_CHUNK * 4 * sizeof(int) + 256, 256); }
 
+// The run finder alone (tests, diagnostics): colstart / kcount [n] ints, tiles [2 n] ints, meta [4] ints = {columns, work items (0 when
+// the array holds more than one column per 32 points: lengths and work items are then not written), ascending violated, descending
+// violated}; tile = 64 | 128 points per work item.  All device pointers; no synchronisation.
+extern "C" int surs_point_runs(const float *points, long long ld, int n, int tile, int *colstart, int *kcount, int *tiles, int *meta,
+                               void *stream) {
+    SURS_REQUIRE(points && colstart && kcount && tiles && meta, "null argument");
+    SURS_REQUIRE(n > 0 && n <= PR_CHUNK && ld >= n && (tile == 64 || tile == 128), "1 .. %d points, row pitch ld >= n, tile 64 or 128", PR_CHUNK);
+    hipLaunchKernelGGL(point_runs_kernel, dim3(1), dim3(PR_THREADS), 0, as_stream(stream), points, points + ld, points + 2 * ld, n, tile,
+                       colstart, kcount, tiles, meta);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" size_t surs_query_points_columns_workspace_bytes(void) { return col_ws_bytes(COL_BATCH) + point_runs_list_bytes(); }
 
 extern "C" int surs_query_points_columns(const float *points, long long ld, int n, const float *calib, float zmul, float zdiv,

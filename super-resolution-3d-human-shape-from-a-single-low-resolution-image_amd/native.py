@@ -484,6 +484,22 @@ def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtyp
     return phr, plr
 
 
+def point_runs(points, tile=64):
+    """surs_point_runs: the runs surs_query_points_columns would evaluate in points [3,N] (N <= POINT_RUNS_CHUNK) - numpy arrays
+    (colstart, kcount, tiles [ntiles, 2], meta [4]); kcount / tiles are empty when the array holds more than one run per 32 points."""
+    points = _f32c(points)
+    n = points.shape[1]
+    dev = points.device
+    cs, kc = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    tl, meta = torch.empty(2 * n, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    check(lib().surs_point_runs(_ptr(points), n, n, int(tile), _ptr(cs), _ptr(kc), _ptr(tl), _ptr(meta), _stream()))
+    m = meta.cpu().numpy()
+    nc, nt = int(m[0]), int(m[1])
+    listed = nc * 32 <= n
+    return (cs[:nc].cpu().numpy(), kc[:nc].cpu().numpy() if listed else np.zeros(0, np.int32),
+            tl[:2 * nt].cpu().numpy().reshape(-1, 2) if listed else np.zeros((0, 2), np.int32), m)
+
+
 def query_points_hr(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, p_lr):
     """surs_query_points_hr: the hr classifier on points [3,N] with the lr occupancies p_lr [N] given (query_sr on points other than
     query_mr's).  Returns pred_hr [N]."""

@@ -536,3 +536,35 @@ def test_point_runs_refused_where_there_are_none(setup):
     assert _qc(setup, pts, "fp32", calib=cal) is None
     short = _run_points(seed=9, ncols=3000, lo=8, hi=24)                                 # ~ 16 points per run
     assert _qc(setup, short, "fp32") is None
+
+
+def test_point_runs_kernel_equals_its_restatement(setup):
+    """surs_point_runs (one workgroup: ballots, bit counts, two carries across blocks of 4096 points) against oracle.point_runs
+    (plain loops) on ragged runs, runs cut at 4096 points, a chunk cut out of a grid, NaN and -0.0, and an array of singles."""
+    import oracle
+    nat = setup["native"]
+
+    def check(pts, tile):
+        cs, kc, tl, meta = nat.point_runs(torch.from_numpy(np.ascontiguousarray(pts)).to(setup["g"].dev()), tile)
+        ocs, okc, otl, oviol = oracle.point_runs(pts, tile)
+        assert meta[0] == len(ocs) and np.array_equal(cs, ocs)
+        assert (bool(meta[2]), bool(meta[3])) == oviol
+        if len(ocs) * 32 <= pts.shape[1]:
+            assert np.array_equal(kc, okc) and meta[1] == len(otl)
+            assert np.array_equal(tl[np.lexsort((tl[:, 1], tl[:, 0]))], otl)
+        else:
+            assert meta[1] == 0
+    check(_run_points(seed=11, ncols=300, lo=33, hi=700), 64)
+    check(_run_points(seed=12, ncols=90, lo=100, hi=512, descending=True), 128)
+    long_runs = np.concatenate([_run_points(seed=13, ncols=3, lo=9000, hi=9500), _run_points(seed=14, ncols=40, lo=40, hi=80)], axis=1)
+    check(long_runs, 64)
+    grid = oracle.grid_points(64, [-0.5] * 3, [0.5] * 3)
+    check(np.ascontiguousarray(grid[:, 12345:12345 + 50000]), 128)
+    odd = _run_points(seed=15, ncols=120, lo=50, hi=90)
+    odd[2, 777] = np.nan
+    odd[0, 1500:1510] = -0.0
+    odd[0, 1510:1520] = 0.0
+    check(odd, 64)
+    from surs_amd import weights
+    check(weights.synthetic_points(5000, seed=3), 64)
+    check(_run_points(seed=16, ncols=5000, lo=40, hi=64)[:, :262144], 64)    # the largest call: 64 blocks of 4096 points

@@ -146,3 +146,23 @@ def test_query_sr_on_other_points_oracle_matches_reference_golden(golden_dir):
         # the hr mask is that of query_sr's points, not query_mr's
         same_pts, _, _, _ = oracle.query_views(sd, pts_mr[b][None], g["cal_mr"][b][None], fl[None], fh[None])
         assert not np.array_equal(same_pts[0] == 0, hr[0] == 0)
+
+
+def test_point_runs_restatement_on_a_grid_chunk():
+    """oracle.point_runs on a piece of a flattened grid (lib/sdf.py:4-29 order: z fastest) cut mid-column: the runs are the
+    columns, the first and the last one partial; a run longer than the cap is cut; z order violations are reported per direction."""
+    import oracle
+    R = 20
+    pts = oracle.grid_points(R, [-0.5] * 3, [0.5] * 3)
+    a, n = 7 * R * R + 3 * R + 11, 1000
+    cs, kc, tiles, viol = oracle.point_runs(pts[:, a:a + n], tile=8)
+    assert cs[0] == 0 and kc[0] == R - 11 and (kc[1:-1] == R).all() and kc.sum() == n
+    assert (np.diff(cs) == kc[:-1]).all() and viol == (False, True)          # z ascends inside every column
+    assert len(tiles) == sum((k + 7) // 8 for k in kc) and tiles[0].tolist() == [0, 0] and tiles[-1][0] == len(kc) - 1
+    line = np.stack([np.zeros(100, np.float32), np.zeros(100, np.float32), np.linspace(1, 0, 100, dtype=np.float32)])
+    cs, kc, _, viol = oracle.point_runs(line, cap=32)
+    assert cs.tolist() == [0, 32, 64, 96] and kc.tolist() == [32, 32, 32, 4] and viol == (True, False)
+    line[2, 50] = np.nan
+    assert oracle.point_runs(line, cap=32)[3] == (True, True)
+    line[0, 10] = -0.0                                                        # -0.0 == 0.0: no new run
+    assert oracle.point_runs(line, cap=1000)[0].tolist() == [0]

@@ -12,3 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/oct -o oct -- python3
 python3 tools/gpu_slab_stage_times.py 512 bf16 body > $O/slab_stage_times_body.json 2> $O/slab_body.err
 python3 tools/gpu_slab_stage_times.py 512 bf16 noise > $O/slab_stage_times_noise.json 2> $O/slab_noise.err
 find $O -name "*stats.csv" | head -20
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/loop32 -o loop -- python3 tools/gpu_points_loop.py fp32 40 grid > $O/points_loop_fp32.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/loop16 -o loop -- python3 tools/gpu_points_loop.py bf16 40 grid > $O/points_loop_bf16.log 2>&1
