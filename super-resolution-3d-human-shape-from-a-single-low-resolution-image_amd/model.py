@@ -298,6 +298,8 @@ class SuRSNet:
                     with native.reduced_point_operands(self.precision in ("bf16", "fp16")):
                         first = run()
                 outs.append(self._finite_or_wide(run, b, first=first))
+            if B == 1:   # (no copy: the reference's sweep loop comes through here 2 684 times per 512^3 grid)
+                return outs[0][0].view(1, 1, -1), outs[0][1].view(1, 1, -1)
             phr = torch.stack([o[0] for o in outs]).view(B, 1, -1)
             plr = torch.stack([o[1] for o in outs]).view(B, 1, -1)
             return phr, plr
