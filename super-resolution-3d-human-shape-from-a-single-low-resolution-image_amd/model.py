@@ -63,6 +63,7 @@ class SuRSNet:
         self.intermediate_preds_list_lr = []
         self.intermediate_preds_list_hr = []
         self._mr_points = None
+        self._runs_refused = 0        # consecutive point arrays the run finder refused (query_points_columns)
         self._feat_cache = None
         self._mr_version = 0
         self._last_images = None      # what super_res() last ran on, and which buffers came out of that run (reencode_wide)
@@ -292,8 +293,14 @@ class SuRSNet:
                 # precision); non-finite results are repeated fp32-grade on three bf16 parts like every other overflow
                 # points that come as runs of equal (x, y) - the reference's sweep loop: consecutive grid points, z fastest - are
                 # columns: the restated column kernels take them (same arithmetic as reconstruction()'s sweep in this precision)
-                first = native.query_points_columns(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(), self.precision,
-                                                    self._workspace()) if p_lr is None else None
+                # (callers whose arrays hold no runs - random samples - pay the run finder and its host round trip, ~ 0.1 ms, for
+                #  nothing: after two refusals in a row only every 16th call asks again)
+                first = None
+                if p_lr is None and (self._runs_refused < 2 or self._runs_refused % 16 == 0):
+                    first = native.query_points_columns(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(), self.precision,
+                                                        self._workspace())
+                if p_lr is None:
+                    self._runs_refused = 0 if first is not None else self._runs_refused + 1
                 if first is None:
                     with native.reduced_point_operands(self.precision in ("bf16", "fp16")):
                         first = run()
