@@ -245,6 +245,15 @@ int surs_query_points_views(const float *points, int n, int num_views, int proje
                             float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
                             const void *mlp_blob, void *workspace, size_t workspace_bytes, float *pred_hr, float *pred_lr,
                             float *logit_hr, float *logit_lr, void *stream);
+
+/* The dense sweep of such a model as one call: eval_grid's batch loop (lib/sdf.py:32-52) over eval_func (lib/mesh_util.py:20-28 -
+ * every batch of grid points repeated per view, query_mr + query_sr, view 0's predictions kept) for the slab [i0, i1) of the grid
+ * `mat` (rows 0..2 of create_grid's matrix, HOST float64): the voxels are generated in the gather for every view's calibration,
+ * 262 144 at a time; vol_* [(i1-i0)][ry][rz].  Same kernels and bits as surs_query_points_views on create_grid's points. */
+size_t surs_query_grid_views_workspace_bytes(int num_views);
+int surs_query_grid_views(int i0, int i1, int ry, int rz, const double *mat, int num_views, int projection, const float *calibs,
+                          float zmul, float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                          const void *mlp_blob, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr, void *stream);
 size_t surs_query_views_workspace_bytes(int max_points, int num_views);
 
 /* Dense grid sweep: voxel (i,j,k), i in [i0,i1), j in [0,ry), k in [0,rz) has world position

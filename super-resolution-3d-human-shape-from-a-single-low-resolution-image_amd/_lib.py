@@ -86,6 +86,8 @@ _SIGS = {
     "surs_query_points_views": (C.c_int, [_vp, _i, _i, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp,
                                           _vp, _vp]),
     "surs_query_views_workspace_bytes": (_sz, [_i, _i]),
+    "surs_query_grid_views": (C.c_int, [_i, _i, _i, _i, _vp, _i, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "surs_query_grid_views_workspace_bytes": (_sz, [_i]),
     "surs_query_grid": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "surs_query_grid_opt": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp,
                                       C.POINTER(GridOptions), _vp]),

@@ -854,20 +854,12 @@ extern "C" size_t surs_query_views_workspace_bytes(int max_points, int num_views
     return views_ws_bytes((long long)ceil_div(max_points, 256) * 256, num_views < 1 ? 1 : num_views);
 }
 
-extern "C" int surs_query_points_views(const float *points, int n, int num_views, int projection, const float *calibs,
-                                       float zmul, float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr,
-                                       int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,
-                                       float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr, void *stream) {
-    SURS_REQUIRE(n >= 0, "negative point count");
-    SURS_REQUIRE(num_views >= 1 && num_views <= 64, "num_views must be in [1, 64]");
-    SURS_REQUIRE(projection == 0 || projection == 1, "projection: 0 = orthogonal, 1 = perspective");
-    if (n == 0) return 0;
-    SURS_REQUIRE(points && calibs && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
-    SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
-    hipStream_t st = as_stream(stream);
+// The n points every srcs[v] (v < num_views) describes - the same samples seen by each view: explicit points repeated per view, or grid
+// voxels - through both classifiers with the view mean after layer 2; pred_* [num_views][n].
+static int run_points_views(hipStream_t st, const PointSource *srcs, int n, int num_views, const float *feat_lr, int hl, int wl,
+                            const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace, float *pred_hr, float *pred_lr,
+                            float *logit_hr, float *logit_lr) {
     const long long np = (long long)ceil_div(n, 256) * 256;
-    SURS_REQUIRE(workspace_bytes >= views_ws_bytes(np, num_views), "workspace too small: need %zu bytes",
-                 views_ws_bytes(np, num_views));
     const MlpBlobHeader h = blob_layout(SURS_BF16);
     const char *blob = (const char *)mlp_blob;
     const int V = num_views;
@@ -893,13 +885,7 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
     for (int v = 0; v < V; ++v) {
         float *Fv = F + (size_t)v * fstride;
         SURS_HIP_CHECK(hipMemsetAsync(Fv + (size_t)(C_G + 2) * np, 0, (size_t)(C0PAD - C_G - 2) * np * sizeof(float), st));
-        PointSource src;
-        memset(&src, 0, sizeof(src));
-        src.mode = 0;
-        src.pts = points + (size_t)v * 3 * n;
-        src.ld = n;
-        src.persp = projection;
-        fill_calib(src, calibs + 12 * v, zmul, zdiv);
+        const PointSource &src = srcs[v];
         unsigned short *Fsv = x3 ? Fs + (size_t)v * parts * fstride : (unsigned short *)nullptr;
         if (parts == 2)
             hipLaunchKernelGGL(gather_kernel<2>, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, st, src, (long long)n,
@@ -964,6 +950,80 @@ extern "C" int surs_query_points_views(const float *points, int n, int num_views
                                m == 0 ? logit_lr : logit_hr, m == 0 ? F + (size_t)(C_G + 1) * np : (float *)nullptr, fstride,
                                (m == 0 && x3) ? Fs : (unsigned short *)nullptr, fstride);
         SURS_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int surs_query_points_views(const float *points, int n, int num_views, int projection, const float *calibs,
+                                       float zmul, float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr,
+                                       int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,
+                                       float *pred_hr, float *pred_lr, float *logit_hr, float *logit_lr, void *stream) {
+    SURS_REQUIRE(n >= 0, "negative point count");
+    SURS_REQUIRE(num_views >= 1 && num_views <= 64, "num_views must be in [1, 64]");
+    SURS_REQUIRE(projection == 0 || projection == 1, "projection: 0 = orthogonal, 1 = perspective");
+    if (n == 0) return 0;
+    SURS_REQUIRE(points && calibs && feat_lr && feat_hr && mlp_blob && workspace && pred_hr && pred_lr, "null argument");
+    SURS_REQUIRE(hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
+    const long long np = (long long)ceil_div(n, 256) * 256;
+    SURS_REQUIRE(workspace_bytes >= views_ws_bytes(np, num_views), "workspace too small: need %zu bytes",
+                 views_ws_bytes(np, num_views));
+    std::vector<PointSource> srcs((size_t)num_views);
+    for (int v = 0; v < num_views; ++v) {
+        PointSource &src = srcs[v];
+        memset(&src, 0, sizeof(src));
+        src.mode = 0;
+        src.pts = points + (size_t)v * 3 * n;
+        src.ld = n;
+        src.persp = projection;
+        fill_calib(src, calibs + 12 * v, zmul, zdiv);
+    }
+    return run_points_views(as_stream(stream), srcs.data(), n, num_views, feat_lr, hl, wl, feat_hr, hh, wh, mlp_blob, workspace, pred_hr,
+                            pred_lr, logit_hr, logit_lr);
+}
+
+// The dense sweep of a multi-view / perspective model (eval_grid over eval_func, lib/sdf.py:32-52, lib/mesh_util.py:20-28: every batch
+// of grid points repeated per view, query_mr + query_sr, VIEW 0's predictions kept) as one call: the voxels of the slab [i0, i1) are
+// generated in the gather (create_grid's float64 arithmetic) for every view's calibration, VIEWS_GRID_BATCH at a time.
+static const int VIEWS_GRID_BATCH = 262144;
+
+extern "C" size_t surs_query_grid_views_workspace_bytes(int num_views) {
+    const int V = num_views < 1 ? 1 : num_views;
+    return views_ws_bytes(VIEWS_GRID_BATCH, V) + (size_t)2 * V * VIEWS_GRID_BATCH * sizeof(float);
+}
+
+extern "C" int surs_query_grid_views(int i0, int i1, int ry, int rz, const double *mat, int num_views, int projection, const float *calibs,
+                                     float zmul, float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,
+                                     const void *mlp_blob, void *workspace, size_t workspace_bytes, float *vol_hr, float *vol_lr,
+                                     void *stream) {
+    SURS_REQUIRE(mat && calibs && feat_lr && feat_hr && mlp_blob && workspace && vol_hr && vol_lr, "null argument");
+    SURS_REQUIRE(i1 >= i0 && ry > 0 && rz > 0 && hl > 0 && wl > 0 && hh > 0 && wh > 0, "bad sizes");
+    SURS_REQUIRE(num_views >= 1 && num_views <= 64, "num_views must be in [1, 64]");
+    SURS_REQUIRE(projection == 0 || projection == 1, "projection: 0 = orthogonal, 1 = perspective");
+    SURS_REQUIRE(workspace_bytes >= surs_query_grid_views_workspace_bytes(num_views), "workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int V = num_views;
+    float *ph = (float *)((char *)workspace + views_ws_bytes(VIEWS_GRID_BATCH, V)), *pl = ph + (size_t)V * VIEWS_GRID_BATCH;
+    const long long total = (long long)(i1 - i0) * ry * rz;
+    std::vector<PointSource> srcs((size_t)V);
+    for (long long b0 = 0; b0 < total; b0 += VIEWS_GRID_BATCH) {
+        const int nb = (int)((total - b0 < VIEWS_GRID_BATCH) ? total - b0 : VIEWS_GRID_BATCH);
+        for (int v = 0; v < V; ++v) {
+            PointSource &src = srcs[v];
+            memset(&src, 0, sizeof(src));
+            src.mode = 1;
+            src.base = (long long)i0 * ry * rz + b0;
+            src.ry = ry;
+            src.rz = rz;
+            src.persp = projection;
+            for (int i = 0; i < 12; ++i) src.mat[i] = mat[i];
+            fill_calib(src, calibs + 12 * v, zmul, zdiv);
+        }
+        const int rc = run_points_views(st, srcs.data(), nb, V, feat_lr, hl, wl, feat_hr, hh, wh, mlp_blob, workspace, ph, pl, nullptr,
+                                        nullptr);
+        if (rc) return rc;
+        // view 0's row of the [V][nb] predictions
+        SURS_HIP_CHECK(hipMemcpyAsync(vol_hr + b0, ph, (size_t)nb * sizeof(float), hipMemcpyDeviceToDevice, st));
+        SURS_HIP_CHECK(hipMemcpyAsync(vol_lr + b0, pl, (size_t)nb * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     return 0;
 }

@@ -45,14 +45,25 @@ def eval_volumes(opt, net, calib_tensor, resolution, b_min, b_max, transform=Non
     return vh, vl, mat
 
 
-def eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, num_samples=1 << 18):
+def eval_volumes_views(opt, net, calib_tensor, resolution, b_min, b_max, transform=None, num_samples=1 << 18, loop=False):
     """Dense sweep for num_views > 1 or the perspective projection: eval_grid's batch loop (lib/sdf.py:32-52) over
     eval_func (lib/mesh_util.py:20-28) - every batch of grid points repeated per view, query_mr + query_sr, view 0's
-    prediction kept (`net.get_preds()[0][0]`).  Grid coordinates in float64, cast to float32, like create_grid."""
+    prediction kept (`net.get_preds()[0][0]`).  Grid coordinates in float64, cast to float32, like create_grid.
+    One library call (surs_query_grid_views: the voxels generated in the gather, the feature maps laid out once); loop=True - and the
+    retry on three bf16 parts after an f16 overflow - walks the batches through the facade as the reference does (same kernels, same bits:
+    tests/test_gpu_model.py)."""
     _, mat = create_grid(resolution, resolution, resolution, b_min, b_max, transform=transform)
     dev = net._device()
     R = int(resolution)
     total = R * R * R
+    if not loop and not native.wide_operands_active() and net.im_feat_list_lr and net.im_feat_list_hr \
+            and net.im_feat_list_lr[-1].shape[0] == net.num_views == net.im_feat_list_hr[0].shape[0] == calib_tensor.shape[0]:
+        fl = net.im_feat_list_lr[-1].to(dev).permute(0, 2, 3, 1).contiguous()
+        fh = net.im_feat_list_hr[0].to(dev).permute(0, 2, 3, 1).contiguous()
+        zmul, zdiv = net._zscale()
+        vh, vl = native.query_grid_views(0, R, R, R, mat[:3].reshape(-1), net._calib_rows(calib_tensor, None), net.projection_mode, zmul,
+                                         zdiv, fl, fh, net._mlp_blob(), net._workspace())
+        return vh, vl, mat
     M = torch.from_numpy(np.asarray(mat, np.float64)).to(dev)
     vh = torch.empty(total, dtype=torch.float32, device=dev)
     vl = torch.empty_like(vh)

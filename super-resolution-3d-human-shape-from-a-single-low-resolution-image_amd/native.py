@@ -538,6 +538,27 @@ def query_points_views(points, calibs, projection, zmul, zdiv, feat_lr, feat_hr,
     return (phr, plr, lg[0], lg[1]) if want_logits else (phr, plr)
 
 
+def query_grid_views(i0, i1, ry, rz, mat, calibs, projection, zmul, zdiv, feat_lr, feat_hr, blob, ws, vol_hr=None, vol_lr=None):
+    """surs_query_grid_views: the dense sweep of a multi-view / perspective model over the grid slab [i0, i1) - every voxel seen by
+    every view, view 0's predictions kept (lib/mesh_util.py:20-28).  calibs [V,12] (host); feat_lr [V,hl,wl,256], feat_hr [V,hh,wh,64]
+    contiguous NHWC device tensors.  Returns (vol_hr, vol_lr) [(i1-i0), ry, rz]."""
+    feat_lr, feat_hr = _f32c(feat_lr), _f32c(feat_hr)
+    V = feat_lr.shape[0]
+    dev = blob.device
+    assert feat_hr.shape[0] == V and feat_lr.shape[3] == 256 and feat_hr.shape[3] == 64
+    if vol_hr is None:
+        vol_hr = torch.empty((i1 - i0, ry, rz), dtype=torch.float32, device=dev)
+        vol_lr = torch.empty_like(vol_hr)
+    m = (C.c_double * 12)(*[float(v) for v in np.asarray(mat, np.float64).reshape(-1)[:12]])
+    cal = np.ascontiguousarray(np.asarray(calibs, np.float32).reshape(V, -1)[:, :12])
+    cbuf = (C.c_float * (12 * V))(*[float(v) for v in cal.reshape(-1)])
+    w = ws.get(lib().surs_query_grid_views_workspace_bytes(V))
+    check(lib().surs_query_grid_views(i0, i1, ry, rz, m, V, {"orthogonal": 0, "perspective": 1}[projection], cbuf, float(zmul),
+                                      float(zdiv), _ptr(feat_lr), feat_lr.shape[1], feat_lr.shape[2], _ptr(feat_hr), feat_hr.shape[1],
+                                      feat_hr.shape[2], _ptr(blob), _ptr(w), w.numel(), _ptr(vol_hr), _ptr(vol_lr), _stream()))
+    return vol_hr, vol_lr
+
+
 def query_grid(i0, i1, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtype, ws, vol_hr=None, vol_lr=None, kernel=0,
                operand_parts=0):
     """Dense sweep of grid slab [i0, i1): returns (vol_hr, vol_lr) float32 device tensors [(i1-i0), ry, rz].

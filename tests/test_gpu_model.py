@@ -422,6 +422,20 @@ def test_multiview_facade_and_reconstruction(golden_dir):
     vh, vl, _ = mesh_util.eval_volumes_views(opt, net, calibs, R, b_min, b_max)
     assert np.abs(vh.cpu().numpy().reshape(-1) - o_hr[0]).max() < 1e-4
     assert np.abs(vl.cpu().numpy().reshape(-1) - o_lr[0]).max() < 1e-4
+    # the sweep as ONE library call (surs_query_grid_views: voxels generated in the gather) = the reference's batch loop through the
+    # facade, bit for bit - also where the grid is not a multiple of the library's batch of 262 144 voxels (R = 70: 343 000)
+    for Rv in (R, 70):
+        a = mesh_util.eval_volumes_views(opt, net, calibs, Rv, b_min, b_max)
+        b = mesh_util.eval_volumes_views(opt, net, calibs, Rv, b_min, b_max, loop=True, num_samples=50000)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    pnet = model.SuRSNet(opt, "perspective").to(device=torch.device("cuda:0"))
+    pnet.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    pnet.eval()
+    pnet.im_feat_list_lr, pnet.im_feat_list_hr = net.im_feat_list_lr, net.im_feat_list_hr
+    pcal = torch.from_numpy(g["p3_calibs"][:V].copy())      # (two of the three perspective calibrations of the golden file)
+    a = mesh_util.eval_volumes_views(opt, pnet, pcal, 24, b_min, b_max)
+    b = mesh_util.eval_volumes_views(opt, pnet, pcal, 24, b_min, b_max, loop=True, num_samples=5000)
+    assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and float(a[0].max()) > 0
     mat = oracle.coords_matrix(R, b_min, b_max)
     for field, (v_got, f_got) in ((vh, (out[0], out[1])), (vl, (out[4], out[5]))):
         v, f, _, _ = oracle.marching_cubes_lewiner(field.cpu().numpy().astype(np.float64), 0.5)
