@@ -1326,22 +1326,29 @@ static int device_cus() {
     return 256;
 }
 
-// A second stream of the library's own per (device, host thread) with the two events of a fork / join: run_column_batch's small batches.
+// A second stream for run_column_batch's small batches, GIVEN by the caller (surs_set_side_stream, per host thread), with the two
+// events of a fork / join.  The library creates no stream of its own: HIP maps streams onto a handful of hardware queues in creation
+// order, and one more stream in a process shifts the queues of every stream created after it (NOTES R4.4: a copy stream that lands
+// on the sweep's queue costs a reconstruction 19 ms).
 namespace {
 struct SideLane {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
 }  // namespace
+static thread_local SideLane t_lane;
+
+extern "C" int surs_set_side_stream(void *stream) {
+    t_lane.s = as_stream(stream);
+    return 0;
+}
+
 static SideLane *side_lane() {
-    static thread_local std::map<int, SideLane> lanes;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    SideLane &l = lanes[dev];
-    if (!l.s) {
-        if (hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) != hipSuccess) { l.s = nullptr; return nullptr; }
+    SideLane &l = t_lane;
+    if (!l.s) return nullptr;
+    if (!l.fork) {
         if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) { l.s = nullptr; return nullptr; }
+            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) { l.fork = l.join = nullptr; return nullptr; }
     }
     return &l;
 }
@@ -1422,7 +1429,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
                                g_lr, part_lr, g_hr, part_hr);
         SURS_LAUNCH_CHECK();
         // small batches (the ~ 100 columns of a point-runs call: 4 - 6 workgroups per GEMM walking K = 1024, a latency chain of 33 - 62 us
-        // each): the two classifiers' GEMMs side by side, the hr one on a stream of the library's own
+        // each): the two classifiers' GEMMs side by side, the hr one on the caller's side stream if it gave one (surs_set_side_stream)
         SideLane *lane2 = ncp <= 1024 ? side_lane() : nullptr;
         if (lane2) {
             SURS_HIP_CHECK(hipEventRecord(lane2->fork, st));

@@ -468,6 +468,11 @@ def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtyp
     w = ws.get(lib().surs_query_points_columns_workspace_bytes())
     assert feat_lr.ld == feat_lr.c == 256 and feat_hr.ld == feat_hr.c == 64
     ncols = C.c_int(0)
+    # (an existing side stream for the two classifiers' per-run GEMMs: the hourglass's - idle outside the encoder.  Never a new one: a
+    #  stream more in the process shifts the hardware queues of the copy / marching-cubes streams created after it, NOTES R4.4)
+    from . import encoder
+    side = encoder.existing_side_stream()
+    check(lib().surs_set_side_stream(C.c_void_p(side.cuda_stream) if side is not None else None))
     for p0 in range(0, n, POINT_RUNS_CHUNK):
         nb = min(POINT_RUNS_CHUNK, n - p0)
         check(lib().surs_query_points_columns(C.c_void_p(points.data_ptr() + 4 * p0), n, nb, cal, float(zmul), float(zdiv),
