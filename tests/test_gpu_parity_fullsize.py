@@ -174,3 +174,52 @@ def test_configs0_dense_r128_h512_vs_reference(golden_dir):
         b = torch.from_numpy(((np.asarray(vv) + 0.5) * Rr).astype(np.float32)).to(dev)
         d = pr.nearest_vertex_distance(a, b, Rr)
         assert bool(torch.isfinite(d).all()) and float(d.max()) < 0.02, (k, float(d.max()))
+
+
+def test_configs0_through_the_reference_loop_vs_reference(golden_dir):
+    """BASELINE configs[0] the way the REFERENCE drives it: lib/sdf.py:32-45's batch loop over lib/mesh_util.py:20-28's eval_func -
+    50 000 grid points per call, numpy in, query_mr + query_sr + get_preds, numpy out - around the facade, the whole 128^3 grid
+    (42 calls; every call is taken through the column kernels as point runs, the last one is ragged).  Both fields against the
+    reference's own run of the same loop (tests/golden/recon_r128_h512.npz): 1e-4; and against the product's sweep."""
+    from surs_amd import mesh_util, model, native, sdf, weights
+    g = np.load(os.path.join(golden_dir, "recon_r128_h512.npz"))
+    dev = torch.device("cuda:0")
+    opt = common.opt()
+    net = model.SuRSNet(opt).to(device=dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    _, f_lr, f_hr = net.super_res(torch.from_numpy(weights.synthetic_image(512, seed=1)).to(dev))
+    net.filter_hr(f_hr)
+    net.filter_lr(f_lr)
+    calib = torch.from_numpy(common.CALIB[None]).to(dev)
+    b_min, b_max = np.array([-0.5] * 3), np.array([0.5] * 3)
+    R, ns = 128, 50000
+    _, mat = sdf.create_grid(R, R, R, b_min, b_max)
+    ijk = np.mgrid[:R, :R, :R].reshape(3, -1).astype(np.float64)       # lib/sdf.py:20-26: the coordinate array in float64
+    pts = np.matmul(mat[:3, :3], ijk) + mat[:3, 3:4]
+    taken = []
+    real = native.query_points_columns
+
+    def spy(*a, **k):
+        r = real(*a, **k)
+        taken.append(r is not None)
+        return r
+    native.query_points_columns = spy
+    try:
+        hr, lr = np.zeros(pts.shape[1]), np.zeros(pts.shape[1])
+        for i in range(0, pts.shape[1], ns):
+            p = np.repeat(np.expand_dims(pts[:, i:i + ns], 0), net.num_views, axis=0)          # eval_func
+            samples = torch.from_numpy(p).to(device=dev).float()
+            net.query_mr(samples, calib)
+            net.query_sr(samples, calib)
+            hr[i:i + ns] = net.get_preds()[0][0].detach().cpu().numpy()
+            lr[i:i + ns] = net.get_preds()[1][0].detach().cpu().numpy()
+    finally:
+        native.query_points_columns = real
+    assert len(taken) == -(-pts.shape[1] // ns) and all(taken)          # every chunk went through the column kernels
+    hr, lr = hr.reshape(R, R, R), lr.reshape(R, R, R)
+    e_hr, e_lr = float(np.abs(hr - g["sdf_hr"]).max()), float(np.abs(lr[::2, ::2, ::2] - g["sdf_lr_sub"]).max())
+    print("configs[0] through the reference's loop: max |d occupancy| hr %.2e lr %.2e" % (e_hr, e_lr))
+    assert e_hr < 1e-4 and e_lr < 1e-4
+    vh, vl, _ = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max)
+    assert float(np.abs(hr - vh.cpu().numpy()).max()) < 2e-5 and float(np.abs(lr - vl.cpu().numpy()).max()) < 2e-5
