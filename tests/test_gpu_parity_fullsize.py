@@ -223,3 +223,56 @@ def test_configs0_through_the_reference_loop_vs_reference(golden_dir):
     assert e_hr < 1e-4 and e_lr < 1e-4
     vh, vl, _ = mesh_util.eval_volumes(opt, net, calib, R, b_min, b_max)
     assert float(np.abs(hr - vh.cpu().numpy()).max()) < 2e-5 and float(np.abs(lr - vl.cpu().numpy()).max()) < 2e-5
+
+
+def test_whole_512_grid_through_the_reference_loop_equals_the_sweep():
+    """BASELINE's full grid the reference's way: all 134 217 728 voxels of a 512^3 grid in 2 685 calls of 50 000 points through
+    query_mr / query_sr / get_preds (lib/sdf.py:32-45 over lib/mesh_util.py:20-28), full-size PRNG feature maps, fp32.  Every call
+    must be taken through the column kernels (point runs), and the assembled volumes must equal the product's own fp32 sweep of
+    the same grid to 2e-5 (same kernel v11; the depth at which a column's branches are taken differs, so the last bits do)."""
+    import gpu_common as gc
+    from surs_amd import model, native, sdf
+    from surs_amd.model import _as_nchw_view
+    dev = torch.device("cuda:0")
+    opt = common.opt()
+    net = model.SuRSNet(opt).to(device=dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in common.state_dict().items()})
+    net.eval()
+    fl, fh = common.synth_features(seed=7, hl=256, hh=1024)
+    Fl, Fh = gc.upload_nhwc(fl), gc.upload_nhwc(fh)
+    del fl, fh
+    net.im_feat_list_lr, net.im_feat_list_hr = [_as_nchw_view(Fl)], [_as_nchw_view(Fh)]
+    calib = torch.from_numpy(common.CALIB[None]).to(dev)
+    R, ns = 512, 50000
+    _, mat = sdf.create_grid(R, R, R, np.array([-0.5] * 3), np.array([0.5] * 3))
+    vh = torch.empty(R * R * R, dtype=torch.float32, device=dev)
+    vl = torch.empty_like(vh)
+    taken = [0, 0]
+    real = native.query_points_columns
+
+    def spy(*a, **k):
+        r = real(*a, **k)
+        taken[0 if r is not None else 1] += 1
+        return r
+    native.query_points_columns = spy
+    try:
+        plane = R * R
+        for s0 in range(0, R ** 3, ns):                               # the reference's chunks; their coordinates in float64
+            s1 = min(s0 + ns, R ** 3)
+            idx = np.arange(s0, s1, dtype=np.int64)
+            ijk = np.stack([idx // plane, (idx // R) % R, idx % R]).astype(np.float64)
+            pts = np.matmul(mat[:3, :3], ijk) + mat[:3, 3:4]
+            samples = torch.from_numpy(pts[None]).to(device=dev).float()
+            net.query_mr(samples, calib)
+            net.query_sr(samples, calib)
+            vh[s0:s1] = net.get_preds()[0][0, 0]
+            vl[s0:s1] = net.get_preds()[1][0, 0]
+    finally:
+        native.query_points_columns = real
+    print("512^3 through the reference's loop: %d calls on the column kernels, %d on the layer kernels" % tuple(taken))
+    assert taken[1] == 0 and taken[0] >= R ** 3 // ns
+    ws = native.Workspace(dev)
+    sh, sl = native.query_grid(0, R, R, R, mat[:3].reshape(-1), common.CALIB.reshape(-1)[:12], 512, 200.0, Fl, Fh, net._mlp_blob(), "fp32", ws)
+    dh, dl = float((sh.reshape(-1) - vh).abs().max()), float((sl.reshape(-1) - vl).abs().max())
+    print("   max |d occupancy| against the sweep: hr %.2e lr %.2e" % (dh, dl))
+    assert dh < 2e-5 and dl < 2e-5
