@@ -395,7 +395,10 @@ def main():
                 extras[key] = {"what": "the reference's eval_grid loop (50 000-point chunks, host numpy in / out, lib/sdf.py:32-45) "
                                        "around SuRSNet.query_mr / query_sr / get_preds, " + what,
                                "points": int(pts_all.shape[1] // ns * ns), "seconds": tl, "value": pts_all.shape[1] // ns * ns / tl,
-                               "unit": "queries/s", "ms_per_50k_chunk": tl / (pts_all.shape[1] // ns) * 1e3}
+                               "unit": "queries/s", "ms_per_50k_chunk": tl / (pts_all.shape[1] // ns) * 1e3,
+                               # (the reference's own sweep of a 512^3 grid is 2 685 such calls: north_star's "< 2 s" through the
+                               #  UNCHANGED loop; tests/test_gpu_parity_fullsize.py runs all of them against the product's sweep)
+                               "seconds_per_512_grid_at_this_rate": tl / (pts_all.shape[1] // ns) * -(-R ** 3 // ns)}
                 if key == "reference_loop":
                     ref_hr = out_hr.copy()
                 else:
