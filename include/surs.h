@@ -221,11 +221,11 @@ int surs_query_points_hr(const float *points, int n, const float *calib, float z
  *   points [3][n] with row pitch ld >= n (a piece of a longer array), n <= 262 144; dtype = the blob's use: SURS_F32 (kernel v11,
  *   fp32-grade: logits within 1e-4 of surs_query_points'), SURS_BF16 / SURS_F16 (kernel v10: surs_query_grid's arithmetic);
  *   *columns = the number of runs evaluated, or 0 - NOTHING WAS WRITTEN, call surs_query_points - when the array holds fewer than
- *   2048 points or more than one run per 32 points, z is not monotonic inside the runs, or the calibration lets the image position
+ *   2048 points or more than one run per 16 (SURS_F32) / 32 (SURS_BF16, SURS_F16) points - the layer kernels are the faster evaluator there -, z is not monotonic inside the runs, or the calibration lets the image position
  *   depend on z (calib[2], calib[6]) or the depth on x, y (calib[8], calib[9]).  Synchronises the stream once (the run count). */
 /* Its run finder alone (tests, diagnostics): colstart[c] / kcount[c] = first point and length of run c (ints, room for n each), tiles =
  * (run, z tile) pairs of `tile` = 64 | 128 points (room for 2 n ints), meta[4] = {runs, work items - 0 and no lengths / work items when the
- * array holds more than one run per 32 points -, z ascending violated, z descending violated}.  Device pointers; no synchronisation. */
+ * array holds more than one run per tile / 4 points -, z ascending violated, z descending violated}.  Device pointers; no synchronisation. */
 int surs_point_runs(const float *points, long long ld, int n, int tile, int *colstart, int *kcount, int *tiles, int *meta, void *stream);
 /* A second stream the calling host thread lends the library (NULL: none): surs_query_points_columns then runs the two classifiers'
  * per-run GEMMs side by side (forked from and joined to the call's stream by events) instead of one behind the other - 25 us of a

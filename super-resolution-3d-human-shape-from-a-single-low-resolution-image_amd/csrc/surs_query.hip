@@ -1970,11 +1970,16 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
 // affine part + the listed channels' residuals.  Nothing about a grid is assumed: the runs are found in the data (maximal sequences
 // of points with bit-equal x and y, cut at PR_CAP points, z monotonic inside every run - the kernels take a tile's z range from its
 // ends), every point's own z is read from the caller's array, results go straight to the caller's prediction arrays.  Arrays
-// without such runs (random samples: fewer than 32 points per run on average) are refused (*columns = 0, nothing written) and
+// without such runs (random samples: fewer than a quarter tile of points per run on average) are refused (*columns = 0, nothing written) and
 // the caller takes surs_query_points.
 // ------------------------------------------------------------------------------------------------
 static const int PR_CHUNK = 262144;   // points per call
 static const int PR_CAP = 4096;       // points per column: a longer run is cut into several (one more gather row each)
+// Average points per run below which the layer kernels are the faster evaluator: a quarter of the column kernel's tile - 16 for v11
+// (64 slots), 32 for v10 (128).  Measured on 50 000 points as runs of 8 - 24 / 12 - 36 / 16 - 48 / 24 - 72 points (the dirty lattice points
+// of the reference's octree levels come as ~ 25 per column; tools/dev/short_runs_time.py), column kernels against layer kernels:
+// fp32-grade 0.87 / 0.70 / 0.63 / 0.55 against 0.94 ms, bf16 0.81 / 0.64 / 0.51 / 0.41 against 0.55 ms.
+static inline __host__ __device__ int pr_min_run(int tile) { return tile / 4; }
 static const int PR_THREADS = 1024;
 
 __device__ __forceinline__ int pr_wave_scan_sum(int v, int lane) {   // inclusive, 64 lanes
@@ -1999,7 +2004,7 @@ __device__ __forceinline__ int pr_wave_scan_max(int v, int lane) {
 // through 16 LDS words twice per block (the last natural head, then the number of heads), what crosses the blocks is carried in
 // registers.  colstart[c] / kcount[c]: first point and length of column c; tiles[2 j], tiles[2 j + 1]: column and z tile (of `tile`
 // points) of work item j; meta = {columns, tiles, ascending violated, descending violated}.  An array with more than one column
-// per 32 points is not worth the column kernels: lengths and work items are skipped.
+// per quarter tile of points is not worth the column kernels: lengths and work items are skipped.
 __global__ __launch_bounds__(PR_THREADS) void point_runs_kernel(const float *__restrict__ px, const float *__restrict__ py,
                                                                 const float *__restrict__ pz, int n, int tile,
                                                                 int *__restrict__ colstart, int *__restrict__ kcount,
@@ -2099,7 +2104,7 @@ __global__ __launch_bounds__(PR_THREADS) void point_runs_kernel(const float *__r
     __threadfence_block();
     __syncthreads();   // colstart (global) and viol visible to the workgroup
     int ntiles = 0;
-    if ((long long)ncols * 32 <= n) {
+    if ((long long)ncols * pr_min_run(tile) <= n) {
         int carry_t = 0;
         for (int c0 = 0; c0 < ncols; c0 += PR_THREADS) {
             const int c = c0 + tid;
@@ -2141,7 +2146,7 @@ __global__ __launch_bounds__(PR_THREADS) void point_runs_kernel(const float *__r
 static size_t point_runs_list_bytes() { return align_up((size_t)PR_CHUNK * 4 * sizeof(int) + 256, 256); }
 
 // The run finder alone (tests, diagnostics): colstart / kcount [n] ints, tiles [2 n] ints, meta [4] ints = {columns, work items (0 when
-// the array holds more than one column per 32 points: lengths and work items are then not written), ascending violated, descending
+// the array holds more than one column per tile / 4 points: lengths and work items are then not written), ascending violated, descending
 // violated}; tile = 64 | 128 points per work item.  All device pointers; no synchronisation.
 extern "C" int surs_point_runs(const float *points, long long ld, int n, int tile, int *colstart, int *kcount, int *tiles, int *meta,
                                void *stream) {
@@ -2185,7 +2190,7 @@ extern "C" int surs_query_points_columns(const float *points, long long ld, int 
     SURS_HIP_CHECK(hipMemcpyAsync(host, meta, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     SURS_HIP_CHECK(hipStreamSynchronize(st));
     const long long ncols = host[0];
-    if (ncols <= 0 || ncols * 32 > n || ncols > COL_BATCH || (host[2] && host[3])) return 0;
+    if (ncols <= 0 || ncols * pr_min_run(tile) > n || ncols > COL_BATCH || (host[2] && host[3])) return 0;
     ColumnSweep cs;
     cs.st = st;
     cs.blob = (const char *)mlp_blob;

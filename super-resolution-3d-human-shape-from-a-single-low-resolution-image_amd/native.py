@@ -491,7 +491,7 @@ def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtyp
 
 def point_runs(points, tile=64):
     """surs_point_runs: the runs surs_query_points_columns would evaluate in points [3,N] (N <= POINT_RUNS_CHUNK) - numpy arrays
-    (colstart, kcount, tiles [ntiles, 2], meta [4]); kcount / tiles are empty when the array holds more than one run per 32 points."""
+    (colstart, kcount, tiles [ntiles, 2], meta [4]); kcount / tiles are empty when the array holds more than one run per tile / 4 points."""
     points = _f32c(points)
     n = points.shape[1]
     dev = points.device
@@ -500,7 +500,7 @@ def point_runs(points, tile=64):
     check(lib().surs_point_runs(_ptr(points), n, n, int(tile), _ptr(cs), _ptr(kc), _ptr(tl), _ptr(meta), _stream()))
     m = meta.cpu().numpy()
     nc, nt = int(m[0]), int(m[1])
-    listed = nc * 32 <= n
+    listed = nc * (int(tile) // 4) <= n
     return (cs[:nc].cpu().numpy(), kc[:nc].cpu().numpy() if listed else np.zeros(0, np.int32),
             tl[:2 * nt].cpu().numpy().reshape(-1, 2) if listed else np.zeros((0, 2), np.int32), m)
 

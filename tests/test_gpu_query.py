@@ -534,7 +534,7 @@ def test_point_runs_refused_where_there_are_none(setup):
     cal = np.array(common.CALIB, np.float32).copy()
     cal[0, 2] = 0.05
     assert _qc(setup, pts, "fp32", calib=cal) is None
-    short = _run_points(seed=9, ncols=3000, lo=8, hi=24)                                 # ~ 16 points per run
+    short = _run_points(seed=9, ncols=6000, lo=4, hi=12)                                 # ~ 8 points per run
     assert _qc(setup, short, "fp32") is None
 
 
@@ -549,7 +549,7 @@ def test_point_runs_kernel_equals_its_restatement(setup):
         ocs, okc, otl, oviol = oracle.point_runs(pts, tile)
         assert meta[0] == len(ocs) and np.array_equal(cs, ocs)
         assert (bool(meta[2]), bool(meta[3])) == oviol
-        if len(ocs) * 32 <= pts.shape[1]:
+        if len(ocs) * (tile // 4) <= pts.shape[1]:
             assert np.array_equal(kc, okc) and meta[1] == len(otl)
             assert np.array_equal(tl[np.lexsort((tl[:, 1], tl[:, 0]))], otl)
         else:
