@@ -294,9 +294,10 @@ class SuRSNet:
                 # points that come as runs of equal (x, y) - the reference's sweep loop: consecutive grid points, z fastest - are
                 # columns: the restated column kernels take them (same arithmetic as reconstruction()'s sweep in this precision)
                 # (callers whose arrays hold no runs - random samples - pay the run finder and its host round trip, ~ 0.1 ms, for
-                #  nothing: after two refusals in a row only every 16th call asks again)
+                #  nothing: after four refusals in a row only every 8th call asks again - the reference's octree loop mixes chunks
+                #  with longer and shorter runs, so the question is not dropped for long)
                 first = None
-                if p_lr is None and (self._runs_refused < 2 or self._runs_refused % 16 == 0):
+                if p_lr is None and (self._runs_refused < 4 or self._runs_refused % 8 == 0):
                     first = native.query_points_columns(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(), self.precision,
                                                         self._workspace())
                 if p_lr is None:
