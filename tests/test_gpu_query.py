@@ -514,6 +514,11 @@ def test_point_runs_grid_chunk_equals_the_sweep(setup):
     piece = np.ascontiguousarray(pts[:, a:a + 50000])
     phr, plr = [o.cpu().numpy() for o in _qc(setup, piece, "fp32")]
     assert np.abs(phr - vh.reshape(-1)[a:a + 50000]).max() < 2e-5 and np.abs(plr - vl.reshape(-1)[a:a + 50000]).max() < 2e-5
+    # more points than one library call takes (262 144): the host walks the array in pieces, a run cut at a piece's end is two runs
+    big = np.ascontiguousarray(pts[:, 5 * R * R + 7:5 * R * R + 7 + 300000])
+    bhr, blr = [o.cpu().numpy() for o in _qc(setup, big, "fp32")]
+    assert np.abs(bhr - vh.reshape(-1)[5 * R * R + 7:5 * R * R + 7 + 300000]).max() < 2e-5
+    assert np.abs(blr - vl.reshape(-1)[5 * R * R + 7:5 * R * R + 7 + 300000]).max() < 2e-5
     long_run = np.stack([np.full(10000, 0.123, np.float32), np.full(10000, -0.2, np.float32), np.linspace(-0.5, 0.5, 10000, dtype=np.float32)])
     got = _qc(setup, long_run, "fp32")
     assert got is not None
