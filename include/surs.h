@@ -312,6 +312,12 @@ int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigned char *dir
                               const float *calib, float zmul, float zdiv, const float *feat_lr, int hl, int wl,
                               const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace, size_t workspace_bytes,
                               long long *counts, void *stream);
+/* The same with the level's evaluator chosen: dtype SURS_F32 = the fp32-grade column kernel (what surs_octree_level_columns runs),
+ * SURS_BF16 / SURS_F16 = the 16-bit column kernel on the blob's cores - the octree sweep of `--precision bf16 | fp16`. */
+int surs_octree_level_columns_dt(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid, const double *mat,
+                                 const float *calib, float zmul, float zdiv, const float *feat_lr, int hl, int wl,
+                                 const float *feat_hr, int hh, int wh, const void *mlp_blob, int dtype, void *workspace,
+                                 size_t workspace_bytes, long long *counts, void *stream);
 size_t surs_octree_columns_workspace_bytes(int R);
 int surs_query_grid_indexed(const long long *idx, int n, int ry, int rz, const double *mat, const float *calib, float zmul,
                             float zdiv, const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh,

@@ -99,6 +99,8 @@ _SIGS = {
     "surs_octree_scatter": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "surs_octree_level_columns": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz,
                                             C.POINTER(C.c_longlong), _vp]),
+    "surs_octree_level_columns_dt": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz,
+                                               C.POINTER(C.c_longlong), _vp]),
     "surs_octree_columns_workspace_bytes": (_sz, [_i]),
     "surs_octree_workspace_bytes": (_sz, [_i, _i]),
     "surs_octree_cells": (C.c_int, [_vp, _vp, _vp, _i, _i, C.c_double, _vp, _sz, _vp]),

@@ -1889,10 +1889,27 @@ extern "C" size_t surs_octree_columns_workspace_bytes(int R) {
     return col_ws_bytes(COL_BATCH) + lattice_list_bytes(R) + (size_t)COL_BATCH * R * (2 * sizeof(float) + sizeof(unsigned short)) + 512;
 }
 
+extern "C" int surs_octree_level_columns_dt(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid,
+                                            const double *mat, const float *calib, float zmul, float zdiv, const float *feat_lr, int hl,
+                                            int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, int dtype, void *workspace,
+                                            size_t workspace_bytes, long long *counts, void *stream);
+
 extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid,
                                          const double *mat, const float *calib, float zmul, float zdiv, const float *feat_lr, int hl,
                                          int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, void *workspace,
                                          size_t workspace_bytes, long long *counts, void *stream) {
+    return surs_octree_level_columns_dt(sdf_hr, sdf_lr, dirty, R, reso, kmid, mat, calib, zmul, zdiv, feat_lr, hl, wl, feat_hr, hh, wh,
+                                        mlp_blob, SURS_F32, workspace, workspace_bytes, counts, stream);
+}
+
+// ... with the arithmetic of the level's evaluator chosen: SURS_F32 = kernel v11 (fp32-grade: the default of surs_octree_level_columns);
+// SURS_BF16 / SURS_F16 = kernel v10 on the blob's 16-bit cores (tiles of 128 listed points) - the octree sweep of `--precision bf16 |
+// fp16`, whose dense sweep runs the same arithmetic.
+extern "C" int surs_octree_level_columns_dt(double *sdf_hr, double *sdf_lr, unsigned char *dirty, int R, int reso, int kmid,
+                                            const double *mat, const float *calib, float zmul, float zdiv, const float *feat_lr, int hl,
+                                            int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob, int dtype, void *workspace,
+                                            size_t workspace_bytes, long long *counts, void *stream) {
+    SURS_REQUIRE(dtype == SURS_F32 || dtype == SURS_BF16 || dtype == SURS_F16, "unknown dtype %d", dtype);
     SURS_REQUIRE(sdf_hr && sdf_lr && dirty && mat && calib && feat_lr && feat_hr && mlp_blob && workspace, "null argument");
     SURS_REQUIRE(R > 0 && reso > 0 && R <= 32768, "bad grid");
     const int nl = (R + reso - 1) / reso;
@@ -1926,10 +1943,10 @@ extern "C" int surs_octree_level_columns(double *sdf_hr, double *sdf_lr, unsigne
     ColumnSweep cs;
     cs.st = st;
     cs.blob = (const char *)mlp_blob;
-    cs.h = blob_layout((uint32_t)SURS_F32);
-    cs.dtype = SURS_F32;
-    cs.kver = SURS_DEFAULT_GRID_KERNEL;
-    cs.kver32 = 11;   // (the dense-layer-1 kernel v5 has no strided / masked form)
+    cs.h = blob_layout((uint32_t)dtype);
+    cs.dtype = dtype;
+    cs.kver = 10;     // (the eight-wave kernel: the streamed kernel v12 and its overflow hand-over have not been run on lattice lists)
+    cs.kver32 = 11;   // (the dense-layer-1 kernels v3 / v5 have no strided / masked form)
     cs.restated = true;
     cs.feat_lr = feat_lr; cs.hl = hl; cs.wl = wl;
     cs.feat_hr = feat_hr; cs.hh = hh; cs.wh = wh;

@@ -114,8 +114,19 @@ def eval_volumes_octree(opt, net, calib_tensor, resolution, b_min, b_max, transf
     calib = calib_tensor[0].detach().to("cpu", torch.float32).numpy().reshape(-1)[:12]
     fl, fh = features if features is not None else net.features()
     zmul, zdiv = net._zscale()
-    vh, vl = native.octree_volumes(resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, net._mlp_blob(), net._workspace(),
-                                   opt.threshold, init_resolution)
+    # The levels are fp32-grade whatever --precision says (default): a flat / not-flat decision of the walk flips where a cell's corner
+    # range is within the evaluator's error of --threshold, and a flipped block is interpolated instead of evaluated - with bf16's
+    # 7e-3 on the occupancies 5.6 % of the vertices of the body field's octree mesh move by more than half a voxel (most of an octree
+    # mesh is the walk's artefact surfaces; tests/test_gpu_octree.py).  --octree_precision sweep: the levels in --precision's arithmetic
+    # (the 16-bit column kernel; 0.066 against 0.085 s at 512^3 in bf16).
+    prec = getattr(opt, "precision", "fp32")
+    if str(getattr(opt, "octree_precision", "fp32")) != "sweep" or native.wide_operands_active():
+        prec = "fp32"
+    blob = net._mlp_blob()
+    if prec != "fp32" and native.DTYPES[prec] != net._core_dtype:
+        raise ValueError("network was packed for %s, reconstruction asked for %s: set opt.precision before loading" % (net.precision, prec))
+    vh, vl = native.octree_volumes(resolution, mat[:3].reshape(-1), calib, zmul, zdiv, fl, fh, blob, net._workspace(),
+                                   opt.threshold, init_resolution, dtype=prec)
     return vh, vl, mat
 
 

@@ -873,7 +873,7 @@ def transform_points(verts, mat):
 # ------------------------------------------------------------------ octree sweep (lib/sdf.py:55-120)
 
 def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, threshold, init_resolution=64, num_samples=None,
-                   evaluate=None, device=None, columns=None, stats=None):
+                   evaluate=None, device=None, columns=None, stats=None, dtype="fp32"):
     """eval_grid_octree on the device: float64 volumes (sdf_hr, sdf_lr) [R,R,R] like the reference's arrays.
     Host code only walks the levels; selection, evaluation (fp32-grade kernels), scatter and the cell pass are kernels.
     Single view, axis-aligned sweep (gen_mesh's): every level runs on the sweep's COLUMN kernel (surs_octree_level_columns: the
@@ -883,7 +883,8 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
     evaluate(idx int64 device tensor [n]) -> (pred_hr, pred_lr) float32 [n] replaces the single-view evaluator
     (mesh_util passes the multi-view / perspective query there).
     stats: a list that receives (reso, dirty lattice points evaluated, lattice columns, 64-point tiles) per level (None, None on
-    the per-point path)."""
+    the per-point path).  dtype: "fp32" (the fp32-grade column kernel v11) | "bf16" | "fp16" (the 16-bit column kernel v10 on a blob
+    packed for that precision - the octree sweep of `--precision bf16 | fp16`); the per-point fallbacks are fp32-grade in every case."""
     dev = device if device is not None else blob.device
     n3 = R * R * R
     sdf_hr = torch.zeros(n3, dtype=torch.float64, device=dev)
@@ -900,9 +901,10 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
         if use_cols:
             w = ws.get(lib().surs_octree_columns_workspace_bytes(R))
             counts = (C.c_longlong * 3)(0, 0, 0)
-            rc = lib().surs_octree_level_columns(_ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul),
-                                                 float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w,
-                                                 _ptr(blob), _ptr(w), w.numel(), counts, _stream())
+            rc = lib().surs_octree_level_columns_dt(_ptr(sdf_hr), _ptr(sdf_lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul),
+                                                    float(zdiv), feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h,
+                                                    feat_hr.w, _ptr(blob), DTYPES[dtype] if isinstance(dtype, str) else dtype, _ptr(w),
+                                                    w.numel(), counts, _stream())
             if rc == -3 and columns is None:
                 use_cols = False     # general calibration: the per-point kernels (nothing has been written yet)
                 continue
@@ -942,7 +944,7 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
     return sdf_hr.view(R, R, R), sdf_lr.view(R, R, R)
 
 
-def octree_level_values(R, reso, idx, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, columns=True):
+def octree_level_values(R, reso, idx, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, columns=True, dtype="fp32"):
     """What the octree sweep assigns to the lattice points `idx` (flat voxel indices, int64 device tensor, all on the lattice of
     stride reso) at level `reso`: (pred_hr, pred_lr) float32.  columns=True: the column kernel of surs_octree_level_columns, run on
     a walk state in which exactly `idx` is dirty (a point's last bits there depend on which points of its column share its tile:
@@ -971,9 +973,9 @@ def octree_level_values(R, reso, idx, mat, calib, zmul, zdiv, feat_lr, feat_hr, 
     dirty = torch.zeros(n3, dtype=torch.uint8, device=dev)
     dirty[idx] = 1
     w = ws.get(lib().surs_octree_columns_workspace_bytes(R))
-    check(lib().surs_octree_level_columns(_ptr(hr), _ptr(lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul), float(zdiv),
-                                          feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
-                                          _ptr(w), w.numel(), None, _stream()))
+    check(lib().surs_octree_level_columns_dt(_ptr(hr), _ptr(lr), _ptr(dirty), R, reso, R // 2, m, cal, float(zmul), float(zdiv),
+                                             feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
+                                             DTYPES[dtype] if isinstance(dtype, str) else dtype, _ptr(w), w.numel(), None, _stream()))
     return hr[idx].float(), lr[idx].float()
 
 

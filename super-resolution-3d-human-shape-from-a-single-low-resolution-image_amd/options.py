@@ -73,6 +73,8 @@ _NATIVE = [
     ("encoder_graph", str, "0"),     # 1 = the encoder of a single view replays a captured HIP graph (its outputs are the graph's buffers,
                                      # overwritten by the next call: encoder.py "HIP graphs"; measured 2 % SLOWER than the eager launches
                                      # at 512^2: opt-in) | 0 = eager launches, fresh tensors per call
+    ("octree_precision", str, "fp32"),   # fp32 = fp32-grade octree levels whatever --precision says (default) | sweep = the levels in
+                                         # --precision's arithmetic (16-bit column kernel: faster, moves the walk's artefact surfaces)
     ("no_octree", None, False),      # dense sweep (the parity target)
     ("synthetic", None, False),      # synthetic image + PRNG weights instead of dataroot / checkpoint
     ("pipeline", None, False),       # eval driver: subjects as a pipeline (train_util.gen_mesh_pipelined) instead of one by one

@@ -20,7 +20,7 @@ def main():
     R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
     dev = native.require_gpu()
-    opt = options.BaseOptions().parse(pr.FLAGS + ["--precision", prec])
+    opt = options.BaseOptions().parse(pr.FLAGS + ["--precision", prec] + (["--octree_precision", "sweep"] if os.environ.get("SURS_OCT_SWEEP") else []))
     net = model.SuRSNet(opt).to(device=dev)
     full = weights.synthetic_state_dict(opt, seed=0)
     full.update(weights.body_state_dict(opt))
