@@ -424,10 +424,26 @@ def main():
                     out = mesh_util.reconstruction(o32, nb, dev, calib, R, b_min, b_max, use_octree=use_oct, features=feats, want_normals=False)
                     torch.cuda.synchronize()
                     res[name] = {"seconds": time.perf_counter() - t0, "verts_hr": int(len(out[0])), "verts_lr": int(len(out[4]))}
+            if args.precision != "fp32":
+                # opt-in: the levels in the sweep's precision (--octree_precision sweep: the 16-bit column kernel on the lattice lists;
+                # bounded by tests/test_gpu_octree.py::test_octree_levels_in_reduced_precision) - the default keeps them fp32-grade
+                osw = options.BaseOptions().parse(flags + ["--precision", args.precision, "--octree_precision", "sweep"])
+                ns_ = model.SuRSNet(osw).to(device=dev)
+                ns_.load_state_dict(full)
+                ns_.eval()
+                for rep in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    out = mesh_util.reconstruction(osw, ns_, dev, calib, R, b_min, b_max, use_octree=True, features=feats, want_normals=False)
+                    torch.cuda.synchronize()
+                    res["octree_sweep_precision"] = {"precision": args.precision, "seconds": time.perf_counter() - t0,
+                                                     "verts_hr": int(len(out[0])), "verts_lr": int(len(out[4]))}
             extras["octree_mode"] = {"what": "mesh_util.reconstruction(use_octree=True) - gen_mesh's default, lib/sdf.py:55-120 - against the "
                                              "dense sweep, %d^3, fp32, smooth body field (weights.body_*); the octree's output differs from "
                                              "the dense one by construction (interpolated blocks, shared-dirty artefact)" % R,
                                      "octree": res["octree"], "dense": res["dense"]}
+            if "octree_sweep_precision" in res:
+                extras["octree_mode"]["octree_sweep_precision_opt_in"] = res["octree_sweep_precision"]
         except Exception as e:
             extras["octree_mode"] = {"error": repr(e)}
     if world == 1 and not args.no_extras and R == RES:
