@@ -46,6 +46,7 @@ PRODUCTS = {"bf16": 1, "fp16": 1, "fp32": 3}   # MFMA products per MAC (fp32: hi
 PEAK_MFMA = 2.5e15              # dense bf16 / f16, MI355X_MICROARCH.md
 RES = 512
 IMG = 512
+REF_LOOP_PASSES = 7   # timed passes of the reference-loop leg (40 chunks each): median reported, min / max beside it
 
 
 def main():
@@ -386,19 +387,25 @@ def main():
                                   ("reference_loop_reduced", net, "--precision %s (the same runs on the 16-bit column kernel v10)" % args.precision)):
                 if key == "reference_loop_reduced" and args.precision == "fp32":
                     continue
-                loop(nn)
+                loop(nn)                 # warm-up pass (kernel attributes, workspace, clocks)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                loop(nn)
-                torch.cuda.synchronize()
-                tl = time.perf_counter() - t0
+                passes = []
+                for _ in range(REF_LOOP_PASSES):
+                    t0 = time.perf_counter()
+                    loop(nn)
+                    torch.cuda.synchronize()
+                    passes.append(time.perf_counter() - t0)
+                nch = pts_all.shape[1] // ns
+                tl = float(np.median(passes))
                 extras[key] = {"what": "the reference's eval_grid loop (50 000-point chunks, host numpy in / out, lib/sdf.py:32-45) "
                                        "around SuRSNet.query_mr / query_sr / get_preds, " + what,
-                               "points": int(pts_all.shape[1] // ns * ns), "seconds": tl, "value": pts_all.shape[1] // ns * ns / tl,
-                               "unit": "queries/s", "ms_per_50k_chunk": tl / (pts_all.shape[1] // ns) * 1e3,
+                               "points": int(nch * ns), "passes": REF_LOOP_PASSES, "seconds": tl, "value": nch * ns / tl,
+                               "unit": "queries/s", "ms_per_50k_chunk": tl / nch * 1e3,
+                               "ms_per_50k_chunk_min_median_max": [min(passes) / nch * 1e3, tl / nch * 1e3, max(passes) / nch * 1e3],
+                               "ms_per_50k_chunk_passes": [t / nch * 1e3 for t in passes],
                                # (the reference's own sweep of a 512^3 grid is 2 685 such calls: north_star's "< 2 s" through the
                                #  UNCHANGED loop; tests/test_gpu_parity_fullsize.py runs all of them against the product's sweep)
-                               "seconds_per_512_grid_at_this_rate": tl / (pts_all.shape[1] // ns) * -(-R ** 3 // ns)}
+                               "seconds_per_512_grid_at_this_rate": tl / nch * -(-R ** 3 // ns)}
                 if key == "reference_loop":
                     ref_hr = out_hr.copy()
                 else:
@@ -508,11 +515,45 @@ def main():
         if replicas is not None:
             out["config"]["replicas"] = replicas
         out["config"].update(extras)
+        out["config"].update(flat_scalars(stage_ms, extras, args.precision))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, sd, R, b_min, b_max)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def flat_scalars(stage_ms, extras, precision):
+    """The figures a reader of the driver's parsed line needs, as FLAT scalars of config (nested objects do not survive there)."""
+    out = {}
+    if isinstance(stage_ms, dict):
+        out["encoder_ms"] = stage_ms.get("encoder")
+        out["sweep_ms"] = stage_ms.get("query")
+        out["tail_ms"] = stage_ms.get("mesh")
+    oc = extras.get("octree_mode") or {}
+    if "octree" in oc:
+        out["octree_s"] = oc["octree"]["seconds"]
+        out["octree_dense_s"] = oc["dense"]["seconds"]
+    for key, name in (("reference_loop", "ref_loop_fp32_ms"), ("reference_loop_reduced", "ref_loop_reduced_ms")):
+        rl = extras.get(key) or {}
+        if "ms_per_50k_chunk" in rl:
+            out[name] = rl["ms_per_50k_chunk"]
+            out[name + "_min"], _, out[name + "_max"] = rl["ms_per_50k_chunk_min_median_max"]
+            out[name.replace("_ms", "_s_per_512_grid")] = rl["seconds_per_512_grid_at_this_rate"]
+    fl = extras.get("dense_floor") or {}
+    if "ms_per_step" in fl:
+        out["dense_floor_ms_per_step"] = fl["ms_per_step"]
+    # counters are collected by rocprofv3 --pmc on the shipped library (tools/profile_round.sh), not in this run: the committed summary
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_summary.json")) as f:
+            pm = json.load(f)
+        k = pm["kernels"].get("fp32" if precision == "fp32" else "bf16") or {}
+        out["hbm_bytes_per_launch"] = k.get("hbm_bytes_per_launch")
+        out["scratch_bytes_per_lane"] = k.get("scratch_bytes_per_lane")
+        out["pmc_source"] = "profiles/pmc_summary.json (%s, lib %s)" % (pm.get("round"), str(pm.get("lib_sha256"))[:12])
+    except Exception:   # noqa: BLE001 - a missing summary must not cost the bench line
+        pass
+    return out
 
 
 def cpu_baseline(net, sd, R, b_min, b_max):

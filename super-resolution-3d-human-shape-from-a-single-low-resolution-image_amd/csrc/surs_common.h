@@ -37,6 +37,17 @@ inline int fail(int code, const char *fmt, ...) {
         if (!(cond)) return surs::fail(SURS_E_INVALID, __VA_ARGS__); \
     } while (0)
 
+// A value the compiler must materialise as it stands (an empty asm on the register): keeps hipcc from re-forming two instruction
+// shapes that were WRONG on MI355X - v_pk_fma_f32 .. op_sel:[0,1,0] (a lost product in a quarter wave with two workgroups per CU,
+// NOTES R5.1) and v_fma_mixlo_f16 folds of a product whose fp32 rounding the bit-for-bit tests rely on.  tests/test_isa_pins.py
+// disassembles the shipped code object and fails if either shape is back; -DSURS_ABL_NO_ISA_PINS builds the library without the
+// pins (only to show that the test then fails).
+#ifndef SURS_ABL_NO_ISA_PINS
+#define SURS_ISA_PIN(v) asm volatile("" : "+v"(v))
+#else
+#define SURS_ISA_PIN(v) do { } while (0)
+#endif
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -352,7 +352,8 @@ def encode_sharded(net, images, calib_tensor, resolution, b_min, b_max, transfor
     net._last_images = None          # (reencode_wide re-runs super_res on one device: not how these features came about)
     net._sr_out = net._lr_from = net._hr_from = None
     # what reconstruction_sharded's retry after an f16 overflow re-runs on every rank, under native.wide_operands()
-    net._sharded_encode = (images, calib_tensor, resolution, b_min, b_max, transform, group, net.im_feat_list_lr[-1].data_ptr())
+    # (the produced tensor itself, compared with `is`: an address can come back under another subject's features)
+    net._sharded_encode = (images, calib_tensor, resolution, b_min, b_max, transform, group, net.im_feat_list_lr[-1])
     return True
 
 
@@ -385,12 +386,14 @@ def reconstruction_sharded(opt, net, calib_tensor, resolution, b_min, b_max, tra
         with native.wide_operands():
             fl, fh = net.features()
             bad = not (bool(torch.isfinite(fl.buf).all()) and bool(torch.isfinite(fh.buf).all()))
-            flags = all_gather_rows([1.0 if bad else 0.0], fl.buf.device, group)   # (the encoder is deterministic; agree anyway)
-            if flags.any():
-                # features of the sharded encoder are re-made by the sharded encoder (every rank is here: the flag is agreed);
-                # those of the replicated one by reencode_wide
-                se = getattr(net, "_sharded_encode", None)
-                if se is not None and net.im_feat_list_lr and net.im_feat_list_lr[-1].data_ptr() == se[7]:
+            # features of the sharded encoder are re-made by the sharded encoder - a collective: every rank must take that branch, so the
+            # branch travels with the flag and is taken only if EVERY rank holds a sharded encoder's features - those of the replicated
+            # one by reencode_wide
+            se = getattr(net, "_sharded_encode", None)
+            sharded = se is not None and bool(net.im_feat_list_lr) and net.im_feat_list_lr[-1] is se[7]
+            flags = all_gather_rows([1.0 if bad else 0.0, 1.0 if sharded else 0.0], fl.buf.device, group)
+            if flags[:, 0].any():
+                if flags[:, 1].all():
                     encode_sharded(net, *se[:7])
                 elif not net.reencode_wide():
                     raise
@@ -402,7 +405,8 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
                                 timing=None, group=None, wide=False, copy_out=True):
     """One reconstruction on all ranks of the group: each rank sweeps the x-slab slab_range(R, rank, world) and extracts its
     part of the two meshes.  Returns the 8-tuple of mesh_util.reconstruction on `dst` (normals / values None), None on the
-    other ranks.  Every rank raises the same ValueError / RuntimeError as marching_cubes_lewiner when the level is outside
+    other ranks.  want_normals=True: the slabs' VOLUMES are gathered on `dst`, which extracts with normals and values
+    (_reconstruction_sharded_with_normals).  Every rank raises the same ValueError / RuntimeError as marching_cubes_lewiner when the level is outside
     the whole volume's range / there is no surface."""
     from . import mesh_util, native
     from .sdf import create_grid
@@ -411,8 +415,6 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     if world == 1:
         return mesh_util.reconstruction(opt, net, net._device(), calib_tensor, R, b_min, b_max, use_octree=False,
                                         transform=transform, want_normals=want_normals)
-    if want_normals:
-        raise NotImplementedError("slab mode returns vertices and faces (what gen_mesh keeps); normals accumulate across slabs")
     if R < 2 * world:
         raise ValueError("resolution %d is too small for %d slabs (every rank needs at least two planes)" % (R, world))
     i0, i1 = slab_range(R, rank, world)
@@ -460,6 +462,15 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     if k < 0:
         raise kern_err or RuntimeError("the column-kernel probe failed on rank %d" % owner)
     kern = int(k)
+    if want_normals:
+        def sweep_slab():
+            try:
+                return native.query_grid(i0, i1, R, R, m12, calib, zmul, zdiv, fl, fh, blob, prec, ws, kernel=kern)
+            except native._lib.SursError as e:
+                if e.code != -3:
+                    raise
+                return native.query_grid(i0, i1, R, R, m12, calib, zmul, zdiv, fl, fh, blob, "fp32", ws)   # general calibration
+        return _reconstruction_sharded_with_normals(net, sweep_slab, mat, R, dst, group)
     try:
         # ---- the sweep, enqueued in one go; the halo exchange starts behind the first launch
         import os
@@ -557,6 +568,49 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
     else:
         host = ws.to_host(flat)
     return host[0], host[1], None, None, host[2], host[3], None, None
+
+
+def _reconstruction_sharded_with_normals(net, sweep_slab, mat, R, dst, group):
+    """want_normals=True in slab mode (mesh_util.reconstruction's full 8-tuple; gen_mesh itself never asks for it,
+    lib/train_util.py:72): a vertex normal accumulates over the faces of BOTH slabs at a boundary, so the volumes - not the
+    meshes - are exchanged: every rank sweeps its x-slab (sweep_slab() -> (vol_hr, vol_lr) of its planes), gather_slabs puts the
+    slabs in their place of one volume on `dst`, and `dst` extracts both meshes with normals and values from the whole volumes
+    exactly as one GPU does.  What dst raises (marching_cubes_lewiner's ValueError / RuntimeError, a non-finite volume) is raised
+    on every rank."""
+    from . import mesh_util, native
+    world, rank = _world(group)
+    dev = net._device()
+    i0, i1 = slab_range(R, rank, world)
+    status, failure = 0.0, None
+    try:
+        vols = list(sweep_slab())
+    except Exception as e:   # noqa: BLE001 - the others are waiting in the gather below
+        status, failure = 2.0, e
+        vols = [torch.zeros((i1 - i0, R, R), dtype=torch.float32, device=dev) for _ in range(2)]
+    full = [gather_slabs(v, R, dst, group) for v in vols]
+    out = None
+    if rank == dst and not status:
+        try:
+            out = mesh_util.meshes_from_volumes(net, full, mat, want_normals=True)
+        except native._lib.NonFiniteVolumeError as e:
+            status, failure = 1.0, e
+        except ValueError as e:
+            status, failure = 3.0, e
+        except RuntimeError as e:
+            status, failure = 4.0, e
+    codes = all_gather_rows([status], dev, group)[:, 0]
+    if codes.any():
+        if failure is not None:
+            raise failure
+        code = int(codes.max())
+        if code == 1:
+            raise native._lib.NonFiniteVolumeError("non-finite occupancies in the volume (reported by another rank)")
+        if code == 3:
+            raise ValueError("Surface level must be within volume data range.")
+        if code == 4:
+            raise RuntimeError("No surface found at the given iso value.")
+        raise RuntimeError("reconstruction_sharded (normals): a peer rank failed")
+    return out
 
 
 def _agree(ok, dev, group):

@@ -16,10 +16,14 @@ from . import native
 from .native import Img
 
 
+_weights_serial = iter(range(1, 1 << 62))
+
+
 class EncoderWeights:
     """Device-side packed weights of every conv / GroupNorm that is live at eval time."""
 
     def __init__(self, sd, opt, device):
+        self.serial = next(_weights_serial)   # the key of this object's captured graphs: never reused, unlike id()
         self.device = device
         self.conv = {}
         self.gn = {}
@@ -333,7 +337,7 @@ def graphs_enabled(W=None):
 
 def drop_graphs(W=None):
     """Forget the captured graphs (of the weights W; all of them without an argument) and free their buffers."""
-    for k in [k for k in _graphs if W is None or k[1] == id(W)]:
+    for k in [k for k in _graphs if W is None or k[1] == W.serial]:
         del _graphs[k]
     _stable.clear()
 
@@ -384,7 +388,7 @@ def super_res_g(W, x, want_image=True):
     """super_res through a captured graph where that is allowed (see above), eagerly otherwise."""
     if not _graph_ok(W):
         return super_res(W, x, want_image=want_image)
-    key = ("sr", id(W), x.h, x.w, x.c, want_image, _flags())
+    key = ("sr", W.serial, x.h, x.w, x.c, want_image, _flags())
     outs = _run_graphed(key, lambda xin: super_res(W, xin, want_image=want_image), static_in=True, x=x)
     _stable[_addr_key(outs[1])] = outs[1].buf
     return outs
@@ -393,7 +397,7 @@ def super_res_g(W, x, want_image=True):
 def super_res_strip_g(W, x, a, b, want_image=True):
     if not _graph_ok(W):
         return super_res_strip(W, x, a, b, want_image=want_image)
-    key = ("srs", id(W), x.h, x.w, x.c, a, b, want_image, _flags())
+    key = ("srs", W.serial, x.h, x.w, x.c, a, b, want_image, _flags())
     return _run_graphed(key, lambda xin: super_res_strip(W, xin, a, b, want_image=want_image), static_in=True, x=x)
 
 
@@ -411,7 +415,7 @@ def filter_lr_g(W, feature_lr, keep_all=False):
     caller's persistent one): an input at a new address is captured anew, at most GRAPH_CACHE graphs are kept."""
     if not _graph_ok(W):
         return filter_lr(W, feature_lr, keep_all=keep_all)
-    key = ("lr", id(W), _addr_key(feature_lr), keep_all, _flags())
+    key = ("lr", W.serial, _addr_key(feature_lr), keep_all, _flags())
     if key not in _graphs and _addr_key(feature_lr) not in _stable:
         # an address seen for the first time and not a graph's own buffer: a caller that allocates per call would have every call
         # captured (an eager run + a capture each); the second sighting is taken as "persistent"

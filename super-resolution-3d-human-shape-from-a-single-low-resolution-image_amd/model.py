@@ -63,9 +63,9 @@ class SuRSNet:
         self.intermediate_preds_list_lr = []
         self.intermediate_preds_list_hr = []
         self._mr_points = None
-        self._runs_refused = 0        # consecutive point arrays the run finder refused (query_points_columns)
         self._feat_cache = None
         self._mr_version = 0
+        self._sharded_encode = None   # dist.encode_sharded's arguments + the tensor it produced (the overflow retry of slab mode)
         self._last_images = None      # what super_res() last ran on, and which buffers came out of that run (reencode_wide)
         self._sr_out = self._lr_from = self._hr_from = None
 
@@ -76,6 +76,8 @@ class SuRSNet:
             if device.type == "cuda" and device.index is None:
                 device = torch.device("cuda", torch.cuda.current_device())
             self.device = device
+            if self._enc is not None:
+                encoder.drop_graphs(self._enc)
             self._enc = self._blob = None
         return self
 
@@ -146,6 +148,7 @@ class SuRSNet:
         """images [V,3,H,W] -> (img_SR [V,3,2H,2W], feature_lr [V,256,H/2,W/2], feature_hr [V,64,2H,2W])."""
         W = self._encoder_weights()
         self._last_images = images   # (kept for reencode_wide: the retry after an f16 overflow)
+        self._sharded_encode = None  # (features about to be made by THIS device's encoder: dist.encode_sharded's record is stale)
         # (one view: through the captured HIP graph - encoder.graphed; several views would share the graph's output buffers)
         sr = encoder.super_res_g if images.shape[0] == 1 else encoder.super_res
         outs = [sr(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
@@ -160,6 +163,7 @@ class SuRSNet:
         flr = encoder.filter_lr_g if images.shape[0] == 1 else encoder.filter_lr
         per_view = [flr(W, _as_img(images[v:v + 1]), keep_all=self.training) for v in range(images.shape[0])]
         n_out = len(per_view[0])
+        self._sharded_encode = None
         self._feat_lr_imgs = [[pv[i] for pv in per_view] for i in range(n_out)]
         self.im_feat_list_lr = [torch.cat([_as_nchw_view(pv[i]) for pv in per_view], 0) if len(per_view) > 1
                                 else _as_nchw_view(per_view[0][i]) for i in range(n_out)]
@@ -169,6 +173,7 @@ class SuRSNet:
     def filter_hr(self, images):
         W = self._encoder_weights()
         per_view = [encoder.filter_hr(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
+        self._sharded_encode = None
         self._feat_hr_imgs = [[pv[0] for pv in per_view]]
         self.im_feat_list_hr = [torch.cat([_as_nchw_view(pv[0]) for pv in per_view], 0) if len(per_view) > 1
                                 else _as_nchw_view(per_view[0][0])]
@@ -209,15 +214,25 @@ class SuRSNet:
             raise RuntimeError("the encoder ran on %d images, the query asks for image %d" % (self.im_feat_list_lr[-1].shape[0], b))
         # (feature maps assigned by hand as NCHW tensors are converted once, not once per query: the reference's loop asks 2 684
         #  times per 512^3 grid; the encoder's own outputs are NHWC views and cost nothing either way)
+        # The cache entry HOLDS the two source tensors and a hit requires them to be the same objects (`is`, as _calib_rows does): a
+        # freed tensor's address and version cannot come back under another tensor while the entry keeps it alive.  Only device
+        # tensors are cached - a CPU tensor made by torch.from_numpy can be edited through the numpy array without its version
+        # counter moving -; an in-place edit of a cached DEVICE tensor through `.data` is the one case no counter sees:
+        # invalidate_feature_cache() is for that.
         tl, th = self.im_feat_list_lr[-1], self.im_feat_list_hr[0]
+        cacheable = tl.is_cuda and th.is_cuda and not tl.is_inference() and not th.is_inference()
         key = (b, tl.data_ptr(), th.data_ptr(), tuple(tl.shape), tuple(th.shape), tl.stride(), th.stride(),
-               getattr(tl, "_version", None) if not tl.is_inference() else None,
-               getattr(th, "_version", None) if not th.is_inference() else None)
-        if self._feat_cache is not None and self._feat_cache[0] == key:
-            return self._feat_cache[1]
+               tl._version if cacheable else None, th._version if cacheable else None)
+        hit = self._feat_cache
+        if cacheable and hit is not None and hit[0] == key and hit[1] is tl and hit[2] is th:
+            return hit[3]
         out = _as_img(tl[b:b + 1]), _as_img(th[b:b + 1])
-        self._feat_cache = (key, out)
+        self._feat_cache = (key, tl, th, out) if cacheable else None
         return out
+
+    def invalidate_feature_cache(self):
+        """Forget the converted copy of hand-assigned feature maps (see features(): needed only after an edit no version counter sees)."""
+        self._feat_cache = None
 
     # ------------------------------------------------------------------ query
     def _zscale(self):
@@ -293,15 +308,13 @@ class SuRSNet:
                 # precision); non-finite results are repeated fp32-grade on three bf16 parts like every other overflow
                 # points that come as runs of equal (x, y) - the reference's sweep loop: consecutive grid points, z fastest - are
                 # columns: the restated column kernels take them (same arithmetic as reconstruction()'s sweep in this precision)
-                # (callers whose arrays hold no runs - random samples - pay the run finder and its host round trip, ~ 0.1 ms, for
-                #  nothing: after four refusals in a row only every 8th call asks again - the reference's octree loop mixes chunks
-                #  with longer and shorter runs, so the question is not dropped for long)
+                # (which evaluator an array gets is a function of the array alone: the run finder looks at every array - ~ 0.1 ms for
+                #  nothing on random samples, 1.1 -> 1.2 ms per 50 000 points - instead of backing off after refusals, which made the
+                #  same points' last bits depend on the calls before them)
                 first = None
-                if p_lr is None and (self._runs_refused < 4 or self._runs_refused % 8 == 0):
+                if p_lr is None:
                     first = native.query_points_columns(pts, cal[b], zmul, zdiv, *self.features(b), self._mlp_blob(), self.precision,
                                                         self._workspace())
-                if p_lr is None:
-                    self._runs_refused = 0 if first is not None else self._runs_refused + 1
                 if first is None:
                     with native.reduced_point_operands(self.precision in ("bf16", "fp16")):
                         first = run()

@@ -473,19 +473,26 @@ def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtyp
     from . import encoder
     side = encoder.existing_side_stream()
     check(lib().surs_set_side_stream(C.c_void_p(side.cuda_stream) if side is not None else None))
-    for p0 in range(0, n, POINT_RUNS_CHUNK):
-        nb = min(POINT_RUNS_CHUNK, n - p0)
-        check(lib().surs_query_points_columns(C.c_void_p(points.data_ptr() + 4 * p0), n, nb, cal, float(zmul), float(zdiv),
-                                              feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
-                                              code, _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * p0),
-                                              C.c_void_p(plr.data_ptr() + 4 * p0), C.byref(ncols), _stream()))
-        if ncols.value == 0:
-            if p0 == 0 and nb == n:
-                return None
-            # this piece holds no runs: the point kernels for it
-            a, b = query_points(points[:, p0:p0 + nb], calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
-            phr[p0:p0 + nb] = a
-            plr[p0:p0 + nb] = b
+    try:
+        for p0 in range(0, n, POINT_RUNS_CHUNK):
+            nb = min(POINT_RUNS_CHUNK, n - p0)
+            check(lib().surs_query_points_columns(C.c_void_p(points.data_ptr() + 4 * p0), n, nb, cal, float(zmul), float(zdiv),
+                                                  feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
+                                                  code, _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * p0),
+                                                  C.c_void_p(plr.data_ptr() + 4 * p0), C.byref(ncols), _stream()))
+            if ncols.value == 0:
+                if p0 == 0 and nb == n:
+                    return None
+                # this piece holds no runs: the point kernels for it, in the arithmetic the rest of the array gets (one product per
+                # MAC behind --precision bf16 | fp16: the column kernel's pieces are 16-bit there too)
+                with reduced_point_operands(code != DTYPES["fp32"]):
+                    a, b = query_points(points[:, p0:p0 + nb], calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
+                phr[p0:p0 + nb] = a
+                plr[p0:p0 + nb] = b
+    finally:
+        # (the lane is per host thread and outlives the call otherwise: a later small column batch of this thread - an octree level, a
+        #  small slab - on another stream or device would inherit it)
+        lib().surs_set_side_stream(None)
     return phr, plr
 
 

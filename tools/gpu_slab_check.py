@@ -103,6 +103,16 @@ def worker(rank, world, port, R, H=0):
                       flush=True)
             else:
                 assert got is None
+    # want_normals=True (the 8-tuple of mesh_util.reconstruction): the volumes are gathered on rank 0, which extracts them whole
+    if R <= 128:
+        got = sdist.reconstruction_sharded(opt, net, calib, R, b_min, b_max, want_normals=True)
+        if rank == 0:
+            refn = mesh_util.reconstruction(opt, make(), dev, calib, R, b_min, b_max, use_octree=False, want_normals=True)
+            ok = all(np.array_equal(got[i], refn[i]) for i in (0, 1, 3, 4, 5, 7))                      # vertices, faces, values
+            ok = ok and all(np.abs(got[i] - refn[i]).max() < 1e-4 for i in (2, 6))                      # normals: float atomics
+            print("normals world %d R %d: %s" % (world, R, "slab == one piece" if ok else "MISMATCH"), flush=True)
+        else:
+            assert got is None
     # the checks of marching_cubes_lewiner, on every rank: no level crossing anywhere in the grid
     net.im_feat_list_lr = [torch.zeros_like(net.im_feat_list_lr[0])]
     net.im_feat_list_hr = [torch.zeros_like(net.im_feat_list_hr[0])]
