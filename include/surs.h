@@ -155,6 +155,80 @@ int surs_image_prepare(const unsigned char *rgb, const unsigned char *mask, int 
 int surs_nchw_to_nhwc(const float *x, int c, int h, int w, float *y, int y_ld, void *stream);
 int surs_nhwc_to_nchw(const float *x, int c, int h, int w, int x_ld, float *y, void *stream);
 
+/* GroupNorm(32) statistics of a map as the kernels that wrote it left them: partial sums [32 groups][pitch][2] doubles (sum, sum of
+ * squares).  A map written by ONE kernel has slots[0] slots in every group (g1 = g2 = 0).  A map written slice by slice by several
+ * kernels, each with its own pixel tiling - a ConvBlock's cat(o1, o2, o3) + x -: groups [0, g1) hold slots[0], [g1, g2) slots[1],
+ * [g2, 32) slots[2] slots. */
+typedef struct SursGnStats { double *sums; int pitch, g1, g2; int slots[3]; } SursGnStats;
+/* One 3x3 / stride-1 convolution of a ConvBlock (lib/model/HGFilters.py:57-73) with the block's closing sum in its epilogue:
+ *   v  = conv(pre(x)) + bias,  pre = GroupNorm(gamma, beta, eps) + ReLU from gn_in's statistics, or from in_scale / in_shift, or none
+ *   y  = v                      (nullable: the last convolution's own value is not read by anybody) + its statistics in gn_out
+ *        (nullable; on entry gn_out->sums and ->pitch = capacity in slots, on return the slot counts)
+ *   y2 = v + residual           the slice of out = cat(o1, o2, o3) + x this convolution makes, and - gn_out2 not NULL - the statistics
+ *        of those values in the numbering of the WHOLE sum: group gn2_g0 + channel / gn2_cg, rows gn2_pitch slots apart,
+ *        *gn2_slots = the slots this launch wrote per group.
+ * The same tiles and bits as surs_conv2d_nhwc_gn followed by surs_add3_gn on the slice. */
+int surs_conv2d_nhwc_gn_sum(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                            const SursGnStats *gn_in, const float *in_scale, const float *in_shift, const float *gamma, const float *beta,
+                            float eps, float *y, int cout, int y_ld, SursGnStats *gn_out, const float *residual, int res_ld, float *y2,
+                            int y2_ld, double *gn_out2, int gn2_pitch, int gn2_g0, int gn2_cg, int *gn2_slots, void *stream);
+
+/* ------------------------------------------------------------------ the encoder as ONE call per network
+ * SuRSNet.super_res / filter_hr / filter_lr (lib/model/SuRSNet.py:101-129) = SuRSSR_v3.forward (lib/model/SuRSSR_v3.py:143-181),
+ * HGFilter.forward high_res (lib/model/HGFilters.py:179-181) and low_res (:183-206; ConvBlock :29-74, HourGlass :76-120), sequenced
+ * inside the library (csrc/surs_encoder_net.cpp): the launches of the primitives above in the reference's order, intermediates in
+ * the caller's workspace, nothing allocated, no stream created.  The results equal the per-primitive sequencing of the host mirror
+ * (encoder.py) bit for bit.  All weight pointers are DEVICE pointers in the layouts of the pack functions above; the struct itself
+ * is HOST memory and is only read during the call. */
+enum { SURS_ENC_SEPARATE_SUM = 1 };  /* SursEncoderNet.flags: a ConvBlock's closing sum as a pass of its own (surs_add3_gn: the four-launch
+                                         form of rounds 4 - 5, whose bits the host mirror's per-launch sequencing reproduces) instead of in
+                                         the three convolutions' epilogues (surs_conv2d_nhwc_gn_sum: the default) */
+typedef struct SursConv {
+    const void *w_split;    /* surs_conv_pack_weights_x2 image (3x3 and 1x1), or NULL: only the fp32 kernel applies */
+    const float *w_packed;  /* surs_conv_pack_weights image (the fp32 MFMA / direct kernels: 3 -> 32 head, 32 -> 3 tail) */
+    const float *bias;      /* [cout] or NULL */
+    int cin, cout, ksize, reserved;
+} SursConv;
+typedef struct SursGroupNorm { const float *gamma, *beta; } SursGroupNorm;           /* GroupNorm(32, C), eps 1e-5 */
+typedef struct SursConvBlock { SursConv conv[3]; SursGroupNorm bn[3]; } SursConvBlock; /* ConvBlock with in_planes == out_planes */
+typedef struct SursEncoderNet {
+    int residual;           /* opt.residual: the ResBlocks of the super-resolution stages run */
+    int n_block[3];         /* opt.n_block */
+    int num_stack, hg_depth;
+    int parts;              /* 2 = fp32-grade (two f16 parts, three products per MAC); 1 = one f16 product in the 3x3 convolutions */
+    int flags;              /* SURS_ENC_* */
+    /* super_resolution.* (SuRSSR_v3): head.0, down{1,2,3}.0, tail{1,2,3}.0 / .2, bottleneck.0, bott2.0, ups2.0, ups3.0, ups4.0,
+     * last.0, last.2; body: body{i}.{b}.body.0, .body.2 for i = 1..3, b = 0..n_block[i-1]-1, in that order */
+    SursConv head, down[3], tail0[3], tail2[3], bottleneck, bott2, ups2, ups3, ups4, last0, last2;
+    const SursConv *body;
+    SursConv conv5;         /* image_filter_hr.conv5 */
+    SursConvBlock conv2;    /* image_filter_lr.conv2 */
+    /* image_filter_lr.m{s}: per stack 3 * hg_depth + 1 blocks in module order b1_d, b2_d, [b1_{d-1}, b2_{d-1}, ...], b2_plus_1, b3_1, .., b3_d */
+    const SursConvBlock *hg;
+    const SursConvBlock *top_m;   /* [num_stack] */
+    const SursConv *conv_last, *l, *next;   /* [num_stack]; next[s] = bl{s} + al{s} o l{s} merged (W_bl + W_al W_l), unused for the last stack */
+    const SursGroupNorm *bn_end;  /* [num_stack] */
+} SursEncoderNet;
+/* Streams the caller lends for the low-resolution branch of hourglass level 1..4 (NULL entries / NULL struct: the branches run one
+ * behind the other on `stream`).  The library never creates a stream (see surs_set_side_stream). */
+typedef struct SursEncoderStreams { void *side[4]; } SursEncoderStreams;
+/* bytes of workspace the calls below need for an h x w input image (0: bad arguments) */
+size_t surs_encoder_workspace_bytes(const SursEncoderNet *net, int h, int w);
+/* x [h][w][3] (pitch x_ld) -> feature_lr [h/2][w/2][256], feature_hr [2h][2w][64] and, if want_image, img_sr [2h][2w][3] (dense) */
+int surs_encoder_super_res(const SursEncoderNet *net, const float *x, int h, int w, int x_ld, int want_image, float *img_sr,
+                           float *feature_lr, float *feature_hr, void *workspace, size_t workspace_bytes, void *stream);
+/* feature_lr [h][w][256] (pitch ld) -> outs[s] [h][w][last_ch] for every stack s with outs[s] != NULL (HOST array of num_stack device
+ * pointers; the last one is required - eval keeps only it, training keeps all) */
+int surs_encoder_filter_lr(const SursEncoderNet *net, const float *feature_lr, int h, int w, int ld, float *const *outs,
+                           void *workspace, size_t workspace_bytes, const SursEncoderStreams *streams, void *stream);
+/* feature_hr [h][w][64] (pitch ld) -> out [h][w][64] */
+int surs_encoder_filter_hr(const SursEncoderNet *net, const float *feature_hr, int h, int w, int ld, float *out, void *stream);
+/* the three in the order gen_mesh runs them (lib/train_util.py:57-59): image [h][w][3] -> feature_lr, feature_hr (kept: the caller's
+ * buffers), im_feat_lr [h/2][w/2][last_ch] (last stack), im_feat_hr [2h][2w][64] */
+int surs_encoder_forward(const SursEncoderNet *net, const float *image, int h, int w, int x_ld, float *feature_lr, float *feature_hr,
+                         float *im_feat_lr, float *im_feat_hr, void *workspace, size_t workspace_bytes,
+                         const SursEncoderStreams *streams, void *stream);
+
 /* ------------------------------------------------------------------ point evaluator */
 
 /* HOST: pack the two SurfaceClassifier MLPs (lr: 321-1024-512-256-128-1, hr: 322-..., skip-concat at layers

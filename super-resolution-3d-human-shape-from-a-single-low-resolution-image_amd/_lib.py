@@ -39,6 +39,41 @@ class GridOptions(C.Structure):
     _fields_ = [("kernel", C.c_int), ("operand_parts", C.c_int), ("reserved", C.c_int * 6)]
 
 
+class Conv(C.Structure):
+    """SursConv of include/surs.h."""
+    _fields_ = [("w_split", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("cin", C.c_int), ("cout", C.c_int),
+                ("ksize", C.c_int), ("reserved", C.c_int)]
+
+
+class GroupNorm(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p)]
+
+
+class ConvBlock(C.Structure):
+    _fields_ = [("conv", Conv * 3), ("bn", GroupNorm * 3)]
+
+
+class EncoderNet(C.Structure):
+    """SursEncoderNet of include/surs.h (device pointers of the packed weights; the arrays behind the pointer fields are kept alive by
+    encoder.NativeNet)."""
+    _fields_ = [("residual", C.c_int), ("n_block", C.c_int * 3), ("num_stack", C.c_int), ("hg_depth", C.c_int), ("parts", C.c_int),
+                ("flags", C.c_int),
+                ("head", Conv), ("down", Conv * 3), ("tail0", Conv * 3), ("tail2", Conv * 3), ("bottleneck", Conv), ("bott2", Conv),
+                ("ups2", Conv), ("ups3", Conv), ("ups4", Conv), ("last0", Conv), ("last2", Conv),
+                ("body", C.POINTER(Conv)), ("conv5", Conv), ("conv2", ConvBlock), ("hg", C.POINTER(ConvBlock)),
+                ("top_m", C.POINTER(ConvBlock)), ("conv_last", C.POINTER(Conv)), ("l", C.POINTER(Conv)), ("next", C.POINTER(Conv)),
+                ("bn_end", C.POINTER(GroupNorm))]
+
+
+class EncoderStreams(C.Structure):
+    _fields_ = [("side", C.c_void_p * 4)]
+
+
+class GnStats(C.Structure):
+    """SursGnStats of include/surs.h."""
+    _fields_ = [("sums", C.c_void_p), ("pitch", C.c_int), ("g1", C.c_int), ("g2", C.c_int), ("slots", C.c_int * 3)]
+
+
 class McCounts(C.Structure):
     _fields_ = [("n_verts", C.c_int32), ("n_faces", C.c_int32), ("vmin", C.c_float), ("vmax", C.c_float)]
 
@@ -72,6 +107,13 @@ _SIGS = {
     "surs_avgpool2_gn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int), _vp]),
     "surs_bicubic_up2_gn": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int), _vp]),
     "surs_add3_gn": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int), _vp]),
+    "surs_conv2d_nhwc_gn_sum": (C.c_int, [_i, _vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(GnStats), _vp, _vp, _vp, _vp, _f, _vp, _i, _i,
+                                          C.POINTER(GnStats), _vp, _i, _vp, _i, _vp, _i, _i, _i, C.POINTER(C.c_int), _vp]),
+    "surs_encoder_workspace_bytes": (_sz, [C.POINTER(EncoderNet), _i, _i]),
+    "surs_encoder_super_res": (C.c_int, [C.POINTER(EncoderNet), _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "surs_encoder_filter_lr": (C.c_int, [C.POINTER(EncoderNet), _vp, _i, _i, _i, C.POINTER(_vp), _vp, _sz, C.POINTER(EncoderStreams), _vp]),
+    "surs_encoder_filter_hr": (C.c_int, [C.POINTER(EncoderNet), _vp, _i, _i, _i, _vp, _vp]),
+    "surs_encoder_forward": (C.c_int, [C.POINTER(EncoderNet), _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(EncoderStreams), _vp]),
     "surs_mlp_pack": (_sz, [_vp, _vp, _vp, _vp, _i, _vp]),
     "surs_set_operand_split": (C.c_int, [_i]),
     "surs_set_operand_split_local": (C.c_int, [_i]),

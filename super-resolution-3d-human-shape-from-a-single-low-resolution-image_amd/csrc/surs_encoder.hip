@@ -49,6 +49,16 @@ struct ConvArgs {
     // pixel tile (blockIdx.y * gridDim.x + blockIdx.x), for the GroupNorm(32, cout) that follows.
     const double *gn_in; int gn_in_slots; const float *gamma, *beta; float eps;
     double *gn_out;
+    // A map written by SEVERAL kernels, each with its own tiling (a ConvBlock's cat(o1, o2, o3) + x, each slice by its convolution):
+    // the rows of gn_in are gn_in_pitch doubles-pairs apart (0: gn_in_slots) and the groups [gn_in_g1, gn_in_g2) / [gn_in_g2, 32) hold
+    // gn_in_slots1 / gn_in_slots2 slots (gn_in_g1 = 0: one count for all).
+    int gn_in_pitch, gn_in_g1, gn_in_g2, gn_in_slots1, gn_in_slots2;
+    // Second output (conv_x3_kernel only; null = not used): y2 = value + res (res required) while the value itself goes to y (if y is
+    // not null) - the ConvBlock's closing sum out = cat(o1, o2, o3) + x (lib/model/HGFilters.py:66-73) leaves with the convolution
+    // that makes the slice instead of in a pass of its own.  gn_out2: statistics of the y2 values in the numbering of the WHOLE sum -
+    // group gn2_g0 + (channel / gn2_cg), rows gn2_pitch slots apart, one slot per pixel tile.
+    float *y2; int y2_ld;
+    double *gn_out2; int gn2_pitch, gn2_cg, gn2_g0;
 };
 
 template <int KS, int STRIDE, int TR, int NT>
@@ -249,8 +259,9 @@ template <> struct ConvSplit<1> {
 // order (eight loads in flight), then a butterfly over the eight - a fixed summation tree, the same in every workgroup of every
 // launch - then gn_finish_kernel's arithmetic.  cin is a multiple of 32: no pad channels.  The caller synchronises.
 __device__ __forceinline__ void gn_fold_to_lds(const ConvArgs &a, float *gn, int shift_off, int tid) {
-    const int g = tid >> 3, sub = tid & 7, cgi = a.cin / 32, slots = a.gn_in_slots;
-    const double2 *pg = reinterpret_cast<const double2 *>(a.gn_in) + (size_t)g * slots;
+    const int g = tid >> 3, sub = tid & 7, cgi = a.cin / 32;
+    const int slots = (a.gn_in_g1 <= 0 || g < a.gn_in_g1) ? a.gn_in_slots : (g < a.gn_in_g2 ? a.gn_in_slots1 : a.gn_in_slots2);
+    const double2 *pg = reinterpret_cast<const double2 *>(a.gn_in) + (size_t)g * (a.gn_in_pitch > 0 ? a.gn_in_pitch : a.gn_in_slots);
     double S = 0, SS = 0;
     for (int base = 0; base < slots; base += 64) {
         double2 v[8];
@@ -513,10 +524,11 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     CSTAMP(4);   // (the interval since the last chunk's second barrier)
     // ---- epilogue: register q of a tile is pixel column (q&3) + 8*(q>>2) + 4*(lane>>5), lane&31 is the channel
     const int kh = lane >> 5, li = lane & 31;
-    const bool stats = a.gn_out != nullptr;
+    const bool stats = a.gn_out != nullptr, dual = a.y2 != nullptr, stats2 = a.gn_out2 != nullptr;
     double st_s[NJ], st_ss[NJ];   // this lane's sums of the values it stores, per channel tile
+    double s2_s[NJ], s2_ss[NJ];   // ... and of the values of the second output
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) st_s[j] = st_ss[j] = 0.0;
+    for (int j = 0; j < NJ; ++j) st_s[j] = st_ss[j] = s2_s[j] = s2_ss[j] = 0.0;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int oy = oy0 + wave * RPW + r;
@@ -545,6 +557,23 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
                 t += b;
                 if (a.act == 1) t = t > 0.f ? t : a.slope * t;
                 const size_t pix = (size_t)oy * a.wo + ox;
+                if (dual) {
+                    // the value to y (the next convolution's input), value + res to y2 (the block's output slice)
+                    if (a.y) a.y[pix * a.y_ld + co] = t;
+                    if (stats) {
+                        const double d = (double)t;
+                        st_s[j] += d;
+                        st_ss[j] += d * d;
+                    }
+                    const float u = t + rv[q];
+                    a.y2[pix * a.y2_ld + co] = u;
+                    if (stats2) {
+                        const double d = (double)u;
+                        s2_s[j] += d;
+                        s2_ss[j] += d * d;
+                    }
+                    continue;
+                }
                 if (a.res) t += rv[q];
                 a.y[pix * a.y_ld + co] = t;
                 if (stats) {
@@ -555,14 +584,14 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             }
         }
     }
-    if (stats) {
-        // fold: the two pixel halves of a channel (lanes l, l + 32), the cg = cout / 32 (a power of two <= 32) channels of a group
-        // (neighbouring lanes), the four waves (rows) through LDS - every step in a fixed order; one slot per pixel tile
-        const int cg = a.cout / 32, gpt = 32 / cg;
+    // fold: the two pixel halves of a channel (lanes l, l + 32), the cg channels of a group (neighbouring lanes), the four waves
+    // (rows) through LDS - every step in a fixed order; one slot per pixel tile
+    auto publish = [&](double (&vs)[NJ], double (&vss)[NJ], double *dst, int cg, int g0, size_t pitch) {
+        const int gpt = 32 / cg;
         double *red = reinterpret_cast<double *>(lds16);   // [4 waves][NJ][32][2] (the chunk loop ended with a barrier)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            double S = st_s[j], SS = st_ss[j];
+            double S = vs[j], SS = vss[j];
             gn_fold_lanes(S, SS, cg);
             if (lane < 32 && (li & (cg - 1)) == 0) {
                 red[((wave * NJ + j) * 32 + li / cg) * 2] = S;
@@ -572,7 +601,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         __syncthreads();
         if (tid < NJ * gpt) {
             const int j = tid / gpt, k = tid - j * gpt;
-            const int g = (n0 + j * 32) / cg + k;
+            const int g = g0 + (n0 + j * 32) / cg + k;
             if (g < 32) {
                 double S = 0, SS = 0;
 #pragma unroll
@@ -580,12 +609,15 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
                     S += red[((wv * NJ + j) * 32 + k) * 2];
                     SS += red[((wv * NJ + j) * 32 + k) * 2 + 1];
                 }
-                const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x, slots = (size_t)gridDim.x * gridDim.y;
-                a.gn_out[((size_t)g * slots + slot) * 2] = S;
-                a.gn_out[((size_t)g * slots + slot) * 2 + 1] = SS;
+                const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+                dst[((size_t)g * pitch + slot) * 2] = S;
+                dst[((size_t)g * pitch + slot) * 2 + 1] = SS;
             }
         }
-    }
+    };
+    if (stats) publish(st_s, st_ss, a.gn_out, a.cout / 32, 0, (size_t)gridDim.x * gridDim.y);
+    if (stats && stats2) __syncthreads();   // (the reduction buffer is used again)
+    if (stats2) publish(s2_s, s2_ss, a.gn_out2, a.gn2_cg, a.gn2_g0, (size_t)a.gn2_pitch);
     CSTAMP(6);
 }
 
@@ -626,6 +658,12 @@ extern "C" int surs_conv_tile_scale(int num, int den) {
     return 0;
 }
 
+// workgroups of the 8-row x 64-channel tile from which a launch takes it (experiment knob of round 6: SURS_CONV_BIG_MIN_WG)
+static int conv_big_min_wg() {
+    static const int v = getenv("SURS_CONV_BIG_MIN_WG") ? atoi(getenv("SURS_CONV_BIG_MIN_WG")) : 512;
+    return v;
+}
+
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
@@ -634,7 +672,7 @@ static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipSt
     //  AGPRs - was measured in round 5: super_res 2.93 -> 2.84 ms, filter_lr unchanged, and im_feat_lr wrong by up to 2.3 when four
     //  processes share the GPU (tests/test_gpu_dist.py: the waves are preempted there; identical results in every single-process
     //  run).  Not shipped: NOTES R5.7.)
-    if (wg_big >= 512) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
+    if (wg_big >= conv_big_min_wg()) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
@@ -1393,7 +1431,7 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
                          "GroupNorm(32) output statistics: cout / 32 must be a power of two <= 32");
             // one slot per pixel tile of the launch below (launch_conv_x3's choice, restated)
             const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-            const bool big = stride == 1 && (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= 512;
+            const bool big = stride == 1 && (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= conv_big_min_wg();
             const int slots = ksize == 1 ? (int)(((long long)a.ho * a.wo + 127) / 128) : ceil_div(a.wo, TC) * ceil_div(a.ho, big ? 8 : 4);
             SURS_REQUIRE(slots <= gn->out_capacity, "GroupNorm statistics buffer too small: %d slots needed", slots);
             *gn->out_slots = slots;
@@ -1408,6 +1446,55 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
         return launch_conv_x3<3, 1, 1>(a, (const unsigned short *)wsplit, as_stream(stream));
     }
     if (stride == 2) return launch_conv_x3_cfg<3, 2, 4, 32, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
+    return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
+}
+
+// One convolution of a ConvBlock (lib/model/HGFilters.py:57-73) with the block's closing sum in its epilogue: see include/surs.h.
+extern "C" int surs_conv2d_nhwc_gn_sum(int parts, const float *x, int h, int w, int cin, int x_ld, const void *wsplit, const float *bias,
+                                       const SursGnStats *gn_in, const float *in_scale, const float *in_shift, const float *gamma,
+                                       const float *beta, float eps, float *y, int cout, int y_ld, SursGnStats *gn_out,
+                                       const float *residual, int res_ld, float *y2, int y2_ld, double *gn_out2, int gn2_pitch, int gn2_g0,
+                                       int gn2_cg, int *gn2_slots, void *stream) {
+    SURS_REQUIRE(parts == 1 || parts == 2, "one or two f16 parts");
+    SURS_REQUIRE(x && wsplit && y2 && residual, "null argument (the sum needs its second operand and its output)");
+    SURS_REQUIRE(h > 0 && w > 0 && cin > 0 && cout > 0 && x_ld >= cin && y2_ld >= cout && (!y || y_ld >= cout), "bad sizes");
+    SURS_REQUIRE(cin % 16 == 0 && x_ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0,
+                 "the split-f16 kernels need cin %% 16 == 0 and 16-byte aligned pixels");
+    SURS_REQUIRE((long long)h * w * x_ld < (1ll << 31), "input too large for 32-bit element offsets");
+    SURS_REQUIRE(!(gn_in && in_scale) && (in_scale == nullptr) == (in_shift == nullptr), "GroupNorm input: either coefficients or statistics");
+    ConvArgs a{};
+    a.x = x; a.h = h; a.w = w; a.cin = cin; a.x_ld = x_ld;
+    a.cin_pad = (cin + 15) / 16 * 16; a.cout_pad = (cout + 63) / 64 * 64;
+    a.bias = bias;
+    a.y = y; a.ho = h; a.wo = w; a.cout = cout; a.y_ld = y_ld;
+    a.in_scale = in_scale; a.in_shift = in_shift;
+    a.res = residual; a.res_ld = res_ld;
+    a.y2 = y2; a.y2_ld = y2_ld;
+    if (gn_in) {
+        SURS_REQUIRE(gn_in->sums && gamma && beta && gn_in->slots[0] > 0 && cin % 32 == 0 && cin <= 1024, "bad GroupNorm(32) input statistics");
+        a.gn_in = gn_in->sums; a.gn_in_slots = gn_in->slots[0]; a.gamma = gamma; a.beta = beta; a.eps = eps;
+        a.gn_in_pitch = gn_in->pitch; a.gn_in_g1 = gn_in->g1; a.gn_in_g2 = gn_in->g2;
+        a.gn_in_slots1 = gn_in->slots[1]; a.gn_in_slots2 = gn_in->slots[2];
+    }
+    const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
+    const bool big = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= conv_big_min_wg();
+    const int slots = ceil_div(a.wo, TC) * ceil_div(a.ho, big ? 8 : 4);
+    if (gn_out) {
+        const int cg = cout / 32;
+        SURS_REQUIRE(y && gn_out->sums && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0 && slots <= gn_out->pitch,
+                     "GroupNorm(32) output statistics: cout / 32 must be a power of two <= 32, %d slots needed", slots);
+        a.gn_out = gn_out->sums;
+        gn_out->pitch = slots;   // (rows of a single-kernel map lie slot count apart)
+        gn_out->g1 = gn_out->g2 = 0;
+        gn_out->slots[0] = gn_out->slots[1] = gn_out->slots[2] = slots;
+    }
+    if (gn_out2) {
+        SURS_REQUIRE(gn2_slots && gn2_cg >= 1 && gn2_cg <= 32 && (gn2_cg & (gn2_cg - 1)) == 0 && cout % gn2_cg == 0 && gn2_g0 >= 0 &&
+                     gn2_g0 + cout / gn2_cg <= 32 && slots <= gn2_pitch, "bad statistics of the sum: %d slots needed", slots);
+        a.gn_out2 = gn_out2; a.gn2_pitch = gn2_pitch; a.gn2_cg = gn2_cg; a.gn2_g0 = gn2_g0;
+        *gn2_slots = slots;
+    }
+    if (parts == 1) return launch_conv_x3<3, 1, 1>(a, (const unsigned short *)wsplit, as_stream(stream));
     return launch_conv_x3<3, 1, 2>(a, (const unsigned short *)wsplit, as_stream(stream));
 }
 

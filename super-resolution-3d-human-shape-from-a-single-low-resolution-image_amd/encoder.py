@@ -7,6 +7,7 @@ Mirrors, layer for layer:
   HGFilter.forward high_res   lib/model/HGFilters.py:179-181
 torch.cat is never materialised: producers write into channel slices of the concatenated tensor.
 """
+import ctypes as C
 import numpy as np
 import os
 
@@ -90,6 +91,163 @@ class EncoderWeights:
                 wb, bb = get(L + "bl%d.weight" % s).astype(np.float64)[:, :, 0, 0], get(L + "bl%d.bias" % s).astype(np.float64)
                 self.conv[L + "next%d" % s] = native.ConvWeights((wb + wa @ wl).astype(np.float32)[:, :, None, None],
                                                                  (bb + wa @ bl_ + ba).astype(np.float32), device, reduced=self.reduced)
+
+
+# ------------------------------------------------------------------ the networks sequenced inside the library (default)
+# csrc/surs_encoder_net.cpp runs the launches of super_res / filter_lr / filter_hr below - the same kernels, order, tiles and bits -
+# from ONE C call per network: no ctypes hop per launch (~ 160 per image), intermediates in one workspace tensor instead of a tensor
+# per map.  The Python sequencing below stays as the readable mirror, as the reference the native one is held to bit for bit
+# (tests/test_gpu_encoder_net.py) and as the path of the non-default forms: wide operands (the retry after an f16 overflow), the
+# three-part bf16 split, SURS_ENC_FUSED_GN=0, captured graphs, SURS_ENC_NATIVE=0.
+class NativeNet:
+    """SursEncoderNet (include/surs.h) of an EncoderWeights: device pointers of its packed weights, in the header's order."""
+
+    def __init__(self, W):
+        from . import _lib
+        opt = W.opt
+        self.keep = []   # ctypes arrays behind the struct's pointer fields
+
+        def conv(name):
+            cw = W.conv[name]
+            w3 = cw.w3 if cw.parts == 2 else None
+            return _lib.Conv(w3.data_ptr() if w3 is not None else None, cw.w.data_ptr(), cw.b.data_ptr() if cw.b is not None else None,
+                             cw.cin, cw.cout, cw.k, 0)
+
+        def gn(name):
+            g, b = W.gn[name]
+            return _lib.GroupNorm(g.data_ptr(), b.data_ptr())
+
+        def block(prefix):
+            return _lib.ConvBlock((_lib.Conv * 3)(*[conv(prefix + "conv%d" % i) for i in (1, 2, 3)]),
+                                  (_lib.GroupNorm * 3)(*[gn(prefix + "bn%d" % i) for i in (1, 2, 3)]))
+
+        def array(ctype, items):
+            a = (ctype * max(1, len(items)))(*items)
+            self.keep.append(a)
+            return a
+
+        n = _lib.EncoderNet()
+        n.residual = 1 if opt.residual else 0
+        n.n_block = (C.c_int * 3)(*[int(v) for v in opt.n_block])
+        n.num_stack, n.hg_depth, n.parts = int(opt.num_stack_lr), int(opt.hg_depth), 1 if W.reduced else 2
+        # SURS_ENC_SEPARATE_SUM=1: a ConvBlock's closing sum as a launch of its own (the form whose bits the sequencing below
+        # reproduces: tests/test_gpu_encoder_net.py); default: in the three convolutions' epilogues (surs_conv2d_nhwc_gn_sum)
+        n.flags = 1 if os.environ.get("SURS_ENC_SEPARATE_SUM", "0") != "0" else 0
+        S = "super_resolution."
+        n.head = conv(S + "head.0")
+        n.down = (_lib.Conv * 3)(*[conv(S + "down%d.0" % i) for i in (1, 2, 3)])
+        n.tail0 = (_lib.Conv * 3)(*[conv(S + "tail%d.0" % i) for i in (1, 2, 3)])
+        n.tail2 = (_lib.Conv * 3)(*[conv(S + "tail%d.2" % i) for i in (1, 2, 3)])
+        for f, k in (("bottleneck", "bottleneck.0"), ("bott2", "bott2.0"), ("ups2", "ups2.0"), ("ups3", "ups3.0"), ("ups4", "ups4.0"),
+                     ("last0", "last.0"), ("last2", "last.2")):
+            setattr(n, f, conv(S + k))
+        body = []
+        for i, nb in zip((1, 2, 3), opt.n_block):
+            for b in range(nb):
+                body += [conv(S + "body%d.%d.body.0" % (i, b)), conv(S + "body%d.%d.body.2" % (i, b))]
+        n.body = array(_lib.Conv, body)
+        n.conv5 = conv("image_filter_hr.conv5")
+        L = "image_filter_lr."
+        n.conv2 = block(L + "conv2.")
+        hg = []
+        for s in range(opt.num_stack_lr):
+            def gen(level):
+                hg.append(block(L + "m%d.b1_%d." % (s, level)))
+                hg.append(block(L + "m%d.b2_%d." % (s, level)))
+                if level > 1:
+                    gen(level - 1)
+                else:
+                    hg.append(block(L + "m%d.b2_plus_%d." % (s, level)))
+                hg.append(block(L + "m%d.b3_%d." % (s, level)))
+            gen(opt.hg_depth)
+        n.hg = array(_lib.ConvBlock, hg)
+        S_ = range(opt.num_stack_lr)
+        n.top_m = array(_lib.ConvBlock, [block(L + "top_m_%d." % s) for s in S_])
+        n.conv_last = array(_lib.Conv, [conv(L + "conv_last%d" % s) for s in S_])
+        n.l = array(_lib.Conv, [conv(L + "l%d" % s) for s in S_])
+        n.next = array(_lib.Conv, [conv(L + "next%d" % s) if s < opt.num_stack_lr - 1 else _lib.Conv() for s in S_])
+        n.bn_end = array(_lib.GroupNorm, [gn(L + "bn_end%d" % s) for s in S_])
+        self.net = n
+        self.last_ch = W.conv[L + "l0"].cout
+        self.ws = None
+
+    def workspace(self, h, w, device):
+        """The calls' workspace: one tensor per stream the encoder runs on (two encoders side by side - gen_mesh_pipelined - must not
+        share intermediates), grown on demand."""
+        need = native.lib().surs_encoder_workspace_bytes(C.byref(self.net), h, w)
+        if need == 0:
+            raise ValueError("surs_encoder_workspace_bytes refused a %dx%d image" % (h, w))
+        if self.ws is None:
+            self.ws = {}
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        t = self.ws.get(key)
+        if t is None or t.numel() < need:
+            self.ws.pop(key, None)
+            t = self.ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        return t
+
+
+def native_enabled(W):
+    """The library's own sequencing applies: default operand split (two f16 parts, or the one-part opt-in), statistics handed from kernel
+    to kernel, not inside wide_operands(), no captured graphs, SURS_ENC_NATIVE != 0."""
+    return (os.environ.get("SURS_ENC_NATIVE", "1") != "0" and not native.wide_operands_active() and native.fused_groupnorm()
+            and os.environ.get("SURS_CONV_SPLIT", "f16x2").startswith("f") and os.environ.get("SURS_CONV_X3", "1") != "0"
+            and not graphs_enabled(W) and not torch.cuda.is_current_stream_capturing())
+
+
+def _native_net(W):
+    nn = getattr(W, "_native", None)
+    if nn is None:
+        nn = W._native = NativeNet(W)
+    return nn
+
+
+def _lent_streams(depth):
+    """SursEncoderStreams: the hourglass levels' side streams, lent only to an encoder on the device's default stream (hourglass());
+    created in the order the Python sequencing creates them (the deepest level first: the stream -> hardware-queue mapping depends on
+    creation order, NOTES R4.4)."""
+    from . import _lib
+    cur = torch.cuda.current_stream()
+    if os.environ.get("SURS_ENC_STREAMS", "1") == "0" or cur.cuda_stream != torch.cuda.default_stream(cur.device).cuda_stream:
+        return None, None
+    arr = (C.c_void_p * 4)()
+    sides = []
+    for level in range(min(depth, 4), 0, -1):
+        st = _side_stream(level)
+        arr[level - 1] = st.cuda_stream
+        sides.append(st)
+    return _lib.EncoderStreams(arr), sides
+
+
+def super_res_native(W, x, want_image=True):
+    """super_res() as one library call (surs_encoder_super_res): same outputs, bit for bit."""
+    if x.h % 4 or x.w % 4:
+        raise ValueError("input image height/width must be multiples of 4 (three stride-2 stages), got %dx%d" % (x.h, x.w))
+    nn, dev = _native_net(W), x.buf.device
+    ws = nn.workspace(x.h, x.w, dev)
+    new2 = Img(x.h // 2, x.w // 2, 256, device=dev)
+    new_fin = Img(2 * x.h, 2 * x.w, 64, device=dev)
+    img_sr = Img(2 * x.h, 2 * x.w, 3, device=dev) if want_image else None
+    native.check(native.lib().surs_encoder_super_res(C.byref(nn.net), x.ptr(), x.h, x.w, x.ld, 1 if want_image else 0,
+                                                     img_sr.ptr() if want_image else None, new2.ptr(), new_fin.ptr(), native._ptr(ws),
+                                                     ws.numel(), native._stream()))
+    return img_sr, new2, new_fin
+
+
+def filter_lr_native(W, feature_lr, keep_all=False):
+    """filter_lr() as one library call (surs_encoder_filter_lr)."""
+    opt = W.opt
+    if feature_lr.h % (1 << opt.hg_depth) or feature_lr.w % (1 << opt.hg_depth):
+        raise ValueError("feature_lr size must be a multiple of 2^hg_depth")
+    nn, dev = _native_net(W), feature_lr.buf.device
+    ws = nn.workspace(2 * feature_lr.h, 2 * feature_lr.w, dev)
+    S = opt.num_stack_lr
+    outs = [Img(feature_lr.h, feature_lr.w, nn.last_ch, device=dev) if (keep_all or s == S - 1) else None for s in range(S)]
+    ptrs = (C.c_void_p * S)(*[o.ptr() if o is not None else None for o in outs])
+    ss, sides = _lent_streams(opt.hg_depth)   # (forked from and joined to the call's stream by events inside the call)
+    native.check(native.lib().surs_encoder_filter_lr(C.byref(nn.net), feature_lr.ptr(), feature_lr.h, feature_lr.w, feature_lr.ld, ptrs,
+                                                     native._ptr(ws), ws.numel(), C.byref(ss) if ss is not None else None, native._stream()))
+    return [o for o in outs if o is not None]
 
 
 LRELU = dict(act=1, slope=0.2)
@@ -386,6 +544,8 @@ def _run_graphed(key, build, static_in=None, x=None):
 
 def super_res_g(W, x, want_image=True):
     """super_res through a captured graph where that is allowed (see above), eagerly otherwise."""
+    if native_enabled(W):
+        return super_res_native(W, x, want_image=want_image)
     if not _graph_ok(W):
         return super_res(W, x, want_image=want_image)
     key = ("sr", W.serial, x.h, x.w, x.c, want_image, _flags())
@@ -413,6 +573,8 @@ def persistent(img):
 def filter_lr_g(W, feature_lr, keep_all=False):
     """filter_lr through a graph captured on the ADDRESS of its input (the super-resolution graph's feature_lr buffer, or a
     caller's persistent one): an input at a new address is captured anew, at most GRAPH_CACHE graphs are kept."""
+    if native_enabled(W):
+        return filter_lr_native(W, feature_lr, keep_all=keep_all)
     if not _graph_ok(W):
         return filter_lr(W, feature_lr, keep_all=keep_all)
     key = ("lr", W.serial, _addr_key(feature_lr), keep_all, _flags())

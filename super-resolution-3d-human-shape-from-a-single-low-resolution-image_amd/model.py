@@ -150,7 +150,7 @@ class SuRSNet:
         self._last_images = images   # (kept for reencode_wide: the retry after an f16 overflow)
         self._sharded_encode = None  # (features about to be made by THIS device's encoder: dist.encode_sharded's record is stale)
         # (one view: through the captured HIP graph - encoder.graphed; several views would share the graph's output buffers)
-        sr = encoder.super_res_g if images.shape[0] == 1 else encoder.super_res
+        sr = encoder.super_res_g if (images.shape[0] == 1 or encoder.native_enabled(W)) else encoder.super_res
         outs = [sr(W, _as_img(images[v:v + 1])) for v in range(images.shape[0])]
         cat = lambda i: torch.cat([_as_nchw_view(o[i]) for o in outs], 0) if len(outs) > 1 else _as_nchw_view(outs[0][i])
         self.im_SR, self.feature_lr, self.feature_hr = cat(0), cat(1), cat(2)
@@ -160,7 +160,7 @@ class SuRSNet:
 
     def filter_lr(self, images):
         W = self._encoder_weights()
-        flr = encoder.filter_lr_g if images.shape[0] == 1 else encoder.filter_lr
+        flr = encoder.filter_lr_g if (images.shape[0] == 1 or encoder.native_enabled(W)) else encoder.filter_lr
         per_view = [flr(W, _as_img(images[v:v + 1]), keep_all=self.training) for v in range(images.shape[0])]
         n_out = len(per_view[0])
         self._sharded_encode = None

@@ -173,7 +173,6 @@ def test_query_facade_takes_grid_chunks_through_the_column_kernels(net, monkeypa
     a = 61 * R * R + 17 * R + 5
     chunk = oracle.grid_points(R, [-0.5] * 3, [0.5] * 3, a, a + 50000)
     pts = torch.from_numpy(chunk[None]).to("cuda:0")
-    net._runs_refused = 0      # (after four refusals in a row - the random samples of the tests above - only every 8th call asks)
     calls = []
     real = native.query_points_columns
     monkeypatch.setattr(native, "query_points_columns", lambda *a_, **k_: calls.append(real(*a_, **k_)) or calls[-1])
@@ -182,19 +181,20 @@ def test_query_facade_takes_grid_chunks_through_the_column_kernels(net, monkeypa
     phr, plr = [t.detach().cpu().numpy()[0, 0] for t in net.get_preds()]
     assert len(calls) == 1 and calls[0] is not None
     monkeypatch.setenv("SURS_POINT_RUNS", "0")
-    net._runs_refused = 0
     net.query_mr(pts.clone(), calib)
     net.query_sr(pts.clone(), calib)
     qhr, qlr = [t.detach().cpu().numpy()[0, 0] for t in net.get_preds()]
     assert len(calls) == 2 and calls[1] is None
-    # callers without runs stop paying for the run finder: four refusals, then one question in eight calls
+    # which evaluator an array gets is a function of the array alone: the run finder looks at every array, refusals
+    # leave no state behind
     monkeypatch.delenv("SURS_POINT_RUNS")
     rnd = torch.from_numpy(weights.synthetic_points(4096, seed=5)[None]).to("cuda:0")
-    net._runs_refused = 0
     del calls[:]
-    for _ in range(20):
+    for _ in range(6):
         net.query_mr(rnd, calib)
-    assert len(calls) == 6 and all(c is None for c in calls)       # calls 1 - 4, 9, 17
+    assert len(calls) == 6 and all(c is None for c in calls)
+    net.query_mr(pts, calib)
+    assert len(calls) == 7 and calls[6] is not None
     assert np.abs(phr - qhr).max() < 1e-4 and np.abs(plr - qlr).max() < 1e-4
     ohr, olr = oracle.query(common.state_dict(), chunk[:, ::17], common.CALIB, fl, fh, 1024, 200.0)
     assert np.abs(phr[::17] - ohr).max() < 1e-4 and np.abs(plr[::17] - olr).max() < 1e-4
