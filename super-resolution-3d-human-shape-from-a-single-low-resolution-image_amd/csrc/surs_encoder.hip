@@ -59,6 +59,7 @@ struct ConvArgs {
     // group gn2_g0 + (channel / gn2_cg), rows gn2_pitch slots apart, one slot per pixel tile.
     float *y2; int y2_ld;
     double *gn_out2; int gn2_pitch, gn2_cg, gn2_g0;
+    int fast_offsets;   // every output / residual element offset fits 32 bits (set by launch_conv_x3_cfg)
 };
 
 template <int KS, int STRIDE, int TR, int NT>
@@ -529,57 +530,115 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     double s2_s[NJ], s2_ss[NJ];   // ... and of the values of the second output
 #pragma unroll
     for (int j = 0; j < NJ; ++j) st_s[j] = st_ss[j] = s2_s[j] = s2_ss[j] = 0.0;
+    // A tile that lies inside the map and the channel range (every tile of the encoder's maps: their sizes are multiples of the tile)
+    // takes the straight form: one 32-bit element offset per output row, the 16 pixel columns of a register tile at scalar multiples
+    // of the pitch, no per-element bounds.  (Until round 6 every tile ran the guarded form below: 8 000 instructions - 64-bit
+    // multiplies and two branches per element - against 2 100 for the whole multiply loop, 15 - 38 % of a workgroup's cycles.)
+    // The same operations per element in the same order: the same bits.
+    const bool full = ox0 + TC <= a.wo && oy0 + TR <= a.ho && n0 + NT3 <= a.cout;   // (uniform)
+    if (full && a.fast_offsets) {
+        const float sl = a.act == 1 ? a.slope : 1.0f;   // (x > 0 ? x : 1 * x: the identity, bit for bit, where there is no activation)
+        // (one instantiation per combination of outputs: the flags are compile-time inside, so that the 64 elements of a wave's
+        //  tiles are straight-line code)
+        auto emit = [&](auto dual_c, auto res_c, auto st_c, auto st2_c) {
+            constexpr bool DUAL = decltype(dual_c)::value, RES = decltype(res_c)::value, ST = decltype(st_c)::value, ST2 = decltype(st2_c)::value;
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int oy = oy0 + wave * RPW + r;
-        if (oy >= a.ho) continue;
+            for (int r = 0; r < RPW; ++r) {
+                const unsigned pix0 = (unsigned)((oy0 + wave * RPW + r) * a.wo + ox0 + 4 * kh);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int co = n0 + j * 32 + li;
-            if (co >= a.cout) continue;
-            const float b = a.bias ? a.bias[co] : 0.f;
-            // the tile's 16 residual values first, all in flight together: read one by one between the stores (which the compiler
-            // must keep in order: res and y may alias) every element cost a memory round trip
-            float rv[16];
-            if (a.res) {
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned co = (unsigned)(n0 + j * 32 + li);
+                    const float b = a.bias ? a.bias[co] : 0.f;
+                    float rv[16];
+                    if (RES) {
+                        const float *rp = a.res + (pix0 * (unsigned)a.res_ld + co);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) rv[q] = rp[((q & 3) + 8 * (q >> 2)) * a.res_ld];
+                    }
+                    float *yp = a.y + (pix0 * (unsigned)a.y_ld + co);
+                    float *y2p = DUAL ? a.y2 + (pix0 * (unsigned)a.y2_ld + co) : nullptr;
+                    const bool have_y = !DUAL || a.y != nullptr;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int pc = (q & 3) + 8 * (q >> 2);
+                        float t = acc[0][r][j][q];
+                        if (NA == 3) t = (acc[0][r][j][q] + acc[1][r][j][q]) + acc[2][r][j][q];
+                        t += b;
+                        t = t > 0.f ? t : sl * t;
+                        if (DUAL) {   // the value to y (the next convolution's input), value + res to y2 (the block's output slice)
+                            if (have_y) yp[pc * a.y_ld] = t;
+                            if (ST) {
+                                const double d = (double)t;
+                                st_s[j] += d;
+                                st_ss[j] += d * d;
+                            }
+                            const float u = t + rv[q];
+                            y2p[pc * a.y2_ld] = u;
+                            if (ST2) {
+                                const double d = (double)u;
+                                s2_s[j] += d;
+                                s2_ss[j] += d * d;
+                            }
+                        } else {
+                            if (RES) t += rv[q];
+                            yp[pc * a.y_ld] = t;
+                            if (ST) {
+                                const double d = (double)t;
+                                st_s[j] += d;
+                                st_ss[j] += d * d;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (dual) {
+            if (stats) { if (stats2) emit(T(), T(), T(), T()); else emit(T(), T(), T(), F()); }
+            else       { if (stats2) emit(T(), T(), F(), T()); else emit(T(), T(), F(), F()); }
+        } else if (a.res) {
+            if (stats) emit(F(), T(), T(), F()); else emit(F(), T(), F(), F());
+        } else {
+            if (stats) emit(F(), F(), T(), F()); else emit(F(), F(), F(), F());
+        }
+    } else {
+        // the guarded form (ragged tiles; the second output is not made here: its callers hand over whole tiles only)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int oy = oy0 + wave * RPW + r;
+            if (oy >= a.ho) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int co = n0 + j * 32 + li;
+                if (co >= a.cout) continue;
+                const float b = a.bias ? a.bias[co] : 0.f;
+                // the tile's 16 residual values first, all in flight together: read one by one between the stores (which the compiler
+                // must keep in order: res and y may alias) every element cost a memory round trip
+                float rv[16];
+                if (a.res) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                        rv[q] = ox < a.wo ? a.res[((size_t)oy * a.wo + ox) * a.res_ld + co] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                    rv[q] = ox < a.wo ? a.res[((size_t)oy * a.wo + ox) * a.res_ld + co] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int ox = ox0 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                if (ox >= a.wo) continue;
-                float t = acc[0][r][j][q];
-                if (NA == 3) t = (acc[0][r][j][q] + acc[1][r][j][q]) + acc[2][r][j][q];
-                t += b;
-                if (a.act == 1) t = t > 0.f ? t : a.slope * t;
-                const size_t pix = (size_t)oy * a.wo + ox;
-                if (dual) {
-                    // the value to y (the next convolution's input), value + res to y2 (the block's output slice)
-                    if (a.y) a.y[pix * a.y_ld + co] = t;
+                    if (ox >= a.wo) continue;
+                    float t = acc[0][r][j][q];
+                    if (NA == 3) t = (acc[0][r][j][q] + acc[1][r][j][q]) + acc[2][r][j][q];
+                    t += b;
+                    if (a.act == 1) t = t > 0.f ? t : a.slope * t;
+                    const size_t pix = (size_t)oy * a.wo + ox;
+                    if (a.res) t += rv[q];
+                    a.y[pix * a.y_ld + co] = t;
                     if (stats) {
                         const double d = (double)t;
                         st_s[j] += d;
                         st_ss[j] += d * d;
                     }
-                    const float u = t + rv[q];
-                    a.y2[pix * a.y2_ld + co] = u;
-                    if (stats2) {
-                        const double d = (double)u;
-                        s2_s[j] += d;
-                        s2_ss[j] += d * d;
-                    }
-                    continue;
-                }
-                if (a.res) t += rv[q];
-                a.y[pix * a.y_ld + co] = t;
-                if (stats) {
-                    const double d = (double)t;
-                    st_s[j] += d;
-                    st_ss[j] += d * d;
                 }
             }
         }
@@ -630,7 +689,12 @@ static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, h
     if (attr.first())
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(ceil_div(a.wo, TC), ceil_div(a.ho, TR), ceil_div(a.cout_pad, NT3));
-    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3, NP>), grid, dim3(256), lds, st, a, wsplit);
+    ConvArgs b = a;
+    {
+        const long long npix = (long long)a.ho * a.wo, lim = 1ll << 31;
+        b.fast_offsets = npix * (a.y ? a.y_ld : 1) < lim && npix * (a.res ? a.res_ld : 1) < lim && npix * (a.y2 ? a.y2_ld : 1) < lim;
+    }
+    hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3, NP>), grid, dim3(256), lds, st, b, wsplit);
     SURS_LAUNCH_CHECK();
 #ifdef SURS_CONV_TRACE
     if (getenv("SURS_CONV_TRACE")) {
@@ -788,6 +852,49 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
     double st_s[CT], st_ss[CT];
 #pragma unroll
     for (int j = 0; j < CT; ++j) st_s[j] = st_ss[j] = 0.0;
+    // a wave whose 64 pixels and 32 CT channels all exist (every wave of the encoder's maps) takes the straight form: 32-bit element
+    // offsets, no per-element bounds, the output flags compile-time (as in conv_x3_kernel: the guarded form below was 5 600 of the
+    // kernel's 6 800 instructions)
+    const bool full = p0 + 64 <= npix && n0 + 32 * CT <= a.cout && a.fast_offsets;   // (wave-uniform)
+    if (full) {
+        const float sl = a.act == 1 ? a.slope : 1.0f;
+        auto emit = [&](auto res_c, auto st_c) {
+            constexpr bool RES = decltype(res_c)::value, ST = decltype(st_c)::value;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned pix0 = (unsigned)(p0 + 32 * t + 4 * kh);
+#pragma unroll
+                for (int j = 0; j < CT; ++j) {
+                    const unsigned co = (unsigned)(n0 + 32 * j + li);
+                    const float b = a.bias ? a.bias[co] : 0.f;
+                    float rv[16];
+                    if (RES) {
+                        const float *rp = a.res + (pix0 * (unsigned)a.res_ld + co);
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) rv[q] = rp[((q & 3) + 8 * (q >> 2)) * a.res_ld];
+                    }
+                    float *yp = a.y + (pix0 * (unsigned)a.y_ld + co);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        float v = acc[t][j][q] + b;
+                        v = v > 0.f ? v : sl * v;
+                        if (RES) v += rv[q];
+                        yp[((q & 3) + 8 * (q >> 2)) * a.y_ld] = v;
+                        if (ST) {
+                            const double d = (double)v;
+                            st_s[j] += d;
+                            st_ss[j] += d * d;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // (one tile's residual loads in flight at a time: registers)
+                }
+            }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (a.res) { if (stats) emit(T(), T()); else emit(T(), F()); }
+        else       { if (stats) emit(F(), T()); else emit(F(), F()); }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -818,6 +925,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_x2_kernel(ConvArgs a, const un
                 }
             }
         }
+    }
     if (stats) {
         // as in conv_x3_kernel: lanes, then the two pixel halves of the workgroup (waves ph = 0, 1) through LDS; one slot per
         // 128-pixel block (blockIdx.x)
@@ -852,10 +960,12 @@ static int launch_conv1x1_x2(const ConvArgs &a, const unsigned short *wsplit, hi
     SURS_REQUIRE(a.cin_pad <= 1024, "split-operand convolution: at most 1024 input channels");
     const long long npix = (long long)a.h * a.w;
     const unsigned gx = (unsigned)((npix + 127) / 128);
+    ConvArgs b = a;
+    b.fast_offsets = npix * a.y_ld < (1ll << 31) && npix * (a.res ? a.res_ld : 1) < (1ll << 31);
     if (a.cout_pad % 256 == 0)
-        hipLaunchKernelGGL(conv1x1_x2_kernel<4>, dim3(gx, a.cout_pad / 256), dim3(256), 0, st, a, wsplit);
+        hipLaunchKernelGGL(conv1x1_x2_kernel<4>, dim3(gx, a.cout_pad / 256), dim3(256), 0, st, b, wsplit);
     else
-        hipLaunchKernelGGL(conv1x1_x2_kernel<1>, dim3(gx, a.cout_pad / 64), dim3(256), 0, st, a, wsplit);
+        hipLaunchKernelGGL(conv1x1_x2_kernel<1>, dim3(gx, a.cout_pad / 64), dim3(256), 0, st, b, wsplit);
     SURS_LAUNCH_CHECK();
     return 0;
 }
@@ -1479,6 +1589,11 @@ extern "C" int surs_conv2d_nhwc_gn_sum(int parts, const float *x, int h, int w, 
     const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
     const bool big = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= conv_big_min_wg();
     const int slots = ceil_div(a.wo, TC) * ceil_div(a.ho, big ? 8 : 4);
+    // (the kernel makes the second output in its whole-tile epilogue only)
+    SURS_REQUIRE(a.wo % TC == 0 && a.ho % (big ? 8 : 4) == 0 && cout % (big ? 64 : 32) == 0 &&
+                 (long long)h * w * (y2_ld > res_ld ? y2_ld : res_ld) < (1ll << 31) && (!y || (long long)h * w * y_ld < (1ll << 31)),
+                 "the sum in the epilogue needs whole tiles: width %% 32, height %% %d, cout %% %d (use surs_conv2d_nhwc_gn + surs_add3_gn)",
+                 big ? 8 : 4, big ? 64 : 32);
     if (gn_out) {
         const int cg = cout / 32;
         SURS_REQUIRE(y && gn_out->sums && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0 && slots <= gn_out->pitch,

@@ -250,8 +250,10 @@ Map conv_block(Run &r, const SursConvBlock &b, const Map &x, bool want_stats) {
         void *scratch = r.a->take(surs_groupnorm_scratch_bytes());
         if (!r.dry && !r.rc) r.fail(surs_groupnorm_coeffs_ws(t.p, t.h * t.w, t.c, t.ld, 32, 1e-5f, g.gamma, g.beta, sc, sh, scratch, r.st));
     };
+    // (the second output is made by the kernels' whole-tile epilogue: maps of whole 8-row x 32-column x 64-channel tiles - every map
+    //  of a 512 x 512 image's hourglass; smaller ones take the separate sum)
     const bool sum_in_conv = fused && !(r.net->flags & SURS_ENC_SEPARATE_SUM) && b.conv[0].ksize == 3 && b.conv[1].ksize == 3 &&
-                             b.conv[2].ksize == 3;
+                             b.conv[2].ksize == 3 && x.w % 32 == 0 && x.h % 8 == 0 && c % 256 == 0;
     if (sum_in_conv) {
         const int cap = ((x.w + 31) / 32) * ((x.h + 3) / 4), cg = c / 32;
         Map raw1 = r.map(x.h, x.w, c / 2), raw2 = r.map(x.h, x.w, c / 4);
@@ -277,7 +279,7 @@ Map conv_block(Run &r, const SursConvBlock &b, const Map &x, bool want_stats) {
         if (!S) out.set_stats(nullptr, 0);
         return out;
     }
-    if (fused && x.st.sums) {
+    if (fused && x.st.sums && x.st.g1 == 0) {
         conv_gn(r, x, b.conv[0], o1, &b.bn[0], true);
         conv_gn(r, o1, b.conv[1], o2, &b.bn[1], true);
         conv_gn(r, o2, b.conv[2], o3, &b.bn[2], false);

@@ -69,7 +69,7 @@ def test_native_sequencing_equals_host_sequencing_bit_for_bit(monkeypatch, H, tr
     assert torch.equal(_hwc(f_lr), _hwc(ref_sr[1])) and torch.equal(_hwc(f_hr), _hwc(ref_sr[2]))
 
 
-@pytest.mark.parametrize("H,training", [(64, True), (512, False)])
+@pytest.mark.parametrize("H,training", [(64, True), (128, True), (512, False)])
 def test_sum_in_the_convolutions_epilogues_against_the_separate_sum(monkeypatch, H, training):
     from surs_amd import encoder, weights
     from surs_amd.model import _as_img
@@ -94,7 +94,7 @@ def test_conv_with_the_sum_in_its_epilogue_against_conv_then_add(monkeypatch):
     from surs_amd import native, prng
     from surs_amd import _lib
     import gpu_common as g
-    h, w, cin, cout, ctot = 40, 72, 64, 32, 128    # ragged tiles; this convolution makes channels [64, 96) of a 128-channel sum
+    h, w, cin, cout, ctot = 40, 96, 64, 32, 128    # whole tiles of 4 rows x 32 columns; channels [64, 96) of a 128-channel sum
     x = g.upload_nhwc(prng.uniform("sx", 1, (cin, h, w), -1, 1))
     xin = g.upload_nhwc(prng.uniform("sr", 2, (ctot, h, w), -1, 1))
     wt = prng.uniform("sw", 3, (cout, cin, 3, 3), -0.2, 0.2)
@@ -127,6 +127,13 @@ def test_conv_with_the_sum_in_its_epilogue_against_conv_then_add(monkeypatch):
     got2 = sb2.view(32, cap, 2)[16:24, :n].sum(1).cpu().numpy()
     assert np.allclose(got2, want, rtol=1e-12, atol=1e-9)
     assert float(sb2.view(32, cap, 2)[:16].abs().max()) == 0.0 and float(sb2.view(32, cap, 2)[24:].abs().max()) == 0.0
+    # ragged tiles are refused (the second output is made by the whole-tile epilogue): callers take conv + add there
+    from surs_amd._lib import SursError
+    with pytest.raises(SursError, match="whole tiles"):
+        native.check(native.lib().surs_conv2d_nhwc_gn_sum(2, x0.ptr(), h - 1, w, cin, x0.ld, native._ptr(cw.w3), None, C.byref(s_in), None, None,
+                                                          native._ptr(gam), native._ptr(bet), 1e-5, raw.ptr(), cout, raw.ld, C.byref(s_out),
+                                                          xin.slice(64, cout).ptr(), xin.ld, out.slice(64, cout).ptr(), out.ld, native._ptr(sb2),
+                                                          cap, 64 // 4, 4, C.byref(slots), native._stream()))
 
 
 def test_facade_takes_the_native_encoder_and_falls_back_where_it_does_not_apply(monkeypatch):
