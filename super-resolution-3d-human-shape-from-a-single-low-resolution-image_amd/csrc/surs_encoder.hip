@@ -1390,6 +1390,112 @@ __global__ __launch_bounds__(VS_THREADS) void vec4_stats_kernel(Op op, int c, do
     }
 }
 
+// Bicubic x2 with the statistics of its output, a 2 x 2 block of output pixels (x 4 channels) per item: the four outputs' 4 x 4
+// neighbourhoods lie in ONE 5 x 5 window of the input (floor(s (2 i + 1)) - floor(s 2 i) is 0 or 1 for a scale s <= 1/2), read once -
+// 25 loads for four outputs instead of 64 (the one-output form is bound by its loads: 62 - 79 us per 256^2 x 256 map, a twelfth of a
+// stack of the hourglass).  Every output is the SAME expression as BicubicUp2Op::compute - the horizontal sums r = sum_b cx[b] v[b] in
+// order, then sum_a cy[a] r[a] in order, then addend + acc - on the same (clamped) input pixels: the same bits.  Statistics as in
+// vec4_stats_kernel (a thread keeps its channel quad; the fold is the same fixed tree).
+constexpr int BB_THREADS = 512;   // (256 registers per lane: the window's ten horizontal sums stay in registers)
+__global__ __launch_bounds__(BB_THREADS) void bicubic_block_stats_kernel(BicubicUp2Op op, double *__restrict__ partial) {
+    __shared__ double red[BB_THREADS][8];
+    const int tid = threadIdx.x, c = op.c, c4 = c / 4, cg = c / 32, ppl = BB_THREADS / c4;
+    const int h = op.h, w = op.w, ho = 2 * h, wo = 2 * w;
+    const unsigned n = (unsigned)h * w * c4;   // one item per input pixel position = one 2 x 2 output block
+    const float sy = op.align_corners ? (ho > 1 ? (float)(h - 1) / (float)(ho - 1) : 0.f) : 0.5f;
+    const float sx = op.align_corners ? (wo > 1 ? (float)(w - 1) / (float)(wo - 1) : 0.f) : 0.5f;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const unsigned stride = gridDim.x * (unsigned)BB_THREADS;
+    for (unsigned i = blockIdx.x * (unsigned)BB_THREADS + tid; i < n; i += stride) {
+        const unsigned blk = i / c4, q = i - blk * c4;
+        const int by = (int)(blk / w), bx = (int)(blk - (unsigned)by * w);
+        int iy[2], ix[2];
+        float cy[2][4], cx[2][4];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int oy = 2 * by + d, ox = 2 * bx + d;
+            const float ry = op.align_corners ? sy * (float)oy : sy * ((float)oy + 0.5f) - 0.5f;
+            const float rx = op.align_corners ? sx * (float)ox : sx * ((float)ox + 0.5f) - 0.5f;
+            iy[d] = (int)floorf(ry);
+            ix[d] = (int)floorf(rx);
+            cubic_coeffs(ry - (float)iy[d], cy[d]);
+            cubic_coeffs(rx - (float)ix[d], cx[d]);
+        }
+        const int dy = iy[1] - iy[0], dx = ix[1] - ix[0];   // 0 or 1
+        // horizontal sums of the window's five rows for both output columns
+        f32x4 r[5][2];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int yy = min(max(iy[0] - 1 + k, 0), h - 1);
+            const float *rowp = op.x + (size_t)yy * w * op.x_ld + 4 * q;
+            f32x4 v[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) v[m] = *reinterpret_cast<const f32x4 *>(rowp + (size_t)min(max(ix[0] - 1 + m, 0), w - 1) * op.x_ld);
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 u = dx ? v[b + 1] : v[b];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[e] += cx[0][b] * v[b][e];
+                    r1[e] += cx[1][b] * u[e];
+                }
+            }
+            r[k][0] = r0;
+            r[k][1] = r1;
+        }
+#pragma unroll
+        for (int d = 0; d < 2; ++d)        // output row 2 by + d: window rows a + (d ? dy : 0)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {  // output column 2 bx + g
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 rr = (d && dy) ? r[a + 1][g] : r[a][g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += cy[d][a] * rr[e];
+                }
+                const size_t pix = (size_t)(2 * by + d) * wo + (2 * bx + g);
+                if (op.addend) {
+                    const f32x4 ad = *reinterpret_cast<const f32x4 *>(op.addend + pix * op.add_ld + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = ad[e] + acc[e];
+                }
+                *reinterpret_cast<f32x4 *>(op.y + pix * op.y_ld + 4 * q) = acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double v = acc[e];
+                    s[e] += v;
+                    ss[e] += v * v;
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid][k] = s[k];
+        red[tid][4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int g = tid >> 3, sub = tid & 7;
+        double S = 0, SS = 0;
+        for (int l = sub; l < ppl; l += 8)
+            for (int chn = g * cg; chn < (g + 1) * cg; ++chn) {
+                S += red[l * c4 + chn / 4][chn % 4];
+                SS += red[l * c4 + chn / 4][4 + chn % 4];
+            }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            S += __shfl_xor(S, o);
+            SS += __shfl_xor(SS, o);
+        }
+        if (sub == 0) {
+            partial[((size_t)g * gridDim.x + blockIdx.x) * 2 + 0] = S;
+            partial[((size_t)g * gridDim.x + blockIdx.x) * 2 + 1] = SS;
+        }
+    }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float *__restrict__ x, int c, size_t hw, float *__restrict__ y, int y_ld) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hw * c) return;
@@ -1776,6 +1882,22 @@ extern "C" int surs_bicubic_up2_gn(const float *x, int h, int w, int c, int x_ld
     SURS_REQUIRE(x && y && h > 0 && w > 0, "bad argument");
     SURS_REQUIRE(c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (!addend || vec4_fits(addend, add_ld)),
                  "the statistics form needs 16-byte aligned rows");
+    // the 2 x 2-block form (a quarter of the items, 25 loads for four outputs): the same bits per output; surs_set_option-free switch
+    // for A/B timing: SURS_BICUBIC_BLOCK=0
+    static const bool block = !(getenv("SURS_BICUBIC_BLOCK") && atoi(getenv("SURS_BICUBIC_BLOCK")) == 0);
+    if (block && (long long)h * w * (c / 4) < (1ll << 32)) {
+        SURS_REQUIRE(gn_out && gn_out_slots && gn_out_capacity >= 1, "null statistics buffer");
+        SURS_REQUIRE(c % 32 == 0 && c <= 1024 && (c & (c - 1)) == 0, "GroupNorm(32) statistics: the channel count must be a power of two in [32, 1024]");
+        const size_t items = (size_t)h * w * (c / 4), want = (items + BB_THREADS - 1) / BB_THREADS;
+        size_t nn = want;
+        if (nn > (size_t)gn_out_capacity) nn = (size_t)gn_out_capacity;
+        if (nn > (size_t)GN_SPLIT) nn = (size_t)GN_SPLIT;
+        *gn_out_slots = (int)nn;
+        hipLaunchKernelGGL(bicubic_block_stats_kernel, dim3((unsigned)nn), dim3(BB_THREADS), 0, as_stream(stream),
+                           BicubicUp2Op{x, h, w, c, x_ld, align_corners, addend, add_ld, y, y_ld}, gn_out);
+        SURS_LAUNCH_CHECK();
+        return 0;
+    }
     return launch_vec4_stats(BicubicUp2Op{x, h, w, c, x_ld, align_corners, addend, add_ld, y, y_ld}, (size_t)4 * h * w * (c / 4), c, gn_out,
                              gn_out_capacity, gn_out_slots, stream);
 }

@@ -191,7 +191,9 @@ def test_pool_and_bicubic_leave_groupnorm_statistics(env):
     add = prng.uniform("sa", 9, (128, 72, 104), -1, 1)
     X, A = _img(env, x), _img(env, add)
     for got, plain in ((nat.avgpool2(X, want_stats=True), nat.avgpool2(X)),
-                       (nat.bicubic_up2(X, True, addend=A, want_stats=True), nat.bicubic_up2(X, True, addend=A))):
+                       (nat.bicubic_up2(X, True, addend=A, want_stats=True), nat.bicubic_up2(X, True, addend=A)),
+                       # (the statistics form computes 2 x 2 blocks of outputs from one 5 x 5 window: the same bits per output)
+                       (nat.bicubic_up2(X, False, want_stats=True), nat.bicubic_up2(X, False))):
         assert plain.stats is None and got.stats is not None and 0 < got.stats.slots <= 512
         v = _chw(got)
         assert np.array_equal(v, _chw(plain))
