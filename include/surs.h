@@ -63,6 +63,15 @@ const char *surs_last_error(void);
 /* number of compute units / gcn arch name of the current device (arch_out: >= 32 bytes, HOST) */
 int surs_device_info(int *cu_count, char *arch_out);
 
+/* Options: every experiment / A-B switch of the library by name, in one table (csrc/surs_api.cpp) - nothing else in the library reads
+ * the environment.  An option's environment variable (SURS_<NAME>; surs_set_option accepts either spelling) is read ONCE, when the
+ * table is first used, as its initial value; surs_set_option changes it at any time, process-wide.  surs_option_name(i) /
+ * surs_option_help(i), i = 0, 1, ... until NULL, list them.  Defaults are the product's configuration: none of them needs setting. */
+int surs_set_option(const char *name, int value);
+int surs_get_option(const char *name, int *value);
+const char *surs_option_name(int index);
+const char *surs_option_help(int index);
+
 /* ------------------------------------------------------------------ encoder primitives */
 
 /* y[:, :, 0:cout] (pitch y_ld) = act( conv_k(pre(x))[...] + bias ) (+ residual)

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SURS_LIB_PATH") or os.path.join(_HERE, "libsurs_hip.so")   # override: timing experiments only
+from . import settings  # noqa: E402
+
+LIB_PATH = settings.get("SURS_LIB_PATH") or os.path.join(_HERE, "libsurs_hip.so")   # override: timing experiments only
 _lib = None
 
 F32, BF16, F16, F32_GEMM = 0, 1, 2, 3
@@ -83,6 +85,10 @@ _SIGS = {
     "surs_abi_version": (C.c_int, []),
     "surs_last_error": (C.c_char_p, []),
     "surs_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p]),
+    "surs_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "surs_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "surs_option_name": (C.c_char_p, [C.c_int]),
+    "surs_option_help": (C.c_char_p, [C.c_int]),
     "surs_conv2d_nhwc": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _i, _vp]),
     "surs_conv_pack_weights": (_sz, [_vp, _i, _i, _i, _vp]),
     "surs_groupnorm_coeffs": (C.c_int, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -48,6 +48,16 @@ inline int fail(int code, const char *fmt, ...) {
 #define SURS_ISA_PIN(v) do { } while (0)
 #endif
 
+// Library options (include/surs.h: surs_set_option / surs_get_option): every experiment / A-B switch of the library, in ONE table
+// (csrc/surs_api.cpp) instead of getenv calls spread over the kernels' launch code.  The environment variable of an option is
+// read once, when the table is first used, as the option's initial value; surs_set_option changes it at any time.
+enum Opt {
+    OPT_GEMM_X3, OPT_GEMM_BIG, OPT_SPLIT_PARTS, OPT_GEMM_WAVES, OPT_GRID_F32_COLUMNS, OPT_GRID_KERNEL, OPT_GRID_F32_KERNEL, OPT_R_PARTS,
+    OPT_GRID_F32_PASSES, OPT_CONV_BIG_MIN_WG, OPT_BICUBIC_BLOCK, OPT_MC_EMIT_RECLASSIFY, OPT_POINT_RUNS_SPECULATE, OPT_CONV_TRACE,
+    OPT_GEMM_TRACE, OPT_V3_TRACE, OPT_COUNT
+};
+int option(Opt id);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 constexpr int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -697,7 +697,7 @@ static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, h
     hipLaunchKernelGGL((conv_x3_kernel<KS, STRIDE, TR, NT3, NP>), grid, dim3(256), lds, st, b, wsplit);
     SURS_LAUNCH_CHECK();
 #ifdef SURS_CONV_TRACE
-    if (getenv("SURS_CONV_TRACE")) {
+    if (option(OPT_CONV_TRACE)) {
         unsigned long long t[8];
         SURS_HIP_CHECK(hipStreamSynchronize(st));
         SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_conv_trace), sizeof(t)));
@@ -722,11 +722,9 @@ extern "C" int surs_conv_tile_scale(int num, int den) {
     return 0;
 }
 
-// workgroups of the 8-row x 64-channel tile from which a launch takes it (experiment knob of round 6: SURS_CONV_BIG_MIN_WG)
-static int conv_big_min_wg() {
-    static const int v = getenv("SURS_CONV_BIG_MIN_WG") ? atoi(getenv("SURS_CONV_BIG_MIN_WG")) : 512;
-    return v;
-}
+// workgroups of the 8-row x 64-channel tile from which a launch takes it (option conv_big_min_wg; measured in round 6: 256 and 128
+// instead of 512 move the 512^2 encoder by 0.1 ms - the tiles sum in different orders, so the choice is part of the bits)
+static int conv_big_min_wg() { return option(OPT_CONV_BIG_MIN_WG); }
 
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
@@ -1882,9 +1880,9 @@ extern "C" int surs_bicubic_up2_gn(const float *x, int h, int w, int c, int x_ld
     SURS_REQUIRE(x && y && h > 0 && w > 0, "bad argument");
     SURS_REQUIRE(c % 4 == 0 && vec4_fits(x, x_ld) && vec4_fits(y, y_ld) && (!addend || vec4_fits(addend, add_ld)),
                  "the statistics form needs 16-byte aligned rows");
-    // the 2 x 2-block form (a quarter of the items, 25 loads for four outputs): the same bits per output; surs_set_option-free switch
-    // for A/B timing: SURS_BICUBIC_BLOCK=0
-    static const bool block = !(getenv("SURS_BICUBIC_BLOCK") && atoi(getenv("SURS_BICUBIC_BLOCK")) == 0);
+    // the 2 x 2-block form (a quarter of the items, 25 loads for four outputs): the same bits per output (option bicubic_block = 0:
+    // the one-output form, for A/B timing)
+    const bool block = option(OPT_BICUBIC_BLOCK) != 0;
     if (block && (long long)h * w * (c / 4) < (1ll << 32)) {
         SURS_REQUIRE(gn_out && gn_out_slots && gn_out_capacity >= 1, "null statistics buffer");
         SURS_REQUIRE(c % 32 == 0 && c <= 1024 && (c & (c - 1)) == 0, "GroupNorm(32) statistics: the channel count must be a power of two in [32, 1024]");

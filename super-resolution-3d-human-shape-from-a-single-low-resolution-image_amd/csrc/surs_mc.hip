@@ -1422,7 +1422,7 @@ static int mc_range(const float *vol, int n0, int n1, int n2, long long cell_beg
     if (count_only || nactive == 0) return 0;
     if (run->n_verts > cap_verts || run->n_faces > cap_faces)
         return fail(SURS_E_CAPACITY, "output capacity too small: need %d vertices, %d faces", run->n_verts, run->n_faces);
-    static const int emit_reclassify = getenv("SURS_MC_EMIT_RECLASSIFY") ? atoi(getenv("SURS_MC_EMIT_RECLASSIFY")) : 0;   // tests
+    const int emit_reclassify = option(OPT_MC_EMIT_RECLASSIFY);   // tests
     if (2ll * nactive > list_cells || emit_reclassify)   // the sorted list would run into the count pass's codes: classify again
         hipLaunchKernelGGL(mc_emit_kernel, dim3(nb < 16384 ? nb : 16384), dim3(SCAN_THREADS), 0, st, vol, d, level, levelf, nb, bcounts, boffs,
                            goffs, alist);

@@ -56,11 +56,16 @@ struct PointSource {
     float calib[12];
     float zmul, zdiv;
     int persp;  // 1: perspective projection (lib/geometry.py:34-48): x, y divided by the projected z
+    int npts;   // mode 5: points in pts (a listed index is clamped into the array: a speculative launch of surs_query_points_columns may
+                // list more runs than this call's array holds - stale list entries -, whose results nobody reads)
 };
 
 __device__ __forceinline__ void make_point(const PointSource &s, long long t, float &px, float &py, float &pz) {
     if (s.mode == 0 || s.mode == 5) {
-        if (s.mode == 5) t = (long long)s.cols[t];
+        if (s.mode == 5) {
+            t = (long long)s.cols[t];
+            t = t < 0 ? 0 : (t >= s.npts ? s.npts - 1 : t);
+        }
         px = s.pts[t];
         py = s.pts[s.ld + t];
         pz = s.pts[2 * s.ld + t];
@@ -378,24 +383,10 @@ static Fp32Workspace carve_fp32(void *ws, long long np) {
 }
 
 // SURS_GEMM_X3=0 in the environment keeps the fp32 MFMA kernel (A/B comparisons)
-static bool gemm_use_x3() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SURS_GEMM_X3");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool gemm_use_x3() { return option(OPT_GEMM_X3) != 0; }
 
 // SURS_GEMM_BIG=0 keeps the 128 x 128 layer kernel for every layer (A/B comparisons)
-static bool gemm_use_big() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SURS_GEMM_BIG");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool gemm_use_big() { return option(OPT_GEMM_BIG) != 0; }
 
 static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const void *W3, int M, const float *X1, int K1,
                        long long ld1, const float *X2, int K2, long long ld2, const float *bias, int act, float *Y,
@@ -422,11 +413,7 @@ static int launch_gemm(hipStream_t st, bool transposed, const float *Wt, const v
 static int g_split_override = 0;   // surs_set_operand_split (process-wide)
 static thread_local int t_split_call = 0;   // SursGridOptions::operand_parts of the surs_query_grid_opt call running on this thread
 static int split_parts() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SURS_SPLIT");
-        v = (e && e[0] == 'b') ? 3 : 2;
-    }
+    const int v = option(OPT_SPLIT_PARTS) == 3 ? 3 : 2;
     // (a thread's 1 = the one-product point path, run_points_fp32 only: everything else that asks here stays fp32-grade)
     const int want = t_split_call > 1 ? t_split_call : (g_split_override ? g_split_override : v);
     return (gemm_use_x3() && gemm_use_big()) ? want : 3;
@@ -502,7 +489,7 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
         int rca = g3_set_attributes();
         if (rca) return rca;
         const int nb256 = (int)(np / 256);
-        static const int nw = getenv("SURS_GEMM_WAVES") ? atoi(getenv("SURS_GEMM_WAVES")) : 8;
+        const int nw = option(OPT_GEMM_WAVES);
         const long long yp = (long long)M * np;
         if (Ys && nw == 16)
             hipLaunchKernelGGL((gemm_x3g_kernel<16, 256, G3_SPLIT>), dim3(gemm_grid(M / 256, nb256)), dim3(1024), g3_lds_bytes(256), st, w3, M,
@@ -524,7 +511,7 @@ static int launch_gemm_s(hipStream_t st, const void *W3, int M, const unsigned s
                            (unsigned short *)nullptr, 0LL, nblocks);
     SURS_LAUNCH_CHECK();
 #ifdef SURS_GEMM_TRACE
-    if (getenv("SURS_GEMM_TRACE")) {
+    if (option(OPT_GEMM_TRACE)) {
         unsigned long long t[64];
         SURS_HIP_CHECK(hipStreamSynchronize(st));
         SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_gemm_trace), sizeof(t)));
@@ -1124,14 +1111,7 @@ extern "C" size_t surs_query_grid_workspace_bytes(int ry, int rz, int dtype) {
 }
 
 // SURS_GRID_F32=gemm keeps the fp32 sweep on the per-point layer kernels (A/B comparisons; the path of general calibrations)
-static bool grid_f32_use_columns() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SURS_GRID_F32");
-        v = (e && e[0] == 'g') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool grid_f32_use_columns() { return option(OPT_GRID_F32_COLUMNS) != 0; }
 
 static int grid_set_attributes() {
     static DeviceOnce attr;
@@ -1300,18 +1280,9 @@ struct ColumnSweep {
 // (SURS_F32): 11 (default: restated, eight waves) or 5 (dense).  Precedence: the call's SursGridOptions.kernel, then
 // surs_set_grid_kernel, then SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL, then the default.
 static void resolve_column_kernels(int kernel_call, int &kver, int &kver32) {
-    static int kver_env = -1;
-    if (kver_env < 0) {
-        const char *e = getenv("SURS_GRID_KERNEL");
-        const int v = e ? atoi(e) : 0;
-        kver_env = (v == 3 || v == 10 || v == 12) ? v : SURS_DEFAULT_GRID_KERNEL;
-    }
-    static int kver32_env = -1;
-    if (kver32_env < 0) {
-        const char *e = getenv("SURS_GRID_F32_KERNEL");
-        const int v = e ? atoi(e) : 0;
-        kver32_env = (v == 5 || v == 11) ? v : SURS_DEFAULT_GRID_F32_KERNEL;
-    }
+    const int ve = option(OPT_GRID_KERNEL), ve32 = option(OPT_GRID_F32_KERNEL);
+    const int kver_env = (ve == 3 || ve == 10 || ve == 12) ? ve : SURS_DEFAULT_GRID_KERNEL;
+    const int kver32_env = (ve32 == 5 || ve32 == 11) ? ve32 : SURS_DEFAULT_GRID_F32_KERNEL;
     const auto is32 = [](int v) { return v == 5 || v == 11; };
     kver = kver_env;
     kver32 = kver32_env;
@@ -1416,7 +1387,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
         // operand parts of this GEMM: the sweep's split (two f16 / three bf16 parts: fp32 grade) for the fp32-grade and the f16
         // kernel; ONE f16 part for the bf16 kernel - 11 significant bits, 8x what bf16 gives the rest of the classifier, a third
         // of the MFMA work, no measurable change of the bf16 sweep's error (SURS_R_PARTS=0: the split's parts there too)
-        static const int r_parts_env = getenv("SURS_R_PARTS") ? atoi(getenv("SURS_R_PARTS")) : 1;
+        const int r_parts_env = option(OPT_R_PARTS);
         const int rparts = (dtype == SURS_BF16 && r_parts_env == 1) ? 1 : parts;
         if (rparts == 1)
             hipLaunchKernelGGL(colsum_prepare_kernel<1>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
@@ -1506,7 +1477,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             // split weights (2.6 MiB), which an XCD's 4 MiB L2 holds; both together do not fit and 8 % of the stream came from
             // HBM.  Only with whole 64-voxel tiles (the hr pass reads its tile's lr occupancies back from vol_lr, which has no
             // room for the voxels beyond the column's end that the one-pass form computes and classifies on); same bits.
-            static const int passes_env = getenv("SURS_GRID_F32_PASSES") ? atoi(getenv("SURS_GRID_F32_PASSES")) : 2;
+            const int passes_env = option(OPT_GRID_F32_PASSES);
             const bool two = passes_env == 2 && items % 64 == 0 && !cs.run_tiles;
             for (int ph = two ? 1 : 0; ph <= (two ? 2 : 0); ++ph) {
                 a.phase = ph;
@@ -1572,7 +1543,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
     }
 #endif
 #ifdef SURS_V3_TRACE
-    if (trace_this && getenv("SURS_V3_TRACE")) {
+    if (trace_this && option(OPT_V3_TRACE)) {
         unsigned long long t[64];
         SURS_HIP_CHECK(hipStreamSynchronize(st));
         SURS_HIP_CHECK(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_v3_trace), sizeof(t)));
@@ -2200,14 +2171,29 @@ extern "C" int surs_query_points_columns(const float *points, long long ld, int 
     hipLaunchKernelGGL(point_runs_kernel, dim3(1), dim3(PR_THREADS), 0, st, points, points + ld, points + 2 * ld, n, tile, colstart,
                        kcount, tiles, meta);
     SURS_LAUNCH_CHECK();
-    // (the four words land in pinned memory: a copy into pageable memory is staged and costs another ~ 15 us of the call's round trip)
-    static thread_local int *host = nullptr;
-    if (!host) SURS_HIP_CHECK(hipHostMalloc((void **)&host, 4 * sizeof(int), hipHostMallocDefault));
+    // The host needs the run count (how many columns the preparation launches cover, whether the array holds runs at all).  Reading
+    // it back in the MIDDLE of the call left the GPU idle for the round trip plus the host's eight launches, every call (rounds 5's
+    // form).  A caller that sends arrays of one length - the reference's sweep loop: 50 000 consecutive grid
+    // points per call - gets the same counts (+- 1 column) call after call, so the launches are sized from the PREVIOUS call's counts
+    // (a quarter more) and enqueued at once behind the run finder; the four words - copied to pinned memory behind the run finder -
+    // are read AFTER the enqueue, when they have long arrived: the wait is on an event recorded right behind the copy, not on the
+    // stream.  The kernels take the true counts from device memory where it matters (the work-item count of the column kernel); rows
+    // of the preparation beyond the true run count are computed from stale list entries (clamped into the array) and never read.
+    // If the array holds more runs than guessed the batch runs again with the true counts (same stream: it overwrites); if it holds
+    // no runs the call reports 0 columns as before and the caller's layer kernels overwrite the outputs.
+    struct Speculation {
+        int *host = nullptr;
+        hipEvent_t ev = nullptr;
+        int n = -1, tile = 0;
+        long long ncols = 0, ntiles = 0;
+    };
+    static thread_local Speculation sp;
+    if (!sp.host) SURS_HIP_CHECK(hipHostMalloc((void **)&sp.host, 4 * sizeof(int), hipHostMallocDefault));
+    if (!sp.ev) SURS_HIP_CHECK(hipEventCreateWithFlags(&sp.ev, hipEventDisableTiming));
+    int *host = sp.host;
     host[0] = host[1] = host[2] = host[3] = 0;
     SURS_HIP_CHECK(hipMemcpyAsync(host, meta, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    SURS_HIP_CHECK(hipStreamSynchronize(st));
-    const long long ncols = host[0];
-    if (ncols <= 0 || ncols * pr_min_run(tile) > n || ncols > COL_BATCH || (host[2] && host[3])) return 0;
+    SURS_HIP_CHECK(hipEventRecord(sp.ev, st));
     ColumnSweep cs;
     cs.st = st;
     cs.blob = (const char *)mlp_blob;
@@ -2226,7 +2212,6 @@ extern "C" int surs_query_points_columns(const float *points, long long ld, int 
     cs.run_z = points + 2 * ld;
     cs.run_tiles = tiles;
     cs.run_ntiles = (const unsigned *)(meta + 1);
-    cs.run_ntiles_host = host[1];
     if ((rc = grid_set_attributes())) return rc;
     PointSource src;
     memset(&src, 0, sizeof(src));
@@ -2234,8 +2219,28 @@ extern "C" int surs_query_points_columns(const float *points, long long ld, int 
     src.pts = points;
     src.ld = ld;
     src.cols = colstart;
+    src.npts = n;
     fill_calib(src, calib, zmul, zdiv);
-    if ((rc = run_column_batch(cs, src, ncols, PR_CAP, 1, kcount, nullptr, pred_hr, pred_lr, false))) return rc;
+    const bool speculate = option(OPT_POINT_RUNS_SPECULATE) != 0;
+    long long guessed = 0;
+    if (speculate && sp.n == n && sp.tile == tile && sp.ncols > 0) {
+        guessed = sp.ncols + sp.ncols / 4 + 8;
+        if (guessed > COL_BATCH) guessed = COL_BATCH;
+        cs.run_ntiles_host = sp.ntiles + sp.ntiles / 4 + 8;
+        if ((rc = run_column_batch(cs, src, guessed, PR_CAP, 1, kcount, nullptr, pred_hr, pred_lr, false))) return rc;
+    }
+    SURS_HIP_CHECK(hipEventSynchronize(sp.ev));
+    const long long ncols = host[0];
+    sp.n = -1;
+    if (ncols <= 0 || ncols * pr_min_run(tile) > n || ncols > COL_BATCH || (host[2] && host[3])) return 0;
+    if (ncols > guessed) {   // no guess, or more runs than guessed: the batch with the true counts
+        cs.run_ntiles_host = host[1];
+        if ((rc = run_column_batch(cs, src, ncols, PR_CAP, 1, kcount, nullptr, pred_hr, pred_lr, false))) return rc;
+    }
+    sp.n = n;
+    sp.tile = tile;
+    sp.ncols = ncols;
+    sp.ntiles = host[1];
     *columns = (int)ncols;
     return 0;
 }

@@ -24,6 +24,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import settings
+
 
 def slab_range(resolution, rank, world):
     """[i0, i1) of rank `rank`: contiguous, ordered, sizes differ by at most one."""
@@ -479,7 +481,7 @@ def reconstruction_sharded_once(opt, net, calib_tensor, resolution, b_min, b_max
         # workgroups) the small launches of a taper cost more than the shorter extraction tail gives back (round 5, one rank of
         # eight on a dedicated GPU: 16 384 + taper 15.9 ms of sweep + 0.76 of tail, one launch 15.0 + 0.85).  SURS_SLAB_COLUMNS:
         # equal launches of that many columns (tests)
-        env = os.environ.get("SURS_SLAB_COLUMNS")
+        env = settings.get("SURS_SLAB_COLUMNS")
         big = max(1, 32768 // R)
         if env:
             sched = mesh_util.sweep_schedule(nloc, big, max(1, int(env) // R))
@@ -686,7 +688,7 @@ def assemble_slab_meshes(res, counts, top_ids, fixup, R, dev, dst=0, group=None,
     import os
     world, rank = _world(group)
     nfields = len(res)
-    shm_ok = os.environ.get("SURS_SLAB_P2P", "0") != "1" and os.path.isdir("/dev/shm")
+    shm_ok = settings.get("SURS_SLAB_P2P") != "1" and os.path.isdir("/dev/shm")
     row = [float(status), node_identity(), float(os.getpid()), float(SharedMeshStore.token()), 1.0 if shm_ok else 0.0]
     for c in counts:
         row += list(c)

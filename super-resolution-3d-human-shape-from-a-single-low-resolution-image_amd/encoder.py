@@ -13,7 +13,7 @@ import os
 
 import torch
 
-from . import native
+from . import native, settings
 from .native import Img
 
 
@@ -132,7 +132,7 @@ class NativeNet:
         n.num_stack, n.hg_depth, n.parts = int(opt.num_stack_lr), int(opt.hg_depth), 1 if W.reduced else 2
         # SURS_ENC_SEPARATE_SUM=1: a ConvBlock's closing sum as a launch of its own (the form whose bits the sequencing below
         # reproduces: tests/test_gpu_encoder_net.py); default: in the three convolutions' epilogues (surs_conv2d_nhwc_gn_sum)
-        n.flags = 1 if os.environ.get("SURS_ENC_SEPARATE_SUM", "0") != "0" else 0
+        n.flags = 1 if settings.get("SURS_ENC_SEPARATE_SUM") != "0" else 0
         S = "super_resolution."
         n.head = conv(S + "head.0")
         n.down = (_lib.Conv * 3)(*[conv(S + "down%d.0" % i) for i in (1, 2, 3)])
@@ -190,8 +190,8 @@ class NativeNet:
 def native_enabled(W):
     """The library's own sequencing applies: default operand split (two f16 parts, or the one-part opt-in), statistics handed from kernel
     to kernel, not inside wide_operands(), no captured graphs, SURS_ENC_NATIVE != 0."""
-    return (os.environ.get("SURS_ENC_NATIVE", "1") != "0" and not native.wide_operands_active() and native.fused_groupnorm()
-            and os.environ.get("SURS_CONV_SPLIT", "f16x2").startswith("f") and os.environ.get("SURS_CONV_X3", "1") != "0"
+    return (settings.get("SURS_ENC_NATIVE") != "0" and not native.wide_operands_active() and native.fused_groupnorm()
+            and settings.get("SURS_CONV_SPLIT").startswith("f") and settings.get("SURS_CONV_X3") != "0"
             and not graphs_enabled(W) and not torch.cuda.is_current_stream_capturing())
 
 
@@ -208,7 +208,7 @@ def _lent_streams(depth):
     creation order, NOTES R4.4)."""
     from . import _lib
     cur = torch.cuda.current_stream()
-    if os.environ.get("SURS_ENC_STREAMS", "1") == "0" or cur.cuda_stream != torch.cuda.default_stream(cur.device).cuda_stream:
+    if settings.get("SURS_ENC_STREAMS") == "0" or cur.cuda_stream != torch.cuda.default_stream(cur.device).cuda_stream:
         return None, None
     arr = (C.c_void_p * 4)()
     sides = []
@@ -367,7 +367,7 @@ def _side_stream(level):
     if st is None:
         # (high priority: the low-resolution branch is the longer one - chains of small kernels - and the full-resolution block beside
         #  it would otherwise take the CUs first; SURS_ENC_STREAM_PRIORITY=0: default priority)
-        prio = -1 if os.environ.get("SURS_ENC_STREAM_PRIORITY", "1") != "0" else 0
+        prio = -1 if settings.get("SURS_ENC_STREAM_PRIORITY") != "0" else 0
         st = _side_streams[key] = torch.cuda.Stream(device=cur.device, priority=prio)
     return st
 
@@ -392,7 +392,7 @@ def hourglass(W, prefix, depth, x):
     #  subjects/s at 512^3)
     cur0 = torch.cuda.current_stream()
     # (... or one that is being captured into a HIP graph - graphed() below -, where the fork and the join become graph edges)
-    fork = os.environ.get("SURS_ENC_STREAMS", "1") != "0" and (
+    fork = settings.get("SURS_ENC_STREAMS") != "0" and (
         cur0.cuda_stream == torch.cuda.default_stream(cur0.device).cuda_stream or torch.cuda.is_current_stream_capturing())
 
     st = native.fused_groupnorm()   # every map a ConvBlock reads is written with its GroupNorm statistics (conv_block)
@@ -487,7 +487,7 @@ GRAPH_CACHE = 8   # captured graphs kept per process (each holds the encoder's i
 
 def graphs_enabled(W=None):
     """--encoder_graph 1 switches the graphs on for a network, SURS_ENC_GRAPH=1 / 0 for the process whatever the networks say."""
-    env = os.environ.get("SURS_ENC_GRAPH")
+    env = settings.get("SURS_ENC_GRAPH")
     if env is not None:
         return env != "0"
     return W is not None and str(getattr(W.opt, "encoder_graph", "0")) != "0"
@@ -507,7 +507,7 @@ def _graph_ok(W):
 
 
 def _flags():
-    return (native.wide_operands_active(), native.fused_groupnorm(), os.environ.get("SURS_ENC_STREAMS", "1"))
+    return (native.wide_operands_active(), native.fused_groupnorm(), settings.get("SURS_ENC_STREAMS"))
 
 
 def _hwc(t):

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from . import native
+from . import native, settings
 from .sdf import create_grid
 
 
@@ -208,8 +208,8 @@ def reconstruction_streamed(opt, net, calib_tensor, resolution, b_min, b_max, tr
     vl = torch.empty_like(vh)
     streams = [native.MeshStream(ws, 0, vh, mat[:3].reshape(-1), 0.5, want_normals),
                native.MeshStream(ws, 1, vl, mat[:3].reshape(-1), 0.5, want_normals)]
-    if planes is None and os.environ.get("SURS_SLAB_COLUMNS"):
-        planes = max(1, int(os.environ["SURS_SLAB_COLUMNS"]) // R)   # equal slabs of that many columns (timing experiments)
+    if planes is None and settings.get("SURS_SLAB_COLUMNS"):
+        planes = max(1, int(settings.get("SURS_SLAB_COLUMNS")) // R)   # equal slabs of that many columns (timing experiments)
     # the whole sweep is enqueued first (no host synchronisation in it), with an event behind every slab ...
     sweep = torch.cuda.current_stream(dev)
     done = []

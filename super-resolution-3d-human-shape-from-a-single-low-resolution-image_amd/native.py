@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, settings
 from ._lib import BF16, DTYPES, F16, F32, check, lib  # noqa: F401
 
 
@@ -137,8 +137,8 @@ class ConvWeights:
         # split image for the 3x3 / stride-1 kernel: two f16 parts (surs_conv2d_nhwc_x2, default) or, with SURS_CONV_SPLIT=bf16x3,
         # three bf16 parts (surs_conv2d_nhwc_x3: fp32's exponent range); SURS_CONV_X3=0: neither (fp32 MFMA kernel).  1x1
         # convolutions have a two-part kernel only (conv1x1_x2_kernel); with three parts asked for they stay on the fp32 MFMA kernel
-        self.w3, self.parts = None, 3 if os.environ.get("SURS_CONV_SPLIT", "f16x2").startswith("b") else 2
-        if (self.k == 3 or (self.k == 1 and self.parts == 2)) and os.environ.get("SURS_CONV_X3", "1") != "0":
+        self.w3, self.parts = None, 3 if settings.get("SURS_CONV_SPLIT").startswith("b") else 2
+        if (self.k == 3 or (self.k == 1 and self.parts == 2)) and settings.get("SURS_CONV_X3") != "0":
             pack = lib().surs_conv_pack_weights_x3 if self.parts == 3 else lib().surs_conv_pack_weights_x2
             nb = pack(None, self.cout, self.cin, self.k, None)
             buf = np.empty(nb, np.uint8)
@@ -196,7 +196,7 @@ class GnStats:
 
 def fused_groupnorm():
     """SURS_ENC_FUSED_GN=0: GroupNorm coefficients by surs_groupnorm_coeffs' two launches per normalisation (rounds 1 - 3)."""
-    return os.environ.get("SURS_ENC_FUSED_GN", "1") != "0"
+    return settings.get("SURS_ENC_FUSED_GN") != "0"
 
 
 def conv_gn_eligible(x, cw):
@@ -445,6 +445,28 @@ def query_points(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, want_log
     return tuple(outs)
 
 
+def set_option(name, value):
+    """surs_set_option: a library option by name (include/surs.h; `options()` lists them)."""
+    check(lib().surs_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().surs_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def options():
+    """{name: (value, help)} of every library option."""
+    out, i = {}, 0
+    while True:
+        name = lib().surs_option_name(i)
+        if name is None:
+            return out
+        out[name.decode()] = (get_option(name.decode()), lib().surs_option_help(i).decode())
+        i += 1
+
+
 POINT_RUNS_CHUNK = 262144   # points per surs_query_points_columns call
 
 
@@ -454,7 +476,7 @@ def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtyp
     facade.  dtype: the blob's ("fp32": kernel v11, fp32-grade; "bf16" / "fp16": kernel v10).  Returns (pred_hr, pred_lr), or None
     when the array holds no such runs (random samples; a general calibration; fewer than 2048 points; inside wide_operands()) - the
     caller then takes query_points.  One host synchronisation (the run count)."""
-    if wide_operands_active() or os.environ.get("SURS_POINT_RUNS", "1") == "0":
+    if wide_operands_active() or settings.get("SURS_POINT_RUNS") == "0":
         return None
     points = _f32c(points)
     n = points.shape[1]
@@ -626,7 +648,7 @@ def grid_kernel_for(rx, ry, rz, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, 
     feature buffers are written through raw pointers into recycled allocator blocks, so nothing the host can see tells one
     subject's features from the next one's.  SURS_GRID_AUTO=0 or an explicit SURS_GRID_KERNEL / SURS_GRID_F32_KERNEL turn it
     off.  The last decision is left in ws.kernel_choice = (kernel, listed channels per tile) for reports."""
-    if os.environ.get("SURS_GRID_AUTO", "1") == "0" or "SURS_GRID_KERNEL" in os.environ or "SURS_GRID_F32_KERNEL" in os.environ:
+    if settings.get("SURS_GRID_AUTO") == "0" or settings.is_set("SURS_GRID_KERNEL") or settings.is_set("SURS_GRID_F32_KERNEL"):
         return 0
     if dtype not in ("fp32", "bf16", "fp16") or ry > 16384:
         return 0
@@ -903,7 +925,7 @@ def octree_volumes(R, mat, calib, zmul, zdiv, feat_lr, feat_hr, blob, ws, thresh
     reso = R // init_resolution
     batch = 262144
     use_cols = evaluate is None and columns is not False and not wide_operands_active() \
-        and os.environ.get("SURS_OCTREE_COLUMNS", "1") != "0" and (R + max(reso, 1) - 1) // max(reso, 1) <= 2048
+        and settings.get("SURS_OCTREE_COLUMNS") != "0" and (R + max(reso, 1) - 1) // max(reso, 1) <= 2048
     while reso > 0:
         if use_cols:
             w = ws.get(lib().surs_octree_columns_workspace_bytes(R))

@@ -31,6 +31,47 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().surs_abi_version() == 1
 
 
+def test_switches_live_in_one_table():
+    """The host mirror reads the environment in ONE place (settings.get: override, then environment, then default) and the library
+    in one place (its option table behind surs_set_option): no other os.environ / getenv on the path."""
+    import os
+    import re
+    from surs_amd import settings
+    pkg = os.path.dirname(os.path.abspath(settings.__file__))
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py") and f != "settings.py":
+            assert "os.environ" not in open(os.path.join(pkg, f)).read(), f
+    csrc = os.path.join(pkg, "csrc")
+    sites = [f for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp", ".inc", ".h"))
+             for line in open(os.path.join(csrc, f)) if re.search(r"\bgetenv\(", line)]
+    assert sites == ["surs_api.cpp"], sites
+    assert settings.get("SURS_ENC_NATIVE") == os.environ.get("SURS_ENC_NATIVE", "1")
+    settings.set("SURS_ENC_NATIVE", 0)
+    try:
+        assert settings.get("SURS_ENC_NATIVE") == "0" and settings.is_set("SURS_ENC_NATIVE")
+    finally:
+        settings.set("SURS_ENC_NATIVE", None)
+    with pytest.raises(KeyError):
+        settings.get("SURS_NO_SUCH_SWITCH")
+
+
+def test_library_options_by_name():
+    """surs_set_option / surs_get_option / surs_option_name: no GPU needed."""
+    from surs_amd import native
+    opts = native.options()
+    assert {"grid_kernel", "split_parts", "conv_big_min_wg", "point_runs_speculate"} <= set(opts) and len(opts) >= 13
+    assert opts["conv_big_min_wg"][0] == int(__import__("os").environ.get("SURS_CONV_BIG_MIN_WG", 512))
+    old = native.get_option("gemm_waves")
+    native.set_option("gemm_waves", 16)
+    try:
+        assert native.get_option("gemm_waves") == 16 and native.get_option("SURS_GEMM_WAVES") == 16   # either spelling
+    finally:
+        native.set_option("gemm_waves", old)
+    from surs_amd._lib import SursError
+    with pytest.raises(SursError, match="unknown option"):
+        native.set_option("no_such_option", 1)
+
+
 def test_conv_weight_packing_layout():
     import ctypes as C
     from surs_amd import _lib
