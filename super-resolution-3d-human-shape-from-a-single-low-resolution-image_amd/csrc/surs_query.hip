@@ -680,47 +680,76 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 // column batch as the split image [parts][1024 / 16][nvec * ncp][16] that the layer GEMM kernel reads as its point operand
 // (point index = column * nvec + vector).  g_c = 1 or 0.01: the LeakyReLU branch of channel c at mid column (the same
 // expression as in grid_mlp_v7).  Thread = (column, group of 16 channels).
+// Until round 6 a thread took (column, 16 channels) with the LANES along the columns: every lane read its own 11.8 KB-strided row
+// of the column constants - 64 cache lines per load instruction - and the kernel ran at 3 TB/s (197 us per batch of 32 768
+// columns, a quarter of a batch's preparation).  Now a WAVE takes one column and its lanes the 64 groups of 16 channels: the two
+// rows of column constants are read as whole 4 KB lines; the 32-byte results of a workgroup's four columns go through LDS, part by
+// part, and leave as 256-byte (lr: 4 columns x 2 vectors) and 384-byte (hr: x 3) runs of the image.  The same arithmetic per value:
+// the same bits.
 template <int NP>
 __global__ __launch_bounds__(256) void colsum_prepare_kernel(const float *__restrict__ cc, const float *__restrict__ zvec, int ncp,
                                                              float zmid, unsigned short *__restrict__ g_lr, long long part_lr,
                                                              unsigned short *__restrict__ g_hr, long long part_hr) {
     typedef SplitKind<NP> SK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const int c16 = blockIdx.y * 4 + wave;
-    if (col >= ncp) return;
+    __shared__ __attribute__((aligned(16))) unsigned stage[64][20][8];   // [channel group][column of four x vector: 4 x 2 lr, then 4 x 3 hr][32 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col0 = blockIdx.x * 4, col = col0 + wave;   // (ncp is a multiple of 256)
+    const int c16 = lane;
     const float *row = cc + (size_t)col * CC_PAD + 16 * c16;
     unsigned o[5][NP][8];
+    {
+        float a0l[16], a0h[16], wzl[16], wzh[16], wph[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int c = 16 * c16 + j;
-        const float a0l = row[j], a0h = row[CC_A0_HR + j];
-        const float wzl = zvec[ZV_W0Z_LR + c], wzh = zvec[ZV_W0Z_HR + c], wph = zvec[ZV_W0P_HR + c];
-        const float gl = fmaf(zmid, wzl, a0l) > 0.0f ? 1.0f : 0.01f;
-        const float gh = fmaf(0.5f, wph, fmaf(zmid, wzh, a0h)) > 0.0f ? 1.0f : 0.01f;
-        const float val[5] = {gl * a0l, gl * wzl, gh * a0h, gh * wzh, gh * wph};
+        for (int j = 0; j < 16; j += 4) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4 *>(row + j), t1 = *reinterpret_cast<const f32x4 *>(row + CC_A0_HR + j);
+            const f32x4 t2 = *reinterpret_cast<const f32x4 *>(zvec + ZV_W0Z_LR + 16 * c16 + j);
+            const f32x4 t3 = *reinterpret_cast<const f32x4 *>(zvec + ZV_W0Z_HR + 16 * c16 + j);
+            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(zvec + ZV_W0P_HR + 16 * c16 + j);
 #pragma unroll
-        for (int v = 0; v < 5; ++v) {
-            unsigned short p[NP];
-            SK::split(val[v], p);
+            for (int e = 0; e < 4; ++e) {
+                a0l[j + e] = t0[e]; a0h[j + e] = t1[e]; wzl[j + e] = t2[e]; wzh[j + e] = t3[e]; wph[j + e] = t4[e];
+            }
+        }
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                if (j & 1) o[v][q][j >> 1] |= (unsigned)p[q] << 16;
-                else o[v][q][j >> 1] = p[q];
+        for (int j = 0; j < 16; ++j) {
+            const float gl = fmaf(zmid, wzl[j], a0l[j]) > 0.0f ? 1.0f : 0.01f;
+            const float gh = fmaf(0.5f, wph[j], fmaf(zmid, wzh[j], a0h[j])) > 0.0f ? 1.0f : 0.01f;
+            const float val[5] = {gl * a0l[j], gl * wzl[j], gh * a0h[j], gh * wzh[j], gh * wph[j]};
+#pragma unroll
+            for (int v = 0; v < 5; ++v) {
+                unsigned short p[NP];
+                SK::split(val[v], p);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    if (j & 1) o[v][q][j >> 1] |= (unsigned)p[q] << 16;
+                    else o[v][q][j >> 1] = p[q];
+                }
             }
         }
     }
     const long long np_lr = 2LL * ncp, np_hr = 3LL * ncp;
 #pragma unroll
-    for (int v = 0; v < 5; ++v) {
-        unsigned short *dst = v < 2 ? g_lr + ((long long)c16 * np_lr + 2LL * col + v) * 16
-                                    : g_hr + ((long long)c16 * np_hr + 3LL * col + (v - 2)) * 16;
-        const long long part = v < 2 ? part_lr : part_hr;
+    for (int q = 0; q < NP; ++q) {
+        if (q) __syncthreads();   // (the previous part has left)
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            u32x4 w0 = {o[v][q][0], o[v][q][1], o[v][q][2], o[v][q][3]}, w1 = {o[v][q][4], o[v][q][5], o[v][q][6], o[v][q][7]};
-            *reinterpret_cast<u32x4 *>(dst + q * part) = w0;
-            *reinterpret_cast<u32x4 *>(dst + q * part + 8) = w1;
+        for (int v = 0; v < 5; ++v) {
+            const int slot = v < 2 ? 2 * wave + v : 8 + 3 * wave + (v - 2);
+            *reinterpret_cast<u32x4 *>(&stage[c16][slot][0]) = u32x4{o[v][q][0], o[v][q][1], o[v][q][2], o[v][q][3]};
+            *reinterpret_cast<u32x4 *>(&stage[c16][slot][4]) = u32x4{o[v][q][4], o[v][q][5], o[v][q][6], o[v][q][7]};
+        }
+        __syncthreads();
+        // lr: 64 rows of 256 B = 16 pieces of 16 B; hr: 64 rows of 384 B = 24 pieces
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = tid + 256 * k, r = item >> 4, pc = item & 15;
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(&stage[r][0][0] + 4 * pc);
+            *reinterpret_cast<u32x4 *>(g_lr + q * part_lr + ((long long)r * np_lr + 2LL * col0) * 16 + 8 * pc) = w;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int item = tid + 256 * k, r = item / 24, pc = item - 24 * r;
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(&stage[r][8][0] + 4 * pc);
+            *reinterpret_cast<u32x4 *>(g_hr + q * part_hr + ((long long)r * np_hr + 3LL * col0) * 16 + 8 * pc) = w;
         }
     }
 }
@@ -1383,7 +1412,7 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             a.zmid = (calib[11] + calib[10] * zw) * cs.zmul / cs.zdiv;
         }
         const long long part_lr = 2LL * ncp * D1, part_hr = 3LL * ncp * D1;
-        const dim3 pg((unsigned)(ncp / 64), D1 / 64);
+        const dim3 pg((unsigned)(ncp / 4));   // four columns per workgroup, a wave per column
         // operand parts of this GEMM: the sweep's split (two f16 / three bf16 parts: fp32 grade) for the fp32-grade and the f16
         // kernel; ONE f16 part for the bf16 kernel - 11 significant bits, 8x what bf16 gives the rest of the classifier, a third
         // of the MFMA work, no measurable change of the bf16 sweep's error (SURS_R_PARTS=0: the split's parts there too)
