@@ -9,7 +9,7 @@ objects of libsurs_hip.so (llvm-objdump / llvm-readelf of /opt/rocm/lib/llvm: CP
   NEW kernel beyond 256 unified registers that has not been run under GPU sharing (tests/test_gpu_dist.py) and listed here;
 * scratch (register spills) in the column kernels beyond what is recorded here.
 
-SURS_ISA_SO=<path> points the test at another build; a library built with -DSURS_ABL_NO_ISA_PINS (tools/dev/build_variant.sh nopins
+SURS_ISA_SO=<path> points the test at another build; a library built with -DSURS_ABL_NO_ISA_PINS (tools/dev/build_variant.sh nopins surs_query.hip
 -DSURS_ABL_NO_ISA_PINS) makes the first two tests fail - checked in round 6 (NOTES R6.1)."""
 import os
 import re

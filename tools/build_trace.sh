@@ -6,4 +6,4 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 S="$ROOT/super-resolution-3d-human-shape-from-a-single-low-resolution-image_amd/csrc"
 mkdir -p "$ROOT/abl"
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 -DSURS_V3_TRACE "$@" -shared -o "$ROOT/abl/libsurs_trace.so" \
-    "$S"/surs_query.hip "$S"/surs_mc.hip "$S"/surs_encoder.hip "$S"/surs_octree.hip "$S"/surs_pack.cpp "$S"/surs_api.cpp "$S"/surs_obj.cpp
+    "$S"/*.hip "$S"/*.cpp
