@@ -90,7 +90,7 @@ def test_register_budgets(kernels):
 
 
 # scratch bytes per lane the column kernels ship with (profiles/pmc_summary.json: scratch_bytes_per_lane); lower is fine, more is not
-SCRATCH = {r"grid_mlp_kernel_v12<": 88, r"grid_mlp_kernel_v10<": 64, r"grid_mlp_kernel_v11\b": 0, r"grid_mlp_kernel_v3<": 28,
+SCRATCH = {r"grid_mlp_kernel_v12<": 60, r"grid_mlp_kernel_v10<": 64, r"grid_mlp_kernel_v11\b": 0, r"grid_mlp_kernel_v3<": 28,
            r"grid_mlp_kernel_v5\b": 0}
 
 
