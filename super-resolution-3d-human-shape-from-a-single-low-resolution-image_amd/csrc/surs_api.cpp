@@ -49,6 +49,7 @@ const OptionRow kOptions[surs::OPT_COUNT] = {
     {"conv_trace", "SURS_CONV_TRACE", 0, 0, 0, "diagnostic builds (-DSURS_CONV_TRACE): print the 3x3 kernel's phase stamps"},
     {"gemm_trace", "SURS_GEMM_TRACE", 0, 0, 0, "diagnostic builds: print the layer GEMM's stamps"},
     {"v3_trace", "SURS_V3_TRACE", 0, 0, 0, "diagnostic builds (-DSURS_V3_TRACE): print the column kernels' stamps"},
+    {"conv_tall_min_wg", "SURS_CONV_TALL_MIN_WG", 256, 0, 0, "workgroups from which a 3x3 convolution takes the 8-row x 32-channel tile instead of 4 rows (0: never; same bits)"},
 };
 std::atomic<int> g_option[surs::OPT_COUNT];
 std::once_flag g_option_once;

@@ -314,7 +314,7 @@ __device__ unsigned long long g_conv_trace[8];
 #define CSTAMP(i) do { } while (0)
 #endif
 template <int KS, int STRIDE, int TR, int NT3, int NP>
-__global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
+__global__ __launch_bounds__(256, (TR == 8 && NT3 == 32) ? 2 : 1) void conv_x3_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
     typedef ConvSplit<NP> CS;
     typedef typename CS::vec8 vec8;
     constexpr int NJ = NT3 / 32;   // 32-channel MFMA column tiles per wave
@@ -323,8 +323,14 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     constexpr int RPW = TR / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
     unsigned short *xs = lds16;                         // [NP][PR*PC][XS]
-    unsigned short *wsm = lds16 + NP * PR * PC * XS;    // [NP][T][NT3][XS]
-    float *gn = reinterpret_cast<float *>(wsm + NP * T * NT3 * XS);   // [2][cin_pad]: GroupNorm scale, shift (if any)
+    // Weights: TWO buffers of [NP][T][NJ] fragments of 1 KiB, each in MFMA B-fragment order (lane (kh, li) = halfwords [8 kh, + 8) of
+    // output channel 32 j + li: read back conflict-free at lane * 16, no padded rows).  They arrive by LDS-DMA (global_load_lds, 16 B
+    // per lane: a fragment per instruction, no staging registers, no vector work); chunk c + 1's are issued behind the barrier that
+    // opens chunk c's multiply loop and land under it.  (Until round 6: 9 register loads + 9 LDS stores per thread and chunk, 36
+    // registers of prefetch, 48-byte rows.)
+    constexpr int WFR = NP * T * NJ;                    // fragments per chunk
+    unsigned short *wsm = lds16 + NP * PR * PC * XS;    // [2][WFR][512 halfwords]
+    float *gn = reinterpret_cast<float *>(wsm + 2 * WFR * 512);   // [2][cin_pad]: GroupNorm scale, shift (if any)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef SURS_CONV_TRACE
     const unsigned long long t_kernel_start = __builtin_readcyclecounter();
@@ -352,19 +358,16 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
     // A chunk's MFMAs take ~1.7 k cycles, less than a global-memory round trip: the next chunk's patch and weight
     // slices are fetched into registers while the current chunk multiplies, and split / stored to LDS afterwards.
     constexpr int NPI = (PR * PC * (CK / 4) + 255) / 256;   // patch items per thread (4 channels of one pixel each)
-    constexpr int NWI = (NP * T * NT3 * 2 + 255) / 256;     // weight items per thread (16 bytes each)
     // chunks in flight: the small tile's MFMAs (1.7 k cycles) are shorter than a memory round trip -> two; the big tile's
     // (7 k cycles) cover it, and a second buffer (80 more registers) would spill
-    constexpr int PD = (RPW * NJ >= 4) ? 1 : 2;
-    f32x4 pre_x[PD][NPI], pre_w[PD][NWI];
+    constexpr int PD = (RPW * NJ >= 2) ? 1 : 2;   // (the 8 x 32 tile: 1.7 k cycles of MFMAs per chunk, and 256 registers for two workgroups per CU)
+    f32x4 pre_x[PD][NPI];
     // per-thread item descriptors, computed once (the index arithmetic would otherwise cost more than the MFMAs).
     // Loads are unconditional - items outside the image or beyond the item count read element 0 and are masked /
     // dropped afterwards - so that the compiler emits them back to back instead of one branch per item.
     unsigned px_src[NPI];    // element offset of the item's 4 channels in x for chunk 0
     bool px_ok[NPI];         // inside the image
     int px_dst[NPI];         // halfword offset in one part's LDS image, or -1: no such item
-    unsigned w_src[NWI];     // halfword offset in wsplit for chunk 0
-    int w_dst[NWI];          // halfword offset in the LDS weight image, or -1
     const int cq = (tid & 3) * 4;   // the same for every patch item of a thread (256 is a multiple of 4)
 #pragma unroll
     for (int k = 0; k < NPI; ++k) {
@@ -383,40 +386,38 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < NWI; ++k) {
-        const int item = tid + k * 256;
-        w_src[k] = 0;
-        w_dst[k] = -1;
-        if (item < NP * T * NT3 * 2) {
-            const int half = item & 1, row = item >> 1;            // row = (part*T + tap)*NT3 + n
-            const int n = row % NT3, pt = row / NT3;               // pt = part*T + tap
-            const int part = pt / T, tap = pt - part * T;
-            w_src[k] = (unsigned)(part * per_part + ((size_t)tap * nch * a.cout_pad + n0 + n) * 16 + half * 8);
-            w_dst[k] = row * XS + half * 8;
-        }
-    }
     const unsigned w_step = (unsigned)a.cout_pad * 16;   // halfwords per chunk in wsplit
+    // wave w issues the fragments w, w + 4, ..: fragment f = (part * T + tap) * NJ + j
+    const unsigned w_lane = (unsigned)((n0 + (lane & 31)) * 16 + (lane >> 5) * 8);
+    auto weights_dma = [&](int ch, int buf) {
+        typedef const __attribute__((address_space(1))) void gptr_t;
+        typedef __attribute__((address_space(3))) void lptr_t;
+#pragma unroll
+        for (int q = 0; q < (WFR + 3) / 4; ++q) {
+            const int f = wave + 4 * q;
+            if (f < WFR) {
+                const int j = f % NJ, pt = f / NJ, part = pt / T, tap = pt - part * T;
+                const unsigned short *src = wsplit + ((size_t)part * per_part + (size_t)tap * nch * a.cout_pad * 16 + (size_t)ch * w_step +
+                                                      (size_t)j * 512 + w_lane);
+                __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)(wsm + (buf * WFR + f) * 512), 16, 0, 0);
+            }
+        }
+    };
     auto fetch = [&](int ch, int pb) {
 #pragma unroll
         for (int k = 0; k < NPI; ++k) pre_x[pb][k] = *reinterpret_cast<const f32x4 *>(a.x + (px_src[k] + (unsigned)(ch * CK)));
-#pragma unroll
-        for (int k = 0; k < NWI; ++k) pre_w[pb][k] = *reinterpret_cast<const f32x4 *>(wsplit + (w_src[k] + (unsigned)ch * w_step));
     };
     // the same loads in slices, one per tap of the multiply loop: a wave's 15 loads take ~ 1 000 cycles to issue (1 KiB each through
     // the one texture-address unit the four waves share, all four at the same point of the chunk) - a twelfth of the kernel when
     // they were issued in one burst in front of the MFMAs; between the taps' MFMAs they cost nothing
     constexpr int FT = T > 4 ? T - 3 : T;   // ... of the first taps, so that the last loads have the rest of the loop to arrive
-    constexpr int NFI = NPI + NWI, FPT = (NFI + FT - 1) / FT;
+    constexpr int NFI = NPI, FPT = (NFI + FT - 1) / FT;
     auto fetch_slice = [&](int ch, int pb, int tap) {
 #pragma unroll
         for (int q = 0; q < FPT; ++q) {
             const int k = tap * FPT + q;
             if (k < NPI)
                 pre_x[pb][k < NPI ? k : 0] = *reinterpret_cast<const f32x4 *>(a.x + (px_src[k < NPI ? k : 0] + (unsigned)(ch * CK)));
-            else if (k < NFI)
-                pre_w[pb][k < NFI ? k - NPI : 0] =
-                    *reinterpret_cast<const f32x4 *>(wsplit + (w_src[k < NFI ? k - NPI : 0] + (unsigned)ch * w_step));
         }
     };
     auto stage = [&](int ch, int pb) {
@@ -443,12 +444,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
 #pragma unroll
             for (int e = 0; e < NP; ++e) *reinterpret_cast<u16x4 *>(xs + e * PR * PC * XS + px_dst[k]) = pp[e];
         }
-#pragma unroll
-        for (int k = 0; k < NWI; ++k) {
-            if (w_dst[k] < 0) continue;
-            *reinterpret_cast<f32x4 *>(wsm + w_dst[k]) = pre_w[pb][k];
-        }
     };
+    weights_dma(0, 0);
     fetch(0, 0);
     if (PD == 2 && nch > 1) fetch(1, 1);
     // (behind the first chunks' loads: their latency covers the fold)
@@ -471,7 +468,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
         CSTAMP(4);
         stage(ch, pb);
         CSTAMP(0);
-        __syncthreads();
+        __syncthreads();   // (also waits for this chunk's weight fragments: the barrier's fence drains the DMA counter)
+        if (ch + 1 < nch) weights_dma(ch + 1, (ch + 1) & 1);   // the other buffer: chunk ch - 1's multiply loop ended at the barrier behind it
         CSTAMP(1);
         const bool more = ch + PD < nch;   // (uniform) the next fetch goes into the buffer this chunk has just been staged from
         CSTAMP(2);
@@ -485,7 +483,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(ConvArgs a, const unsigned
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    bw[buf][j][p] = *reinterpret_cast<const vec8 *>(wsm + ((size_t)(p * T + tap) * NT3 + j * 32 + li) * XS + 8 * kh);
+                    bw[buf][j][p] = *reinterpret_cast<const vec8 *>(wsm + (((ch & 1) * WFR + (p * T + tap) * NJ + j) * 512 + lane * 8));
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int prow = (wave * RPW + r) * STRIDE + ky, pcol = li * STRIDE + kx;
@@ -684,7 +682,7 @@ template <int KS, int STRIDE, int TR, int NT3, int NP>
 static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
     SURS_REQUIRE(a.cin_pad <= 1024, "split-operand convolution: at most 1024 input channels");
-    const size_t lds = (size_t)(NP * PR * PC * XS + NP * KS * KS * NT3 * XS) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
+    const size_t lds = (size_t)(NP * PR * PC * XS + 2 * NP * KS * KS * (NT3 / 32) * 512) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
     static DeviceOnce attr;
     if (attr.first())
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -726,15 +724,30 @@ extern "C" int surs_conv_tile_scale(int num, int den) {
 // instead of 512 move the 512^2 encoder by 0.1 ms - the tiles sum in different orders, so the choice is part of the bits)
 static int conv_big_min_wg() { return option(OPT_CONV_BIG_MIN_WG); }
 
+// The tile of a stride-1 launch: 0 = 8 rows x 64 channels (one workgroup per CU; the patch is re-read least), 1 = 8 rows x 32 channels
+// (round 6: two workgroups per CU like the 4-row tile, but six MFMAs per tap and wave instead of three - the 4-row tile's multiply
+// loop waits for its LDS operands, 175 cycles per tap against 96 of MFMAs - and the same order of sums as the 4-row tile: the same
+// bits), 2 = 4 rows x 32 channels.  One place: the statistics' slot count (rows per pixel tile) follows it.
+static int conv_x3_tile(const ConvArgs &a, int stride, int np = 2) {
+    const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
+    const long long cols = ceil_div(wo_eff, TC), rows8 = ceil_div(a.ho, 8);
+    if (stride != 1) return 2;
+    if (cols * rows8 * (a.cout_pad / 64) >= conv_big_min_wg()) return 0;
+    // (three bf16 parts - the wide-operand retry - would spill at 256 registers: the 4-row tile there)
+    if (np <= 2 && option(OPT_CONV_TALL_MIN_WG) > 0 && cols * rows8 * (a.cout_pad / 32) >= option(OPT_CONV_TALL_MIN_WG)) return 1;
+    return 2;
+}
+static int conv_x3_tile_rows(const ConvArgs &a, int stride) { return conv_x3_tile(a, stride) == 2 ? 4 : 8; }
+
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
-    const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-    const long long wg_big = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64);
     // (A 16-row tile - every weight fragment read from LDS serves four rows instead of two, 501 registers with the accumulators in
     //  AGPRs - was measured in round 5: super_res 2.93 -> 2.84 ms, filter_lr unchanged, and im_feat_lr wrong by up to 2.3 when four
     //  processes share the GPU (tests/test_gpu_dist.py: the waves are preempted there; identical results in every single-process
     //  run).  Not shipped: NOTES R5.7.)
-    if (wg_big >= conv_big_min_wg()) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
+    const int tile = conv_x3_tile(a, STRIDE, NP);
+    if (tile == 0) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
+    if (tile == 1) return launch_conv_x3_cfg<KS, STRIDE, STRIDE == 1 ? 8 : 4, 32, NP>(a, wsplit, st);
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
@@ -1644,9 +1657,7 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
             SURS_REQUIRE(gn->out_slots && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0,
                          "GroupNorm(32) output statistics: cout / 32 must be a power of two <= 32");
             // one slot per pixel tile of the launch below (launch_conv_x3's choice, restated)
-            const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-            const bool big = stride == 1 && (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= conv_big_min_wg();
-            const int slots = ksize == 1 ? (int)(((long long)a.ho * a.wo + 127) / 128) : ceil_div(a.wo, TC) * ceil_div(a.ho, big ? 8 : 4);
+            const int slots = ksize == 1 ? (int)(((long long)a.ho * a.wo + 127) / 128) : ceil_div(a.wo, TC) * ceil_div(a.ho, conv_x3_tile_rows(a, stride));
             SURS_REQUIRE(slots <= gn->out_capacity, "GroupNorm statistics buffer too small: %d slots needed", slots);
             *gn->out_slots = slots;
             a.gn_out = gn->out;
@@ -1690,14 +1701,14 @@ extern "C" int surs_conv2d_nhwc_gn_sum(int parts, const float *x, int h, int w, 
         a.gn_in_pitch = gn_in->pitch; a.gn_in_g1 = gn_in->g1; a.gn_in_g2 = gn_in->g2;
         a.gn_in_slots1 = gn_in->slots[1]; a.gn_in_slots2 = gn_in->slots[2];
     }
-    const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-    const bool big = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= conv_big_min_wg();
-    const int slots = ceil_div(a.wo, TC) * ceil_div(a.ho, big ? 8 : 4);
+    const int tile = conv_x3_tile(a, 1), trows = tile == 2 ? 4 : 8;
+    const bool big = tile == 0;
+    const int slots = ceil_div(a.wo, TC) * ceil_div(a.ho, trows);
     // (the kernel makes the second output in its whole-tile epilogue only)
-    SURS_REQUIRE(a.wo % TC == 0 && a.ho % (big ? 8 : 4) == 0 && cout % (big ? 64 : 32) == 0 &&
+    SURS_REQUIRE(a.wo % TC == 0 && a.ho % trows == 0 && cout % (big ? 64 : 32) == 0 &&
                  (long long)h * w * (y2_ld > res_ld ? y2_ld : res_ld) < (1ll << 31) && (!y || (long long)h * w * y_ld < (1ll << 31)),
                  "the sum in the epilogue needs whole tiles: width %% 32, height %% %d, cout %% %d (use surs_conv2d_nhwc_gn + surs_add3_gn)",
-                 big ? 8 : 4, big ? 64 : 32);
+                 trows, big ? 64 : 32);
     if (gn_out) {
         const int cg = cout / 32;
         SURS_REQUIRE(y && gn_out->sums && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0 && slots <= gn_out->pitch,
