@@ -42,14 +42,13 @@ const OptionRow kOptions[surs::OPT_COUNT] = {
     {"grid_f32_kernel", "SURS_GRID_F32_KERNEL", 0, 0, 0, "fp32-grade column kernel: 0 (default 11), 5, 11"},
     {"r_parts", "SURS_R_PARTS", 1, 0, 0, "1: the bf16 sweep's R vectors from one f16 part; 0: the sweep's split"},
     {"grid_f32_passes", "SURS_GRID_F32_PASSES", 2, 0, 0, "passes of the fp32-grade column kernel per batch: 2 (lr, then hr) or 1"},
-    {"conv_big_min_wg", "SURS_CONV_BIG_MIN_WG", 512, 0, 0, "workgroups from which a 3x3 convolution takes the 8-row x 64-channel tile"},
     {"bicubic_block", "SURS_BICUBIC_BLOCK", 1, 0, 0, "0: bicubic x2 with statistics one output per item (A/B; same bits)"},
     {"mc_emit_reclassify", "SURS_MC_EMIT_RECLASSIFY", 0, 0, 0, "1: marching cubes' emit pass classifies again (tests)"},
     {"point_runs_speculate", "SURS_POINT_RUNS_SPECULATE", 1, 0, 0, "0: surs_query_points_columns reads the run count before it launches"},
     {"conv_trace", "SURS_CONV_TRACE", 0, 0, 0, "diagnostic builds (-DSURS_CONV_TRACE): print the 3x3 kernel's phase stamps"},
     {"gemm_trace", "SURS_GEMM_TRACE", 0, 0, 0, "diagnostic builds: print the layer GEMM's stamps"},
     {"v3_trace", "SURS_V3_TRACE", 0, 0, 0, "diagnostic builds (-DSURS_V3_TRACE): print the column kernels' stamps"},
-    {"conv_tall_min_wg", "SURS_CONV_TALL_MIN_WG", 256, 0, 0, "workgroups from which a 3x3 convolution takes the 8-row x 32-channel tile instead of 4 rows (0: never; same bits)"},
+    {"conv_tall_min_wg", "SURS_CONV_TALL_MIN_WG", 256, 0, 0, "workgroups from which a stride-1 3x3 convolution takes the 8-row tile instead of 4 rows (0: never; same bits)"},
 };
 std::atomic<int> g_option[surs::OPT_COUNT];
 std::once_flag g_option_once;

@@ -720,34 +720,23 @@ extern "C" int surs_conv_tile_scale(int num, int den) {
     return 0;
 }
 
-// workgroups of the 8-row x 64-channel tile from which a launch takes it (option conv_big_min_wg; measured in round 6: 256 and 128
-// instead of 512 move the 512^2 encoder by 0.1 ms - the tiles sum in different orders, so the choice is part of the bits)
-static int conv_big_min_wg() { return option(OPT_CONV_BIG_MIN_WG); }
-
-// The tile of a stride-1 launch: 0 = 8 rows x 64 channels (one workgroup per CU; the patch is re-read least), 1 = 8 rows x 32 channels
-// (round 6: two workgroups per CU like the 4-row tile, but six MFMAs per tap and wave instead of three - the 4-row tile's multiply
-// loop waits for its LDS operands, 175 cycles per tap against 96 of MFMAs - and the same order of sums as the 4-row tile: the same
-// bits), 2 = 4 rows x 32 channels.  One place: the statistics' slot count (rows per pixel tile) follows it.
-static int conv_x3_tile(const ConvArgs &a, int stride, int np = 2) {
+// The tile of a launch: 8 rows x 32 pixels x 32 channels (stride 1, from a workgroup per CU upwards) or 4 rows x 32 x 32; both two
+// workgroups per CU, both the same order of sums: the same bits.  The 8-row tile has six MFMAs per tap and wave instead of three - the
+// 4-row tile's multiply loop waits for its LDS operands (175 cycles per tap against 96 of MFMAs) - and stages a patch row for 0.8 rows
+// of output instead of 0.67.  (Until round 6 the large maps ran an 8-row x 64-channel tile, one workgroup of 140 KB per CU: at every
+// size the two-workgroup tile is as fast or faster - 5.94 against 6.26 ms per 512^2 image - because one workgroup's staging and
+// barriers run under the other's MFMAs.  Removed: NOTES R6.3.)  One place: the statistics' slot count (rows per pixel tile) follows it.
+// Three bf16 parts (the wide-operand retry) would spill at 256 registers with 8 rows: the 4-row tile there.
+static int conv_x3_tile_rows(const ConvArgs &a, int stride, int np = 2) {
     const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-    const long long cols = ceil_div(wo_eff, TC), rows8 = ceil_div(a.ho, 8);
-    if (stride != 1) return 2;
-    if (cols * rows8 * (a.cout_pad / 64) >= conv_big_min_wg()) return 0;
-    // (three bf16 parts - the wide-operand retry - would spill at 256 registers: the 4-row tile there)
-    if (np <= 2 && option(OPT_CONV_TALL_MIN_WG) > 0 && cols * rows8 * (a.cout_pad / 32) >= option(OPT_CONV_TALL_MIN_WG)) return 1;
-    return 2;
+    const long long wgs = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 32);
+    return (stride == 1 && np <= 2 && option(OPT_CONV_TALL_MIN_WG) > 0 && wgs >= option(OPT_CONV_TALL_MIN_WG)) ? 8 : 4;
 }
-static int conv_x3_tile_rows(const ConvArgs &a, int stride) { return conv_x3_tile(a, stride) == 2 ? 4 : 8; }
 
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
-    // (A 16-row tile - every weight fragment read from LDS serves four rows instead of two, 501 registers with the accumulators in
-    //  AGPRs - was measured in round 5: super_res 2.93 -> 2.84 ms, filter_lr unchanged, and im_feat_lr wrong by up to 2.3 when four
-    //  processes share the GPU (tests/test_gpu_dist.py: the waves are preempted there; identical results in every single-process
-    //  run).  Not shipped: NOTES R5.7.)
-    const int tile = conv_x3_tile(a, STRIDE, NP);
-    if (tile == 0) return launch_conv_x3_cfg<KS, STRIDE, 8, 64, NP>(a, wsplit, st);
-    if (tile == 1) return launch_conv_x3_cfg<KS, STRIDE, STRIDE == 1 ? 8 : 4, 32, NP>(a, wsplit, st);
+    // (A 16-row tile - 501 registers - was measured in round 5: wrong values when four processes share the GPU; NOTES R5.7.)
+    if (conv_x3_tile_rows(a, STRIDE, NP) == 8) return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP <= 2) ? 8 : 4, 32, NP>(a, wsplit, st);
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
@@ -1701,14 +1690,13 @@ extern "C" int surs_conv2d_nhwc_gn_sum(int parts, const float *x, int h, int w, 
         a.gn_in_pitch = gn_in->pitch; a.gn_in_g1 = gn_in->g1; a.gn_in_g2 = gn_in->g2;
         a.gn_in_slots1 = gn_in->slots[1]; a.gn_in_slots2 = gn_in->slots[2];
     }
-    const int tile = conv_x3_tile(a, 1), trows = tile == 2 ? 4 : 8;
-    const bool big = tile == 0;
+    const int trows = conv_x3_tile_rows(a, 1);
     const int slots = ceil_div(a.wo, TC) * ceil_div(a.ho, trows);
     // (the kernel makes the second output in its whole-tile epilogue only)
-    SURS_REQUIRE(a.wo % TC == 0 && a.ho % trows == 0 && cout % (big ? 64 : 32) == 0 &&
+    SURS_REQUIRE(a.wo % TC == 0 && a.ho % trows == 0 && cout % 32 == 0 &&
                  (long long)h * w * (y2_ld > res_ld ? y2_ld : res_ld) < (1ll << 31) && (!y || (long long)h * w * y_ld < (1ll << 31)),
-                 "the sum in the epilogue needs whole tiles: width %% 32, height %% %d, cout %% %d (use surs_conv2d_nhwc_gn + surs_add3_gn)",
-                 trows, big ? 64 : 32);
+                 "the sum in the epilogue needs whole tiles: width %% 32, height %% %d, cout %% 32 (use surs_conv2d_nhwc_gn + surs_add3_gn)",
+                 trows);
     if (gn_out) {
         const int cg = cout / 32;
         SURS_REQUIRE(y && gn_out->sums && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0 && slots <= gn_out->pitch,

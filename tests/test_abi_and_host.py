@@ -59,8 +59,8 @@ def test_library_options_by_name():
     """surs_set_option / surs_get_option / surs_option_name: no GPU needed."""
     from surs_amd import native
     opts = native.options()
-    assert {"grid_kernel", "split_parts", "conv_big_min_wg", "point_runs_speculate"} <= set(opts) and len(opts) >= 13
-    assert opts["conv_big_min_wg"][0] == int(__import__("os").environ.get("SURS_CONV_BIG_MIN_WG", 512))
+    assert {"grid_kernel", "split_parts", "conv_tall_min_wg", "point_runs_speculate"} <= set(opts) and len(opts) >= 13
+    assert opts["conv_tall_min_wg"][0] == int(__import__("os").environ.get("SURS_CONV_TALL_MIN_WG", 256))
     old = native.get_option("gemm_waves")
     native.set_option("gemm_waves", 16)
     try:
