@@ -314,7 +314,7 @@ __device__ unsigned long long g_conv_trace[8];
 #define CSTAMP(i) do { } while (0)
 #endif
 template <int KS, int STRIDE, int TR, int NT3, int NP>
-__global__ __launch_bounds__(256, (TR == 8 && NT3 == 32) ? 2 : 1) void conv_x3_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
+__global__ __launch_bounds__(256, (TR == 8 && STRIDE == 1) ? 2 : 1) void conv_x3_kernel(ConvArgs a, const unsigned short *__restrict__ wsplit) {
     typedef ConvSplit<NP> CS;
     typedef typename CS::vec8 vec8;
     constexpr int NJ = NT3 / 32;   // 32-channel MFMA column tiles per wave
@@ -329,8 +329,11 @@ __global__ __launch_bounds__(256, (TR == 8 && NT3 == 32) ? 2 : 1) void conv_x3_k
     // opens chunk c's multiply loop and land under it.  (Until round 6: 9 register loads + 9 LDS stores per thread and chunk, 36
     // registers of prefetch, 48-byte rows.)
     constexpr int WFR = NP * T * NJ;                    // fragments per chunk
+    // (64-channel tile: ONE weight buffer - two would push the workgroup past half a CU's LDS -, filled behind the barrier that ends the
+    //  previous chunk's multiply loop, landing under this chunk's patch staging)
+    constexpr int WB = NT3 >= 64 ? 1 : 2;
     unsigned short *wsm = lds16 + NP * PR * PC * XS;    // [2][WFR][512 halfwords]
-    float *gn = reinterpret_cast<float *>(wsm + 2 * WFR * 512);   // [2][cin_pad]: GroupNorm scale, shift (if any)
+    float *gn = reinterpret_cast<float *>(wsm + WB * WFR * 512);   // [2][cin_pad]: GroupNorm scale, shift (if any)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef SURS_CONV_TRACE
     const unsigned long long t_kernel_start = __builtin_readcyclecounter();
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256, (TR == 8 && NT3 == 32) ? 2 : 1) void conv_x3_k
         stage(ch, pb);
         CSTAMP(0);
         __syncthreads();   // (also waits for this chunk's weight fragments: the barrier's fence drains the DMA counter)
-        if (ch + 1 < nch) weights_dma(ch + 1, (ch + 1) & 1);   // the other buffer: chunk ch - 1's multiply loop ended at the barrier behind it
+        if (WB == 2 && ch + 1 < nch) weights_dma(ch + 1, (ch + 1) & 1);   // the other buffer: chunk ch - 1's multiply loop ended at the barrier behind it
         CSTAMP(1);
         const bool more = ch + PD < nch;   // (uniform) the next fetch goes into the buffer this chunk has just been staged from
         CSTAMP(2);
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256, (TR == 8 && NT3 == 32) ? 2 : 1) void conv_x3_k
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    bw[buf][j][p] = *reinterpret_cast<const vec8 *>(wsm + (((ch & 1) * WFR + (p * T + tap) * NJ + j) * 512 + lane * 8));
+                    bw[buf][j][p] = *reinterpret_cast<const vec8 *>(wsm + (((WB == 2 ? (ch & 1) : 0) * WFR + (p * T + tap) * NJ + j) * 512 + lane * 8));
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int prow = (wave * RPW + r) * STRIDE + ky, pcol = li * STRIDE + kx;
@@ -515,6 +518,7 @@ __global__ __launch_bounds__(256, (TR == 8 && NT3 == 32) ? 2 : 1) void conv_x3_k
         }
         CSTAMP(3);
         __syncthreads();
+        if (WB == 1 && ch + 1 < nch) weights_dma(ch + 1, 0);
     };
     for (int ch = 0; ch < nch; ch += 2) {
         chunk(ch, 0);
@@ -682,7 +686,7 @@ template <int KS, int STRIDE, int TR, int NT3, int NP>
 static int launch_conv_x3_cfg(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     constexpr int PR = (TR - 1) * STRIDE + KS, PC = (TC - 1) * STRIDE + KS;
     SURS_REQUIRE(a.cin_pad <= 1024, "split-operand convolution: at most 1024 input channels");
-    const size_t lds = (size_t)(NP * PR * PC * XS + 2 * NP * KS * KS * (NT3 / 32) * 512) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
+    const size_t lds = (size_t)(NP * PR * PC * XS + (NT3 >= 64 ? 1 : 2) * NP * KS * KS * (NT3 / 32) * 512) * sizeof(unsigned short) + 2 * 1024 * sizeof(float);
     static DeviceOnce attr;
     if (attr.first())
         SURS_HIP_CHECK(hipFuncSetAttribute((const void *)conv_x3_kernel<KS, STRIDE, TR, NT3, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -720,12 +724,17 @@ extern "C" int surs_conv_tile_scale(int num, int den) {
     return 0;
 }
 
-// The tile of a launch: 8 rows x 32 pixels x 32 channels (stride 1, from a workgroup per CU upwards) or 4 rows x 32 x 32; both two
-// workgroups per CU, both the same order of sums: the same bits.  The 8-row tile has six MFMAs per tap and wave instead of three - the
-// 4-row tile's multiply loop waits for its LDS operands (175 cycles per tap against 96 of MFMAs) - and stages a patch row for 0.8 rows
-// of output instead of 0.67.  (Until round 6 the large maps ran an 8-row x 64-channel tile, one workgroup of 140 KB per CU: at every
-// size the two-workgroup tile is as fast or faster - 5.94 against 6.26 ms per 512^2 image - because one workgroup's staging and
-// barriers run under the other's MFMAs.  Removed: NOTES R6.3.)  One place: the statistics' slot count (rows per pixel tile) follows it.
+// The tile of a stride-1 launch, all three two workgroups per CU (one's staging and barriers run under the other's MFMAs):
+//   8 rows x 32 pixels x 64 channels where that still gives 512 workgroups (the maps of 256^2 and more with >= 128 output channels, the
+//       super-resolution net's large maps): the staged patch - GroupNorm, ReLU, split: the loop's vector work - serves twelve MFMAs
+//       per tap and wave; ONE weight buffer (two would not leave room for a second workgroup), filled by DMA behind the barrier that
+//       ends a chunk's multiply loop and landing under the next chunk's patch staging;
+//   8 rows x 32 x 32 from 256 workgroups: six MFMAs per tap and wave; two weight buffers, the next chunk's landing under this one's MFMAs;
+//   4 rows x 32 x 32 below (the hourglass's 64^2 maps): three per tap - its multiply loop waits for its LDS operands (175 cycles per
+//       tap against 96 of MFMAs).
+// The 32-channel tiles add their three partial products in one order, the 64-channel tile in another: the choice is part of the bits
+// (and reproduces round 5's, whose 8 x 64 tile - 140 KB of LDS, padded weight rows staged through registers, one workgroup per CU - ran
+// the same launches: 7.26 -> 5.8 ms per 512^2 image with the epilogues of R6.3).  One place: the statistics' slot count follows it.
 // Three bf16 parts (the wide-operand retry) would spill at 256 registers with 8 rows: the 4-row tile there.
 static int conv_x3_tile_rows(const ConvArgs &a, int stride, int np = 2) {
     const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
@@ -736,7 +745,13 @@ static int conv_x3_tile_rows(const ConvArgs &a, int stride, int np = 2) {
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     // (A 16-row tile - 501 registers - was measured in round 5: wrong values when four processes share the GPU; NOTES R5.7.)
-    if (conv_x3_tile_rows(a, STRIDE, NP) == 8) return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP <= 2) ? 8 : 4, 32, NP>(a, wsplit, st);
+    if (conv_x3_tile_rows(a, STRIDE, NP) == 8) {
+        const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
+        if (NP == 2 && STRIDE == 1 && option(OPT_CONV_WIDE_MIN_WG) > 0 &&
+            (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= option(OPT_CONV_WIDE_MIN_WG))
+            return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP == 2) ? 8 : 4, (STRIDE == 1 && NP == 2) ? 64 : 32, NP>(a, wsplit, st);
+        return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP <= 2) ? 8 : 4, 32, NP>(a, wsplit, st);
+    }
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
