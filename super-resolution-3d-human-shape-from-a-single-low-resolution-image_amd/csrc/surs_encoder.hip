@@ -736,22 +736,24 @@ extern "C" int surs_conv_tile_scale(int num, int den) {
 // (and reproduces round 5's, whose 8 x 64 tile - 140 KB of LDS, padded weight rows staged through registers, one workgroup per CU - ran
 // the same launches: 7.26 -> 5.8 ms per 512^2 image with the epilogues of R6.3).  One place: the statistics' slot count follows it.
 // Three bf16 parts (the wide-operand retry) would spill at 256 registers with 8 rows: the 4-row tile there.
-static int conv_x3_tile_rows(const ConvArgs &a, int stride, int np = 2) {
+struct ConvTile { int rows, chans; };
+static ConvTile conv_x3_tile(const ConvArgs &a, int stride, int np = 2) {
     const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-    const long long wgs = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 32);
-    return (stride == 1 && np <= 2 && option(OPT_CONV_TALL_MIN_WG) > 0 && wgs >= option(OPT_CONV_TALL_MIN_WG)) ? 8 : 4;
+    const long long px = (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8);
+    if (stride != 1 || np > 2) return {4, 32};
+    if (np == 2 && option(OPT_CONV_WIDE_MIN_WG) > 0 && px * (a.cout_pad / 64) >= option(OPT_CONV_WIDE_MIN_WG)) return {8, 64};
+    if (option(OPT_CONV_TALL_MIN_WG) > 0 && px * (a.cout_pad / 32) >= option(OPT_CONV_TALL_MIN_WG)) return {8, 32};
+    return {4, 32};
 }
+static int conv_x3_tile_rows(const ConvArgs &a, int stride, int np = 2) { return conv_x3_tile(a, stride, np).rows; }
 
 template <int KS, int STRIDE, int NP>
 static int launch_conv_x3(const ConvArgs &a, const unsigned short *wsplit, hipStream_t st) {
     // (A 16-row tile - 501 registers - was measured in round 5: wrong values when four processes share the GPU; NOTES R5.7.)
-    if (conv_x3_tile_rows(a, STRIDE, NP) == 8) {
-        const long long wo_eff = ((long long)a.wo * t_tile_num + t_tile_den - 1) / t_tile_den;
-        if (NP == 2 && STRIDE == 1 && option(OPT_CONV_WIDE_MIN_WG) > 0 &&
-            (long long)ceil_div(wo_eff, TC) * ceil_div(a.ho, 8) * (a.cout_pad / 64) >= option(OPT_CONV_WIDE_MIN_WG))
-            return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP == 2) ? 8 : 4, (STRIDE == 1 && NP == 2) ? 64 : 32, NP>(a, wsplit, st);
-        return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP <= 2) ? 8 : 4, 32, NP>(a, wsplit, st);
-    }
+    const ConvTile t = conv_x3_tile(a, STRIDE, NP);
+    if (t.rows == 8 && t.chans == 64)
+        return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP == 2) ? 8 : 4, (STRIDE == 1 && NP == 2) ? 64 : 32, NP>(a, wsplit, st);
+    if (t.rows == 8) return launch_conv_x3_cfg<KS, STRIDE, (STRIDE == 1 && NP <= 2) ? 8 : 4, 32, NP>(a, wsplit, st);
     return launch_conv_x3_cfg<KS, STRIDE, 4, 32, NP>(a, wsplit, st);
 }
 
@@ -1661,7 +1663,7 @@ static int conv2d_split_f16(int parts, const float *x, int h, int w, int cin, in
             SURS_REQUIRE(gn->out_slots && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0,
                          "GroupNorm(32) output statistics: cout / 32 must be a power of two <= 32");
             // one slot per pixel tile of the launch below (launch_conv_x3's choice, restated)
-            const int slots = ksize == 1 ? (int)(((long long)a.ho * a.wo + 127) / 128) : ceil_div(a.wo, TC) * ceil_div(a.ho, conv_x3_tile_rows(a, stride));
+            const int slots = ksize == 1 ? (int)(((long long)a.ho * a.wo + 127) / 128) : ceil_div(a.wo, TC) * ceil_div(a.ho, conv_x3_tile_rows(a, stride, parts));
             SURS_REQUIRE(slots <= gn->out_capacity, "GroupNorm statistics buffer too small: %d slots needed", slots);
             *gn->out_slots = slots;
             a.gn_out = gn->out;
@@ -1705,13 +1707,14 @@ extern "C" int surs_conv2d_nhwc_gn_sum(int parts, const float *x, int h, int w, 
         a.gn_in_pitch = gn_in->pitch; a.gn_in_g1 = gn_in->g1; a.gn_in_g2 = gn_in->g2;
         a.gn_in_slots1 = gn_in->slots[1]; a.gn_in_slots2 = gn_in->slots[2];
     }
-    const int trows = conv_x3_tile_rows(a, 1);
+    const ConvTile tile = conv_x3_tile(a, 1, parts);
+    const int trows = tile.rows;
     const int slots = ceil_div(a.wo, TC) * ceil_div(a.ho, trows);
     // (the kernel makes the second output in its whole-tile epilogue only)
-    SURS_REQUIRE(a.wo % TC == 0 && a.ho % trows == 0 && cout % 32 == 0 &&
+    SURS_REQUIRE(a.wo % TC == 0 && a.ho % trows == 0 && cout % tile.chans == 0 &&
                  (long long)h * w * (y2_ld > res_ld ? y2_ld : res_ld) < (1ll << 31) && (!y || (long long)h * w * y_ld < (1ll << 31)),
-                 "the sum in the epilogue needs whole tiles: width %% 32, height %% %d, cout %% 32 (use surs_conv2d_nhwc_gn + surs_add3_gn)",
-                 trows);
+                 "the sum in the epilogue needs whole tiles: width %% 32, height %% %d, cout %% %d (use surs_conv2d_nhwc_gn + surs_add3_gn)",
+                 trows, tile.chans);
     if (gn_out) {
         const int cg = cout / 32;
         SURS_REQUIRE(y && gn_out->sums && cout % 32 == 0 && cg >= 1 && cg <= 32 && (cg & (cg - 1)) == 0 && slots <= gn_out->pitch,
