@@ -50,6 +50,7 @@ const OptionRow kOptions[surs::OPT_COUNT] = {
     {"v3_trace", "SURS_V3_TRACE", 0, 0, 0, "diagnostic builds (-DSURS_V3_TRACE): print the column kernels' stamps"},
     {"conv_tall_min_wg", "SURS_CONV_TALL_MIN_WG", 256, 0, 0, "workgroups from which a stride-1 3x3 convolution takes the 8-row tile instead of 4 rows (0: never; same bits)"},
     {"conv_wide_min_wg", "SURS_CONV_WIDE_MIN_WG", 512, 0, 0, "workgroups (of 64 channels) from which such a launch takes 8 rows x 64 channels (part of the bits: another order of sums; 0: never)"},
+    {"mc_ring", "SURS_MC_RING", 258, 0, 0, "planes of marching cubes' edge -> vertex-id ring = layers per chunk of a one-piece extraction + 1 (66: round 5's)"},
 };
 std::atomic<int> g_option[surs::OPT_COUNT];
 std::once_flag g_option_once;

@@ -19,8 +19,8 @@
 //      pass 3  emit: the same classification again, only in blocks that have active cells; one 16-byte entry per active
 //              cell in sweep order: (cell, code = table / offset / counts, first vertex id, first triangle id)
 //      pass 4a vertices, one thread per ACTIVE cell: positions; ids stored in 4 per-voxel tables (x-edge, y-edge, z-edge
-//              starting at the voxel, centre of the cell whose corner 0 it is) that hold a RING of MC_RING planes: the sweep is
-//              walked in chunks of MC_RING - 1 cell layers (mc_chunked), a layer only touches the ids of its two planes
+//              starting at the voxel, centre of the cell whose corner 0 it is) that hold a RING of planes (option mc_ring): the sweep is
+//              walked in chunks of ring - 1 cell layers (mc_chunked), a layer only touches the ids of its two planes
 //      pass 4b faces (+ values by atomic max, normals by atomic add): vertex ids looked up in the tables
 //      pass 5  normalise normals.
 // HBM-bound by design: the volume is read once (pass 1) plus the blocks with a surface once more (pass 3: a few per cent
@@ -1280,12 +1280,19 @@ static int mc_nblocks(long long ncells) { return (int)((ncells + CELLS_PER_BLOCK
 
 // The edge -> vertex-id tables are a RING of planes: Lewiner's sweep has axis 0 outermost, a cell layer reads and writes the ids of
 // its two planes only, and every extraction proceeds in contiguous layer ranges - so a range of L layers needs L + 1 planes, and the
-// plane it shares with the next range survives as long as L + 1 <= ring.  MC_RING planes (the streamed extraction advances by at most
+// plane it shares with the next range survives as long as L + 1 <= ring.  (The streamed extraction advances by at most
 // 64 layers - one launch of the sweep at 512^3); larger ranges, the one-piece extraction included, are walked in chunks of ring - 1
 // layers (mc_chunked).  Until round 4 the tables were dense: 4 x int32[n0 n1 n2] = 2.1 GB per field at 512^3 (now 277 MB), and the
 // active-cell list was sized for every cell of the volume (2.1 GB; now for the cells of one chunk, 272 MB).
-constexpr int MC_RING = 66;
-static int mc_ring(int n0) { return n0 < MC_RING ? n0 : MC_RING; }
+// Round 6: the ring's size is the library option mc_ring (default 258 planes: a one-piece extraction of a 512-layer volume - the
+// octree mode's, a first reconstruction's - is two chunks instead of eight: 10 launches and 2 host synchronisations instead of 40 and
+// 8; 2.2 GB of workspace per field at 512^3 instead of 0.55 - of 288).  Read at every call: every call on one workspace must see the
+// same value (set it before the first extraction).
+static int mc_ring(int n0) {
+    int r = option(OPT_MC_RING);
+    if (r < 3) r = 3;
+    return n0 < r ? n0 : r;
+}
 static long long mc_chunk_cells(int n0, int n1, int n2) {   // the most cells one mc_range call processes
     const int layers = (n0 - 1) < (mc_ring(n0) - 1) ? (n0 - 1) : (mc_ring(n0) - 1);
     return (long long)layers * (n1 - 1) * (n2 - 1);
