@@ -317,7 +317,9 @@ def super_res_strip(W, x, a, b, want_image=True):
     #  image's tiles)
     native.check(native.lib().surs_conv_tile_scale(x.w, xs.w))
     try:
-        img_sr, new2, new_fin = super_res(W, xs, want_image=want_image)
+        # (the library's own sequencing where it applies: the tile scale is the calling thread's, whoever issues the launches)
+        run = super_res_native if native_enabled(W) else super_res
+        img_sr, new2, new_fin = run(W, xs, want_image=want_image)
     finally:
         native.check(native.lib().surs_conv_tile_scale(1, 1))
 
