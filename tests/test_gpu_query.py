@@ -543,6 +543,38 @@ def test_point_runs_refused_where_there_are_none(setup):
     assert _qc(setup, short, "fp32") is None
 
 
+def test_point_runs_launches_sized_from_the_previous_call(setup):
+    """surs_query_points_columns sizes its launches from the PREVIOUS call's run count (same array length) and reads the true count after
+    the enqueue: arrays of one length with very different run structures, one after the other - many more runs than guessed (the batch
+    runs again), far fewer, no runs at all (refused: the guess is dropped) - must give the bits of the call that reads the count first
+    (option point_runs_speculate = 0)."""
+    nat = setup["native"]
+    n = 40000
+    def fit(pts):   # cut / repeat to n points (whole array structure kept: the last run is cut)
+        reps = -(-n // pts.shape[1])
+        return np.ascontiguousarray(np.concatenate([pts] * reps, 1)[:, :n]) if reps > 1 else np.ascontiguousarray(pts[:, :n])
+    arrays = [fit(_run_points(seed=21, ncols=120, lo=300, hi=512)),        # ~ 100 runs
+              fit(_run_points(seed=22, ncols=1200, lo=30, hi=40)),         # ~ 1150 runs: 10 x the guess
+              fit(_run_points(seed=23, ncols=30, lo=1200, hi=1500)),       # ~ 30 runs (cut at 4096 points: more columns than runs)
+              fit(_run_points(seed=21, ncols=120, lo=300, hi=512))]
+    from surs_amd import weights
+    rnd = weights.synthetic_points(n, seed=4)
+    for dtype in ("fp32", "bf16"):
+        nat.set_option("point_runs_speculate", 0)
+        try:
+            want = [_qc(setup, a, dtype) for a in arrays]
+        finally:
+            nat.set_option("point_runs_speculate", 1)
+        assert all(w is not None for w in want)
+        got = []
+        for i, a in enumerate(arrays):
+            got.append(_qc(setup, a, dtype))
+            if i == 1:
+                assert _qc(setup, rnd, dtype) is None      # no runs: refused although the previous call left a guess
+        for w, g_ in zip(want, got):
+            assert g_ is not None and torch.equal(w[0], g_[0]) and torch.equal(w[1], g_[1])
+
+
 def test_point_runs_kernel_equals_its_restatement(setup):
     """surs_point_runs (one workgroup: ballots, bit counts, two carries across blocks of 4096 points) against oracle.point_runs
     (plain loops) on ragged runs, runs cut at 4096 points, a chunk cut out of a grid, NaN and -0.0, and an array of singles."""
