@@ -219,7 +219,7 @@ typedef struct SursEncoderNet {
     const SursGroupNorm *bn_end;  /* [num_stack] */
 } SursEncoderNet;
 /* Streams the caller lends for the low-resolution branch of hourglass level 1..4 (NULL entries / NULL struct: the branches run one
- * behind the other on `stream`).  The library never creates a stream (see surs_set_side_stream). */
+ * behind the other on `stream`).  The library never creates a stream (a new stream shifts the hardware-queue assignment of every later one). */
 typedef struct SursEncoderStreams { void *side[4]; } SursEncoderStreams;
 /* bytes of workspace the calls below need for an h x w input image (0: bad arguments) */
 size_t surs_encoder_workspace_bytes(const SursEncoderNet *net, int h, int w);
@@ -310,10 +310,6 @@ int surs_query_points_hr(const float *points, int n, const float *calib, float z
  * (run, z tile) pairs of `tile` = 64 | 128 points (room for 2 n ints), meta[4] = {runs, work items - 0 and no lengths / work items when the
  * array holds more than one run per tile / 4 points -, z ascending violated, z descending violated}.  Device pointers; no synchronisation. */
 int surs_point_runs(const float *points, long long ld, int n, int tile, int *colstart, int *kcount, int *tiles, int *meta, void *stream);
-/* A second stream the calling host thread lends the library (NULL: none): surs_query_points_columns then runs the two classifiers'
- * per-run GEMMs side by side (forked from and joined to the call's stream by events) instead of one behind the other - 25 us of a
- * 0.5 ms call.  The library never creates a stream itself (a new stream shifts the hardware-queue assignment of every later one). */
-int surs_set_side_stream(void *stream);
 size_t surs_query_points_columns_workspace_bytes(void);
 int surs_query_points_columns(const float *points, long long ld, int n, const float *calib, float zmul, float zdiv,
                               const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,

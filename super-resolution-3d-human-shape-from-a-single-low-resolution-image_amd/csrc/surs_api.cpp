@@ -51,6 +51,7 @@ const OptionRow kOptions[surs::OPT_COUNT] = {
     {"conv_tall_min_wg", "SURS_CONV_TALL_MIN_WG", 256, 0, 0, "workgroups from which a stride-1 3x3 convolution takes the 8-row tile instead of 4 rows (0: never; same bits)"},
     {"conv_wide_min_wg", "SURS_CONV_WIDE_MIN_WG", 512, 0, 0, "workgroups (of 64 channels) from which such a launch takes 8 rows x 64 channels (part of the bits: another order of sums; 0: never)"},
     {"mc_ring", "SURS_MC_RING", 258, 0, 0, "planes of marching cubes' edge -> vertex-id ring = layers per chunk of a one-piece extraction + 1 (66: round 5's)"},
+    {"rvec_small", "SURS_RVEC_SMALL", 1, 0, 0, "0: the affine part's GEMM of batches of <= 1024 columns on the 256 x 256-tile kernel (A/B; same bits)"},
 };
 std::atomic<int> g_option[surs::OPT_COUNT];
 std::once_flag g_option_once;

@@ -54,7 +54,7 @@ inline int fail(int code, const char *fmt, ...) {
 enum Opt {
     OPT_GEMM_X3, OPT_GEMM_BIG, OPT_SPLIT_PARTS, OPT_GEMM_WAVES, OPT_GRID_F32_COLUMNS, OPT_GRID_KERNEL, OPT_GRID_F32_KERNEL, OPT_R_PARTS,
     OPT_GRID_F32_PASSES, OPT_BICUBIC_BLOCK, OPT_MC_EMIT_RECLASSIFY, OPT_POINT_RUNS_SPECULATE, OPT_CONV_TRACE,
-    OPT_GEMM_TRACE, OPT_V3_TRACE, OPT_CONV_TALL_MIN_WG, OPT_CONV_WIDE_MIN_WG, OPT_MC_RING, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_V3_TRACE, OPT_CONV_TALL_MIN_WG, OPT_CONV_WIDE_MIN_WG, OPT_MC_RING, OPT_RVEC_SMALL, OPT_COUNT
 };
 int option(Opt id);
 

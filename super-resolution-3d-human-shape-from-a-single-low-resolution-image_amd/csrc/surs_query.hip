@@ -1326,33 +1326,6 @@ static int device_cus() {
     return 256;
 }
 
-// A second stream for run_column_batch's small batches, GIVEN by the caller (surs_set_side_stream, per host thread), with the two
-// events of a fork / join.  The library creates no stream of its own: HIP maps streams onto a handful of hardware queues in creation
-// order, and one more stream in a process shifts the queues of every stream created after it (NOTES R4.4: a copy stream that lands
-// on the sweep's queue costs a reconstruction 19 ms).
-namespace {
-struct SideLane {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-}  // namespace
-static thread_local SideLane t_lane;
-
-extern "C" int surs_set_side_stream(void *stream) {
-    t_lane.s = as_stream(stream);
-    return 0;
-}
-
-static SideLane *side_lane() {
-    SideLane &l = t_lane;
-    if (!l.s) return nullptr;
-    if (!l.fork) {
-        if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) { l.fork = l.join = nullptr; return nullptr; }
-    }
-    return &l;
-}
-
 // One batch of nc <= COL_BATCH columns described by src (mode 2: consecutive columns from src.base; mode 4: listed columns):
 // gather + column constants, the restated kernels' per-column affine part, then the column kernel over `items` z items per column
 // (dense: the voxels 0 .. items - 1; lattice sweeps: the kcount[column] listed voxels klist[column][.] * zstride).  vol_*: [nc][items].
@@ -1428,15 +1401,27 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
             hipLaunchKernelGGL(colsum_prepare_kernel<3>, pg, dim3(256), 0, st, CC, (const float *)(blob + h.zvec), (int)ncp, a.zmid,
                                g_lr, part_lr, g_hr, part_hr);
         SURS_LAUNCH_CHECK();
-        // small batches (the ~ 100 columns of a point-runs call: 4 - 6 workgroups per GEMM walking K = 1024, a latency chain of 33 - 62 us
-        // each): the two classifiers' GEMMs side by side, the hr one on the caller's side stream if it gave one (surs_set_side_stream)
-        SideLane *lane2 = ncp <= 1024 ? side_lane() : nullptr;
-        if (lane2) {
-            SURS_HIP_CHECK(hipEventRecord(lane2->fork, st));
-            SURS_HIP_CHECK(hipStreamWaitEvent(lane2->s, lane2->fork, 0));
-        }
+        if (ncp <= 1024 && option(OPT_RVEC_SMALL)) {
+            // small batches (the ~ 100 runs of a point-runs call, small slabs, coarse octree levels): both classifiers in one launch of
+            // 64-point x 128-row workgroups (rvec_small_kernel: the same bits as the 256 x 256-tile GEMM below, 4 - 6 workgroups of which
+            // walk K = 1024 in 34 - 62 us each here)
+            RvecSmallArgs ra;
+            for (int m = 0; m < 2; ++m) {
+                const int nvec = m ? 3 : 2;
+                ra.w[m] = (const unsigned short *)(blob + (rparts == 3 ? h.wt3[m][1] : h.wt2[m][1]));
+                ra.g[m] = m ? g_hr : g_lr;
+                ra.g_part[m] = m ? part_hr : part_lr;
+                ra.npm[m] = (long long)nvec * ncp;
+                ra.r[m] = m ? r_hr : r_lr;
+            }
+            ra.wgs0 = (int)(ra.npm[0] / 64) * 4;
+            const unsigned wgs = (unsigned)(ra.wgs0 + (ra.npm[1] / 64) * 4);
+            if (rparts == 1) hipLaunchKernelGGL(rvec_small_kernel<1>, dim3(wgs), dim3(256), 0, st, ra);
+            else if (rparts == 2) hipLaunchKernelGGL(rvec_small_kernel<2>, dim3(wgs), dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL(rvec_small_kernel<3>, dim3(wgs), dim3(256), 0, st, ra);
+            SURS_LAUNCH_CHECK();
+        } else
         for (int m = 0; m < 2; ++m) {
-            hipStream_t st = (m == 1 && lane2) ? lane2->s : cs.st;
             const int nvec = m ? 3 : 2;
             const long long npm = (long long)nvec * ncp;
             SplitSeg s1 = {m ? g_hr : g_lr, m ? part_hr : part_lr, D1 / 16}, s2 = {nullptr, 0, 0};
@@ -1456,10 +1441,6 @@ static int run_column_batch(const ColumnSweep &cs, const PointSource &src, long 
                                    st, (const unsigned short *)(blob + h.wt3[m][1]), D2, D1, s1, s2, npm, (const float *)zero_bias, R,
                                    (long long)D2, (unsigned short *)nullptr, 0LL, nb256);
             SURS_LAUNCH_CHECK();
-        }
-        if (lane2) {
-            SURS_HIP_CHECK(hipEventRecord(lane2->join, lane2->s));
-            SURS_HIP_CHECK(hipStreamWaitEvent(st, lane2->join, 0));
         }
         a.rvec_lr = r_lr;
         a.rvec_hr = r_hr;

@@ -490,31 +490,21 @@ def query_points_columns(points, calib, zmul, zdiv, feat_lr, feat_hr, blob, dtyp
     w = ws.get(lib().surs_query_points_columns_workspace_bytes())
     assert feat_lr.ld == feat_lr.c == 256 and feat_hr.ld == feat_hr.c == 64
     ncols = C.c_int(0)
-    # (an existing side stream for the two classifiers' per-run GEMMs: the hourglass's - idle outside the encoder.  Never a new one: a
-    #  stream more in the process shifts the hardware queues of the copy / marching-cubes streams created after it, NOTES R4.4)
-    from . import encoder
-    side = encoder.existing_side_stream()
-    check(lib().surs_set_side_stream(C.c_void_p(side.cuda_stream) if side is not None else None))
-    try:
-        for p0 in range(0, n, POINT_RUNS_CHUNK):
-            nb = min(POINT_RUNS_CHUNK, n - p0)
-            check(lib().surs_query_points_columns(C.c_void_p(points.data_ptr() + 4 * p0), n, nb, cal, float(zmul), float(zdiv),
-                                                  feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
-                                                  code, _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * p0),
-                                                  C.c_void_p(plr.data_ptr() + 4 * p0), C.byref(ncols), _stream()))
-            if ncols.value == 0:
-                if p0 == 0 and nb == n:
-                    return None
-                # this piece holds no runs: the point kernels for it, in the arithmetic the rest of the array gets (one product per
-                # MAC behind --precision bf16 | fp16: the column kernel's pieces are 16-bit there too)
-                with reduced_point_operands(code != DTYPES["fp32"]):
-                    a, b = query_points(points[:, p0:p0 + nb], calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
-                phr[p0:p0 + nb] = a
-                plr[p0:p0 + nb] = b
-    finally:
-        # (the lane is per host thread and outlives the call otherwise: a later small column batch of this thread - an octree level, a
-        #  small slab - on another stream or device would inherit it)
-        lib().surs_set_side_stream(None)
+    for p0 in range(0, n, POINT_RUNS_CHUNK):
+        nb = min(POINT_RUNS_CHUNK, n - p0)
+        check(lib().surs_query_points_columns(C.c_void_p(points.data_ptr() + 4 * p0), n, nb, cal, float(zmul), float(zdiv),
+                                              feat_lr.ptr(), feat_lr.h, feat_lr.w, feat_hr.ptr(), feat_hr.h, feat_hr.w, _ptr(blob),
+                                              code, _ptr(w), w.numel(), C.c_void_p(phr.data_ptr() + 4 * p0),
+                                              C.c_void_p(plr.data_ptr() + 4 * p0), C.byref(ncols), _stream()))
+        if ncols.value == 0:
+            if p0 == 0 and nb == n:
+                return None
+            # this piece holds no runs: the point kernels for it, in the arithmetic the rest of the array gets (one product per
+            # MAC behind --precision bf16 | fp16: the column kernel's pieces are 16-bit there too)
+            with reduced_point_operands(code != DTYPES["fp32"]):
+                a, b = query_points(points[:, p0:p0 + nb], calib, zmul, zdiv, feat_lr, feat_hr, blob, ws)
+            phr[p0:p0 + nb] = a
+            plr[p0:p0 + nb] = b
     return phr, plr
 
 

@@ -575,6 +575,23 @@ def test_point_runs_launches_sized_from_the_previous_call(setup):
             assert g_ is not None and torch.equal(w[0], g_[0]) and torch.equal(w[1], g_[1])
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_small_batch_affine_gemm_equals_the_tiled_gemm_bit_for_bit(setup, dtype):
+    """Batches of <= 1024 columns (a point-runs call: ~ 100 runs) take rvec_small_kernel for R = W1 (g . [a0 | w0z | w0p]) - 64 x 128
+    workgroups reading MFMA fragments straight from the images - instead of four to six workgroups of the 256 x 256-tile GEMM: the same
+    products in the same order, so the predictions must be equal bit for bit (option rvec_small = 0: the tiled kernel)."""
+    nat = setup["native"]
+    pts = _run_points(seed=31, ncols=150, lo=200, hi=500)
+    got = _qc(setup, pts, dtype)
+    nat.set_option("rvec_small", 0)
+    try:
+        want = _qc(setup, pts, dtype)
+    finally:
+        nat.set_option("rvec_small", 1)
+    assert got is not None and want is not None
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
 def test_point_runs_kernel_equals_its_restatement(setup):
     """surs_point_runs (one workgroup: ballots, bit counts, two carries across blocks of 4096 points) against oracle.point_runs
     (plain loops) on ragged runs, runs cut at 4096 points, a chunk cut out of a grid, NaN and -0.0, and an array of singles."""

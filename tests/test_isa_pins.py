@@ -66,6 +66,7 @@ CO_RESIDENT = [r"grid_mlp_kernel_v12<", r"grid_mlp_kernel_v10<", r"grid_mlp_kern
 BEYOND_256 = {
     r"grid_mlp_kernel_v3<": 512, r"grid_mlp_kernel_v5\b": 512,
     r"conv_x3_kernel<3, 2, 4, 32, [12]>": 304, r"conv_x3_kernel<3, 1, 4, 32, 3>": 288,
+    r"rvec_small_kernel<3>": 288,   # (three bf16 parts: the wide-operand retry's; its prefetch ring of fragments)
 }
 
 
