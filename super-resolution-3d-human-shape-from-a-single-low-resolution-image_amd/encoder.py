@@ -374,16 +374,6 @@ def _side_stream(level):
     return st
 
 
-def existing_side_stream():
-    """A side stream of the current stream's hourglass set if the encoder has made one (it is idle outside filter_lr), else None."""
-    cur = torch.cuda.current_stream()
-    for level in (2, 1, 3):
-        st = _side_streams.get((cur.device.index, cur.cuda_stream, level))
-        if st is not None:
-            return st
-    return None
-
-
 def hourglass(W, prefix, depth, x):
     """HourGlass._forward (HGFilters.py:29-74).  The two branches of a level are independent until their sum: the low-resolution
     one (pool -> ConvBlock -> [next level] -> ConvBlock; maps of 128^2 and 64^2 whose kernels fill a fraction of the chip) runs on
