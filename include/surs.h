@@ -310,6 +310,10 @@ int surs_query_points_hr(const float *points, int n, const float *calib, float z
  * (run, z tile) pairs of `tile` = 64 | 128 points (room for 2 n ints), meta[4] = {runs, work items - 0 and no lengths / work items when the
  * array holds more than one run per tile / 4 points -, z ascending violated, z descending violated}.  Device pointers; no synchronisation. */
 int surs_point_runs(const float *points, long long ld, int n, int tile, int *colstart, int *kcount, int *tiles, int *meta, void *stream);
+/* flag[0] (device) = 1 if a[0..n) or b[0..n) (b nullable) holds a NaN or an infinity, else 0: the check behind every query of the host
+ * mirror (an activation beyond the f16 range of the two-part operand split surfaces as NaN; the query is then repeated on three bf16
+ * parts).  One small launch; no synchronisation. */
+int surs_nonfinite(const float *a, const float *b, long long n, int *flag, void *stream);
 size_t surs_query_points_columns_workspace_bytes(void);
 int surs_query_points_columns(const float *points, long long ld, int n, const float *calib, float zmul, float zdiv,
                               const float *feat_lr, int hl, int wl, const float *feat_hr, int hh, int wh, const void *mlp_blob,

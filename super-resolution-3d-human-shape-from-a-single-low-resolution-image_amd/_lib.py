@@ -129,6 +129,7 @@ _SIGS = {
     "surs_query_points_columns": (C.c_int, [_vp, C.c_longlong, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp,
                                             C.POINTER(C.c_int), _vp]),
     "surs_query_points_columns_workspace_bytes": (_sz, []),
+    "surs_nonfinite": (C.c_int, [_vp, _vp, C.c_longlong, _vp, _vp]),
     "surs_point_runs": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "surs_query_points_hr": (C.c_int, [_vp, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "surs_query_points_views": (C.c_int, [_vp, _i, _i, _i, _vp, _f, _f, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp,

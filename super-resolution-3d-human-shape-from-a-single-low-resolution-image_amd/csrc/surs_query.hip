@@ -1978,6 +1978,30 @@ static const int PR_CAP = 4096;       // points per column: a longer run is cut 
 // of the reference's octree levels come as ~ 25 per column; tools/dev/short_runs_time.py), column kernels against layer kernels:
 // fp32-grade 0.87 / 0.70 / 0.63 / 0.55 against 0.94 ms, bf16 0.81 / 0.64 / 0.51 / 0.41 against 0.55 ms.
 static inline __host__ __device__ int pr_min_run(int tile) { return tile / 4; }
+// Do two prediction arrays hold a non-finite value?  One workgroup, one word written (no zeroing in front of it): what the facade asks
+// after every query (an activation beyond the f16 range of the two-part split shows up as NaN: model.SuRSNet._finite_or_wide) - until
+// round 6 two torch reductions and an addition per call.
+__global__ __launch_bounds__(1024) void nonfinite_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n, int *__restrict__ flag) {
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    int bad = 0;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const unsigned ua = __builtin_bit_cast(unsigned, a[i]), ub = b ? __builtin_bit_cast(unsigned, b[i]) : 0u;
+        bad |= ((ua & 0x7f800000u) == 0x7f800000u) | ((ub & 0x7f800000u) == 0x7f800000u);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) any = 1;   // (benign race: every writer writes 1)
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = any;
+}
+
+extern "C" int surs_nonfinite(const float *a, const float *b, long long n, int *flag, void *stream) {
+    SURS_REQUIRE(a && flag && n >= 0, "bad argument");
+    hipLaunchKernelGGL(nonfinite_kernel, dim3(1), dim3(1024), 0, as_stream(stream), a, b, n, flag);
+    SURS_LAUNCH_CHECK();
+    return 0;
+}
+
 static const int PR_THREADS = 1024;
 
 __device__ __forceinline__ int pr_wave_scan_sum(int v, int lane) {   // inclusive, 64 lanes

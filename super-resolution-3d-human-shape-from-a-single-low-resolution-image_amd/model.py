@@ -351,9 +351,12 @@ class SuRSNet:
         synchronisation) are computed again on three bf16 parts - fp32's exponent range -, after re-running the encoder the same
         way if its features are what overflowed."""
         phr, plr = run() if first is None else first
-        # (occupancies lie in [0, 1]: their sum is finite exactly when every one of them is - two reductions and one host
-        #  synchronisation instead of twelve small kernels per call)
-        if math.isfinite((phr.sum() + plr.sum()).item()):
+        # (one small launch and a 4-byte read-back: surs_nonfinite; until round 6 two torch reductions and an addition)
+        if phr.numel() == plr.numel() and phr.dtype == plr.dtype == torch.float32 and phr.is_cuda:
+            finite = not native.any_nonfinite(phr, plr)
+        else:
+            finite = math.isfinite((phr.sum() + plr.sum()).item())
+        if finite:
             return phr, plr
         import warnings
         warnings.warn("query: non-finite predictions from the two-part f16 operand split; repeating on three bf16 parts", stacklevel=3)

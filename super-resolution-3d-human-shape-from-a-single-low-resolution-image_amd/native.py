@@ -467,6 +467,19 @@ def options():
         i += 1
 
 
+def any_nonfinite(a, b=None):
+    """surs_nonfinite: True if the float32 device tensors a / b hold a NaN or an infinity (one small launch, one 4-byte read-back)."""
+    a = _f32c(a.reshape(-1))
+    if b is not None:
+        b = _f32c(b.reshape(-1))
+        assert b.numel() == a.numel()
+    if a.numel() == 0:
+        return False
+    flag = torch.empty(1, dtype=torch.int32, device=a.device)
+    check(lib().surs_nonfinite(_ptr(a), _ptr(b) if b is not None else None, a.numel(), _ptr(flag), _stream()))
+    return bool(flag.item())
+
+
 POINT_RUNS_CHUNK = 262144   # points per surs_query_points_columns call
 
 

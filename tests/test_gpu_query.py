@@ -622,3 +622,27 @@ def test_point_runs_kernel_equals_its_restatement(setup):
     from surs_amd import weights
     check(weights.synthetic_points(5000, seed=3), 64)
     check(_run_points(seed=16, ncols=5000, lo=40, hi=64)[:, :262144], 64)    # the largest call: 64 blocks of 4096 points
+
+
+@pytest.mark.gpu
+def test_nonfinite_flag():
+    """surs_nonfinite (the facade's check after every query): NaN / +-inf anywhere in either array are seen - first element, last
+    element, an odd length; finite arrays (denormals, the largest float) pass; the flag is written, not accumulated."""
+    from surs_amd import native
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n in (1, 63, 1025, 50000, 262144 + 7):
+        a = torch.rand(n, generator=g).to(dev)
+        b = torch.rand(n, generator=g).to(dev)
+        a[0] = torch.finfo(torch.float32).max
+        b[-1] = 1e-45
+        assert native.any_nonfinite(a, b) is False and native.any_nonfinite(a) is False
+        for bad in (float("nan"), float("inf"), float("-inf")):
+            for arr, pos in ((a, 0), (a, n - 1), (b, n // 2), (b, n - 1)):
+                keep = arr[pos].clone()
+                arr[pos] = bad
+                assert native.any_nonfinite(a, b) is True
+                assert native.any_nonfinite(arr) is True
+                arr[pos] = keep
+        assert native.any_nonfinite(a, b) is False
+    assert native.any_nonfinite(torch.empty(0, device=dev)) is False

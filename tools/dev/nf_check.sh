@@ -1,0 +1,2 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for T in 0 1 0 1 0 1; do for P in fp32 bf16; do echo -n "torch check $T: "; LOOP_TORCH_FINITE_CHECK=$T python tools/gpu_points_loop.py $P 80 2>&1 | grep -v "^[EW]20" | tail -1; done; done

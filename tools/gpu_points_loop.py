@@ -8,6 +8,9 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import common
 from surs_amd import model, options, weights, train_util
+if os.environ.get("LOOP_TORCH_FINITE_CHECK") == "1":   # (A/B of surs_nonfinite against the two torch reductions it replaced, NOTES R6.8)
+    from surs_amd import native
+    native.any_nonfinite = lambda a, b: not bool(torch.isfinite(a.sum() + b.sum()).item())
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 nch = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 dev = torch.device("cuda:0")
