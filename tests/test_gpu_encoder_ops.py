@@ -38,6 +38,7 @@ def _chw(img):
     (32, 64, 33, 47, 3, 2, True),     # stride 2 on the split-f16 kernel, odd sizes (ragged tiles, the last row / column padded)
     (16, 32, 18, 22, 3, 2, False),
     (3, 32, 5, 130, 3, 1, False),     # direct 3 -> 32 kernel: eight lanes per pixel, pixel count not a multiple of 32
+    (3, 32, 32, 96, 3, 1, True),      # ... its whole-tile form (16 rows x 32 pixels per workgroup, the window sliding down in registers)
     (32, 3, 7, 9, 3, 1, False),       # direct 32 -> 3 kernel
     (6, 32, 12, 12, 3, 1, True),      # neither: the fp32 MFMA kernel
 ])
@@ -51,6 +52,29 @@ def test_conv(env, cin, cout, h, w, k, stride, bias):
     y = _chw(nat.conv2d(_img(env, x), cw, stride=stride))
     assert y.shape == ref.shape
     assert common.rel_err(y, ref) < 2e-5
+
+
+def test_head_conv_whole_tile_kernel_equals_the_per_pixel_kernel(env):
+    """conv3x3_3to32_rows_kernel (maps of whole 16 x 32 tiles: the super-resolution net's head at 2H x 2W) against
+    conv3x3_3to32_kernel (any size) on the same data: the interior of a 48 x 64 map computed by the tile kernel equals, bit for
+    bit, the same pixels computed by the per-pixel kernel on the map padded to 49 x 64 by a zero row (which zero padding supplies
+    anyway) - LeakyReLU, bias, residual and a channel slice of a wider output included."""
+    nat = env["native"]
+    h, w = 48, 64
+    x = prng.uniform("hx", 11, (3, h, w), -1, 1)
+    wt = prng.uniform("hw", 12, (32, 3, 3, 3), -0.2, 0.2)
+    b = prng.uniform("hb", 13, (32,), -0.5, 0.5)
+    res = prng.uniform("hr", 14, (32, h, w), -1, 1)
+    cw = nat.ConvWeights(wt, b, env["dev"])
+    wide = nat.Img(h, w, 64, device=env["dev"])
+    wide.buf.zero_()
+    nat.conv2d(_img(env, x), cw, out=wide.slice(32, 32), act=1, slope=0.2, residual=_img(env, res))
+    tile = _chw(wide)
+    assert np.all(tile[:32] == 0)
+    xp = np.concatenate([x, np.zeros((3, 1, w), np.float32)], 1)
+    rp = np.concatenate([res, np.zeros((32, 1, w), np.float32)], 1)
+    pix = _chw(nat.conv2d(_img(env, xp), cw, act=1, slope=0.2, residual=_img(env, rp)))
+    assert np.array_equal(tile[32:], pix[:, :h])
 
 
 def test_conv_fused_groupnorm_relu_lrelu_residual_slice(env):
