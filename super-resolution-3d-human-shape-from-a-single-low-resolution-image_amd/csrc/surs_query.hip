@@ -1981,15 +1981,37 @@ static inline __host__ __device__ int pr_min_run(int tile) { return tile / 4; }
 // Do two prediction arrays hold a non-finite value?  One workgroup, one word written (no zeroing in front of it): what the facade asks
 // after every query (an activation beyond the f16 range of the two-part split shows up as NaN: model.SuRSNet._finite_or_wide) - until
 // round 6 two torch reductions and an addition per call.
+__device__ __forceinline__ int nonfinite_bits(unsigned u) { return (u & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ int nonfinite_bits(const u32x4 &v) {
+    return nonfinite_bits(v[0]) | nonfinite_bits(v[1]) | nonfinite_bits(v[2]) | nonfinite_bits(v[3]);
+}
+// (one workgroup is a latency chain: VEC = 16-byte loads, eight of them in flight per lane - 19 -> 6 us for two arrays of 50 000)
+template <bool VEC>
 __global__ __launch_bounds__(1024) void nonfinite_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n, int *__restrict__ flag) {
     __shared__ int any;
     if (threadIdx.x == 0) any = 0;
     __syncthreads();
     int bad = 0;
-    for (long long i = threadIdx.x; i < n; i += 1024) {
-        const unsigned ua = __builtin_bit_cast(unsigned, a[i]), ub = b ? __builtin_bit_cast(unsigned, b[i]) : 0u;
-        bad |= ((ua & 0x7f800000u) == 0x7f800000u) | ((ub & 0x7f800000u) == 0x7f800000u);
+    const unsigned *ua = reinterpret_cast<const unsigned *>(a), *ub = reinterpret_cast<const unsigned *>(b);
+    long long done = 0;
+    if (VEC) {
+        const long long n4 = n >> 2;
+        const u32x4 *a4 = reinterpret_cast<const u32x4 *>(a), *b4 = reinterpret_cast<const u32x4 *>(b);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (long long i = threadIdx.x; i < n4; i += 4096) {
+            u32x4 va[4], vb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long j = i + 1024 * k;
+                va[k] = j < n4 ? a4[j] : zero;
+                vb[k] = (b && j < n4) ? b4[j] : zero;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= nonfinite_bits(va[k]) | nonfinite_bits(vb[k]);
+        }
+        done = n4 << 2;
     }
+    for (long long i = done + threadIdx.x; i < n; i += 1024) bad |= nonfinite_bits(ua[i]) | (b ? nonfinite_bits(ub[i]) : 0);
     if (__ballot(bad) && (threadIdx.x & 63) == 0) any = 1;   // (benign race: every writer writes 1)
     __syncthreads();
     if (threadIdx.x == 0) *flag = any;
@@ -1997,7 +2019,9 @@ __global__ __launch_bounds__(1024) void nonfinite_kernel(const float *__restrict
 
 extern "C" int surs_nonfinite(const float *a, const float *b, long long n, int *flag, void *stream) {
     SURS_REQUIRE(a && flag && n >= 0, "bad argument");
-    hipLaunchKernelGGL(nonfinite_kernel, dim3(1), dim3(1024), 0, as_stream(stream), a, b, n, flag);
+    const bool vec = ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(nonfinite_kernel<true>, dim3(1), dim3(1024), 0, as_stream(stream), a, b, n, flag);
+    else hipLaunchKernelGGL(nonfinite_kernel<false>, dim3(1), dim3(1024), 0, as_stream(stream), a, b, n, flag);
     SURS_LAUNCH_CHECK();
     return 0;
 }

@@ -645,4 +645,8 @@ def test_nonfinite_flag():
                 assert native.any_nonfinite(arr) is True
                 arr[pos] = keep
         assert native.any_nonfinite(a, b) is False
+        if n > 1:   # (views that do not start on 16 bytes: the scalar form of the kernel)
+            assert native.any_nonfinite(a[1:], b[1:]) is False
+            b[-1] = float("inf")
+            assert native.any_nonfinite(a[1:], b[1:]) is True and native.any_nonfinite(a[:-1], b[:-1]) is False
     assert native.any_nonfinite(torch.empty(0, device=dev)) is False
