@@ -668,6 +668,14 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
     asm volatile("" : "+v"(v));
     return v;
 }
+// The lane index made on the spot (two VALU instructions, no input register): for per-lane values that are needed at the END of a long
+// item - derived from the copy made at its start they stay live across it and are spilled, with a scratch store per item (round 6:
+// the output pointer and `lane & 31` of kernel v12 were 0.4 GB of HBM writes per launch).
+__device__ __forceinline__ unsigned fresh_lane() {
+    unsigned v;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v));
+    return v;
+}
 
 #include "surs_grid_v3.inc"
 #include "surs_grid_v5.inc"
