@@ -91,7 +91,7 @@ def test_register_budgets(kernels):
 
 
 # scratch bytes per lane the column kernels ship with (profiles/pmc_summary.json: scratch_bytes_per_lane); lower is fine, more is not
-SCRATCH = {r"grid_mlp_kernel_v12<1>": 0, r"grid_mlp_kernel_v12<2>": 8, r"grid_mlp_kernel_v10<": 56, r"grid_mlp_kernel_v11\b": 0, r"grid_mlp_kernel_v3<": 28,
+SCRATCH = {r"grid_mlp_kernel_v12<": 0, r"grid_mlp_kernel_v10<": 0, r"grid_mlp_kernel_v11\b": 0, r"grid_mlp_kernel_v3<": 28,
            r"grid_mlp_kernel_v5\b": 0}
 
 
